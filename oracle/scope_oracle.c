@@ -1,0 +1,310 @@
+/*
+ * scope_oracle.c -- CPU restatement of obs-color-monitor's scope-accumulation path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see scope_oracle.h).  PARITY STATUS: "parity unpinned".
+ *
+ * Build with -ffp-contract=off: K0 must not be FMA-contracted.
+ * Citations are relative to /root/reference.
+ */
+#include "scope_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- K0 ---- */
+
+struct k0_matrix {
+	float u[3], y[3], v[3]; /* coefficients of r, g, b */
+};
+
+/* data/common.effect:27-29 (601) and :38-40 (709) */
+static const struct k0_matrix k0_bt601 = {
+	{-0.147643f, -0.289855f, +0.437500f},
+	{+0.299000f, +0.587000f, +0.114000f},
+	{+0.437500f, -0.366351f, -0.071147f},
+};
+static const struct k0_matrix k0_bt709 = {
+	{-0.100643f, -0.338571f, +0.439216f},
+	{+0.212600f, +0.715200f, +0.072200f},
+	{+0.439216f, -0.398941f, -0.040273f},
+};
+
+/* FLOAT -> UNORM8 store rule pinned by this build (the reference leaves it to the GPU). */
+static uint8_t k0_quantise(float x)
+{
+	if (!(x > 0.0f))
+		x = 0.0f;
+	else if (x > 1.0f)
+		x = 1.0f;
+	return (uint8_t)floorf(x * 255.0f + 0.5f);
+}
+
+/* One texel: in B,G,R,A bytes -> out U,Y,V,255 bytes.
+ * common.effect samples rgb.x=R, rgb.y=G, rgb.z=B and returns float4(V,Y,U,1) into a
+ * BGRA target, so memory byte0 = .z = U, byte1 = .y = Y, byte2 = .x = V, byte3 = 255. */
+static void k0_texel(const struct k0_matrix *m, const uint8_t *in, uint8_t *out)
+{
+	const float r = (float)in[2] / 255.0f;
+	const float g = (float)in[1] / 255.0f;
+	const float b = (float)in[0] / 255.0f;
+
+	/* a*r - c*g == a*r + (-c)*g exactly in IEEE, so signed coefficients keep the
+	 * left-to-right order of the shader expression. */
+	float u = m->u[0] * r;
+	u = u + m->u[1] * g;
+	u = u + m->u[2] * b;
+	u = u + 0.5f;
+	u = u - 1.0f / 256.0f;
+
+	float y = m->y[0] * r;
+	y = y + m->y[1] * g;
+	y = y + m->y[2] * b;
+
+	float v = m->v[0] * r;
+	v = v + m->v[1] * g;
+	v = v + m->v[2] * b;
+	v = v + 0.5f;
+
+	out[0] = k0_quantise(u);
+	out[1] = k0_quantise(y);
+	out[2] = k0_quantise(v);
+	out[3] = 255;
+}
+
+void oracle_rgb_to_yuv(const uint8_t *rgb, uint32_t rgb_linesize, uint8_t *yuv, uint32_t yuv_linesize,
+		       uint32_t width, uint32_t height, int colorspace)
+{
+	/* src/common.c:207-208: colorspace == 1 picks 601, everything else 709 */
+	const struct k0_matrix *m = colorspace == 1 ? &k0_bt601 : &k0_bt709;
+	for (uint32_t row = 0; row < height; row++) {
+		const uint8_t *in = rgb + (size_t)rgb_linesize * row;
+		uint8_t *out = yuv + (size_t)yuv_linesize * row;
+		for (uint32_t col = 0; col < width; col++)
+			k0_texel(m, in + 4 * col, out + 4 * col);
+	}
+}
+
+/* ---------------------------------------------------------------- K1 ---- */
+
+static inline void sat_inc_u8(uint8_t *cell)
+{
+	/* inc_uint8, src/waveform.c:201-205; same test inline at src/vectorscope.c:233-234 */
+	const unsigned n = *cell;
+	*cell = (uint8_t)(n + (n < 255));
+}
+
+void oracle_vectorscope(uint8_t *out, const struct oracle_surface *sd)
+{
+	memset(out, 0, 256 * 256); /* vectorscope.c:219-220 */
+	if (!sd->yuv_data)
+		return; /* guard lives in vss_surface_cb, vectorscope.c:252 */
+	for (uint32_t row = 0; row < sd->height; row++) {
+		const uint8_t *px = sd->yuv_data + (size_t)sd->linesize * row; /* vd_add, :225,236 */
+		for (uint32_t col = 0; col < sd->width; col++, px += 4) {
+			const unsigned u = px[0], v = px[2];       /* :228-230, alpha not read */
+			sat_inc_u8(&out[u + 256u * (255u - v)]); /* :232-234 */
+		}
+	}
+}
+
+/* ---------------------------------------------------------- plane pick -- */
+
+/* waveform.c:228-234 == histogram.c:367-373: any low-nibble bit selects the RGB plane,
+ * else any of bits 4-6 selects the YUV plane, else nothing. */
+static const uint8_t *pick_plane(const struct oracle_surface *sd, uint32_t components)
+{
+	if (components & 0x07)
+		return sd->rgb_data;
+	if (components & 0x70)
+		return sd->yuv_data;
+	return 0;
+}
+
+/* ---------------------------------------------------------------- K2 ---- */
+
+void oracle_waveform(uint8_t *out, const struct oracle_surface *sd, uint32_t components)
+{
+	const size_t rowbytes = (size_t)sd->width * 4;
+	memset(out, 0, rowbytes * 256); /* waveform.c:225-226 */
+
+	const uint8_t *plane = pick_plane(sd, components);
+	if (!plane)
+		return; /* :233-234 */
+
+	/* :236-238 -- bit c or bit c+4 enables byte c of the texel */
+	int on[3];
+	for (int c = 0; c < 3; c++)
+		on[c] = (components & (0x11u << c)) != 0;
+
+	for (uint32_t row = 0; row < sd->height; row++) {
+		const uint8_t *px = plane + (size_t)sd->linesize * row; /* :241 */
+		for (uint32_t col = 0; col < sd->width; col++, px += 4) {
+			if (px[3] == 0)
+				continue; /* :247-248 */
+			for (int c = 0; c < 3; c++)
+				if (on[c]) /* :249-254 */
+					sat_inc_u8(out + (255u - px[c]) * rowbytes + (size_t)col * 4 + c);
+		}
+	}
+}
+
+/* ---------------------------------------------------------------- K3 ---- */
+
+int oracle_histogram_counts(uint32_t *counts, const struct oracle_surface *sd, uint32_t components)
+{
+	memset(counts, 0, 1024 * sizeof(uint32_t)); /* histogram.c:363-365 */
+
+	const uint8_t *plane = pick_plane(sd, components);
+	if (!plane)
+		return 0; /* :372-373 */
+
+	const int on_b = (components & 0x11) != 0; /* :375-377 */
+	const int on_g = (components & 0x22) != 0;
+	const int on_r = (components & 0x44) != 0;
+
+	for (uint32_t row = 0; row < sd->height; row++) {
+		const uint8_t *px = plane + (size_t)sd->linesize * row; /* :380 */
+		for (uint32_t col = 0; col < sd->width; col++, px += 4) {
+			if (px[3] == 0)
+				continue; /* :386-387 */
+			/* :388-393 -- slot order is R,G,B: byte2 -> slot0, byte1 -> slot1, byte0 -> slot2 */
+			if (on_r)
+				counts[px[2] * 4 + 0] += 1;
+			if (on_g)
+				counts[px[1] * 4 + 1] += 1;
+			if (on_b)
+				counts[px[0] * 4 + 2] += 1;
+		}
+	}
+	return 1;
+}
+
+/* --------------------------------------------------------------- K3b ---- */
+
+void oracle_histogram_level(uint8_t *tex_buf, uint32_t *hi_max, uint32_t width, uint32_t height, uint32_t components,
+			    int logscale, int level_fixed_value, int level_ratio_value)
+{
+	uint32_t cnt[1024];
+	memcpy(cnt, tex_buf, sizeof cnt);
+
+	/* histogram.c:397-402 */
+	if (level_fixed_value > 0 || level_ratio_value > 0) {
+		uint32_t lvl = level_fixed_value > 0
+				       ? (uint32_t)level_fixed_value
+				       : (uint32_t)((uint64_t)width * height * (uint64_t)level_ratio_value / 1000);
+		if (lvl == 0)
+			lvl = 1; /* his_fix_max_level, :349-355 */
+		hi_max[0] = hi_max[1] = hi_max[2] = lvl;
+	} else {
+		/* his_calculate_max, :330-347; index 0=R (0x44), 1=G (0x22), 2=B (0x11) */
+		for (int j = 0; j < 3; j++) {
+			uint32_t best = 1;
+			if (components & (0x44u >> j))
+				for (int i = 0; i < 256; i++)
+					if (cnt[i * 4 + j] > best)
+						best = cnt[i * 4 + j];
+			hi_max[j] = best;
+		}
+	}
+
+	float flt[1024];
+	memcpy(flt, cnt, sizeof flt); /* disabled channels keep their raw bit pattern in logscale */
+	if (logscale) {
+		/* :405-413 */
+		for (int j = 0; j < 3; j++) {
+			if (!(components & (0x44u >> j)))
+				continue;
+			const float s = 1.0f / logf((float)(hi_max[j] + 1));
+			for (int i = 0; i < 256; i++) {
+				const uint32_t n = cnt[i * 4 + j];
+				flt[i * 4 + j] = n ? logf((float)(n + 1)) * s : 0.0f;
+			}
+			hi_max[j] = 1;
+		}
+	} else {
+		/* :414-417 */
+		for (int i = 0; i < 1024; i++)
+			flt[i] = (float)cnt[i];
+	}
+	memcpy(tex_buf, flt, sizeof flt);
+}
+
+void oracle_histogram(uint8_t *tex_buf, uint32_t *hi_max, const struct oracle_surface *sd, uint32_t components,
+		      int logscale, int level_fixed_value, int level_ratio_value)
+{
+	uint32_t cnt[1024];
+	const int counted = oracle_histogram_counts(cnt, sd, components);
+	memcpy(tex_buf, cnt, sizeof cnt);
+	if (!counted)
+		return; /* histogram.c:372-373 returns before the level pass; hi_max untouched */
+	oracle_histogram_level(tex_buf, hi_max, sd->width, sd->height, components, logscale, level_fixed_value,
+			       level_ratio_value);
+}
+
+/* ------------------------------------------------------- test inputs ---- */
+
+static inline uint64_t xorshift64(uint64_t *s)
+{
+	uint64_t x = *s;
+	x ^= x << 13;
+	x ^= x >> 7;
+	x ^= x << 17;
+	return *s = x;
+}
+
+void oracle_fill_frame(uint8_t *dst, uint32_t linesize, uint32_t width, uint32_t height, int dist, uint64_t seed)
+{
+	static const uint8_t bars[8][3] = {
+		/* B, G, R : white yellow cyan green magenta red blue black at 75 % */
+		{191, 191, 191}, {0, 191, 191}, {191, 191, 0}, {0, 191, 0},
+		{191, 0, 191},   {0, 0, 191},   {191, 0, 0},   {0, 0, 0},
+	};
+	uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
+	for (uint32_t row = 0; row < height; row++) {
+		uint8_t *p = dst + (size_t)linesize * row;
+		for (uint32_t col = 0; col < width; col++, p += 4) {
+			const uint64_t r = xorshift64(&s);
+			switch (dist) {
+			default:
+			case 1:
+			case 5:
+				p[0] = (uint8_t)r;
+				p[1] = (uint8_t)(r >> 8);
+				p[2] = (uint8_t)(r >> 16);
+				break;
+			case 2:
+				p[0] = (uint8_t)(120 + (r & 15));
+				p[1] = (uint8_t)(120 + ((r >> 8) & 15));
+				p[2] = (uint8_t)(120 + ((r >> 16) & 15));
+				break;
+			case 3:
+				p[0] = 0xD7;
+				p[1] = 0xCC;
+				p[2] = 0xC6;
+				break;
+			case 4: {
+				const uint32_t bar = (uint32_t)((uint64_t)col * 8 / width);
+				p[0] = bars[bar][0];
+				p[1] = bars[bar][1];
+				p[2] = bars[bar][2];
+			} break;
+			}
+			p[3] = 255;
+			if (dist == 5 && (((row >> 4) ^ (col >> 4)) & 1))
+				p[3] = 0;
+		}
+		for (uint32_t k = width * 4; k < linesize; k++)
+			dst[(size_t)linesize * row + k] = 0xA5;
+	}
+}
+
+uint64_t oracle_fnv1a64(const void *data, uint64_t len)
+{
+	const uint8_t *p = data;
+	uint64_t h = 0xcbf29ce484222325ull;
+	for (uint64_t i = 0; i < len; i++) {
+		h ^= p[i];
+		h *= 0x100000001b3ull;
+	}
+	return h;
+}

@@ -1,0 +1,80 @@
+/*
+ * scope_oracle.h -- CPU restatement of obs-color-monitor's scope-accumulation path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (obs-color-monitor_amd/,
+ * include/) may include, link or call this.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker / reported baseline.
+ *
+ * PARITY STATUS: "parity unpinned".  The reference ships no golden vectors or
+ * known-answer tests for this path, and its sources cannot be
+ * built in this image without stand-ins for libobs headers (obs-module.h is absent),
+ * so no reference-produced outputs exist to pin this restatement against.  It is
+ * written from the reference's semantics, function by function, with each function
+ * citing the reference file:line it follows, and it is cross-checked against an
+ * independently written numpy restatement (oracle/scope_oracle.py) and against
+ * hand-derived known answers (tests/test_oracle.py).
+ *
+ * All citations are relative to /root/reference (obs-color-monitor v0.9.5).
+ */
+#ifndef SCOPE_ORACLE_H
+#define SCOPE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Frame descriptor handed to every reduction.  Field-for-field the meaning of
+ * struct cm_surface_data (src/common.h:24-30) minus the unused `tex`. */
+struct oracle_surface {
+	const uint8_t *rgb_data; /* BGRA8 rows: bytes B,G,R,A  (may be NULL) */
+	const uint8_t *yuv_data; /* BGRA8 rows: bytes U,Y,V,255 (may be NULL) */
+	uint32_t linesize;       /* row pitch in bytes, >= 4*width */
+	uint32_t width, height;
+	int colorspace;          /* 1 = BT.601, anything else = BT.709 (src/common.c:207-208) */
+};
+
+/* K0: RGB -> Y'CbCr, data/common.effect:23-43 driven by src/common.c:202-213.
+ * fp32, terms summed left to right as written, no FMA contraction; the
+ * FLOAT->UNORM8 store (left to the GPU by the reference) is pinned here to
+ * floor(clamp(x,0,1)*255 + 0.5).  In: bytes B,G,R,A.  Out: bytes U,Y,V,255. */
+void oracle_rgb_to_yuv(const uint8_t *rgb, uint32_t rgb_linesize, uint8_t *yuv, uint32_t yuv_linesize,
+		       uint32_t width, uint32_t height, int colorspace);
+
+/* K1: vss_draw_vectorscope, src/vectorscope.c:217-238.  out = uint8[256][256]. */
+void oracle_vectorscope(uint8_t *out, const struct oracle_surface *sd);
+
+/* K2: wvs_draw_waveform, src/waveform.c:220-257 (+ inc_uint8 :201-205).
+ * out = uint8[256][width][4]. */
+void oracle_waveform(uint8_t *out, const struct oracle_surface *sd, uint32_t components);
+
+/* K3: counting part of his_draw_histogram, src/histogram.c:357-395.
+ * counts = uint32[256][4], slots R,G,B,unused.  Returns 0 when no plane was
+ * selectable (the reference returns early there, histogram.c:372-373), else 1. */
+int oracle_histogram_counts(uint32_t *counts, const struct oracle_surface *sd, uint32_t components);
+
+/* K3 + K3b: the whole of his_draw_histogram, src/histogram.c:357-418 with
+ * his_calculate_max / his_fix_max_level (:330-355).  tex_buf = 4096 bytes that
+ * end up holding float[256][4]; hi_max = uint32[3]. */
+void oracle_histogram(uint8_t *tex_buf, uint32_t *hi_max, const struct oracle_surface *sd, uint32_t components,
+		      int logscale, int level_fixed_value, int level_ratio_value);
+
+/* K3b alone, applied in place to an already counted table (used to check the
+ * host-side post-pass of the product, which receives exact counts from the GPU). */
+void oracle_histogram_level(uint8_t *tex_buf, uint32_t *hi_max, uint32_t width, uint32_t height, uint32_t components,
+			    int logscale, int level_fixed_value, int level_ratio_value);
+
+/* Deterministic frame generator shared by tests and bench (xorshift64).
+ * dist: 1 uniform, 2 concentrated (128 + U{-8..7}), 3 flat (R,G,B)=(0xC6,0xCC,0xD7),
+ *       4 eight vertical colour bars, 5 uniform with alpha==0 on a 16x16 checker.
+ * Padding bytes between 4*width and linesize are filled with 0xA5. */
+void oracle_fill_frame(uint8_t *dst, uint32_t linesize, uint32_t width, uint32_t height, int dist, uint64_t seed);
+
+/* FNV-1a 64 over a byte buffer (fixture hashes for large tables). */
+uint64_t oracle_fnv1a64(const void *data, uint64_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
