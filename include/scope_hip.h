@@ -1,0 +1,173 @@
+/*
+ * scope_hip.h -- C-ABI of libscope_hip.so, the MI355X (gfx950) implementation of
+ * obs-color-monitor's scope-accumulation path.
+ *
+ * Plain C: opaque context, plain pointers and sizes, int status codes; no C++ or torch types
+ * cross this boundary and nothing here throws or aborts.  Each entry point names the reference
+ * interface it replaces (file:line relative to the obs-color-monitor source tree, v0.9.5).
+ *
+ * What the library replaces: the reference stages the converted frame to host memory
+ * (gs_stage_texture + gs_stagesurface_map, src/common.c:316-347) and then runs one scalar CPU
+ * loop per scope on the plugin's "color-monitor" thread (src/common.c:366-368 calling
+ * vss_draw_vectorscope / wvs_draw_waveform / his_draw_histogram).  Here the frame is reduced on
+ * the GPU and only the small result tables come back.
+ *
+ * Threading: a scope_ctx may be used from any thread, one call at a time per context (the
+ * reference's pipeline thread is exactly that, src/common.c:375-403).  Every entry point selects
+ * the context's device itself; no current-device state is assumed.
+ *
+ * Errors: every int-returning function returns SCOPE_OK (0) or a negative SCOPE_E* code and
+ * leaves the output buffers untouched on failure (the reference's callbacks are void and keep
+ * the previous table on screen when something fails, src/vectorscope.c:252, src/common.c:349-350).
+ */
+#ifndef SCOPE_HIP_H
+#define SCOPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCOPE_ABI_VERSION 1
+
+/* ---- status codes (negative errno style) -------------------------------------------------- */
+#define SCOPE_OK 0
+#define SCOPE_EINVAL (-22)  /* bad argument (NULL, zero size, misaligned device pointer, ...) */
+#define SCOPE_ENOMEM (-12)  /* host or device allocation failed */
+#define SCOPE_ENODEV (-19)  /* no usable HIP device */
+#define SCOPE_EIO (-5)      /* a HIP runtime call failed; see scope_last_error() */
+#define SCOPE_ENODATA (-61) /* the plane the scope needs is NULL: nothing was done */
+
+/* ---- flags -------------------------------------------------------------------------------- */
+#define SCOPE_IN_DEVICE 0x1u  /* plane pointers are device (HBM) pointers; default: host */
+#define SCOPE_OUT_DEVICE 0x2u /* result pointers are device pointers; default: host */
+#define SCOPE_ASYNC 0x4u      /* enqueue only; only valid with IN_DEVICE|OUT_DEVICE; scope_ctx_sync() later */
+#define SCOPE_FUSE_K0 0x8u    /* yuv_data is NULL: derive Y'CbCr from rgb_data inside the kernel (K0 fused) */
+
+/* ---- component masks, identical to the reference ------------------------------------------- */
+#define SCOPE_COMP_RGB 0x07u /* src/waveform.c:26, src/histogram.c:27 */
+#define SCOPE_COMP_Y 0x20u   /* src/waveform.c:27 */
+#define SCOPE_COMP_UV 0x50u  /* src/waveform.c:28 */
+#define SCOPE_COMP_YUV 0x70u /* src/waveform.c:29 */
+
+#define SCOPE_VS_SIZE 256 /* src/vectorscope.c:26 */
+#define SCOPE_WV_SIZE 256 /* src/waveform.c:20 */
+#define SCOPE_HI_SIZE 256 /* src/histogram.c:20 */
+
+typedef struct scope_ctx scope_ctx;
+
+/* Frame descriptor.  Field-for-field struct cm_surface_data (src/common.h:24-30), so a
+ * `struct cm_surface_data *` may be passed as is.  Planes are BGRA8 rows: rgb_data bytes
+ * B,G,R,A; yuv_data bytes U,Y,V,255 (data/common.effect:23-43).  linesize >= 4*width. */
+struct scope_surface_data {
+	uint8_t *rgb_data, *yuv_data;
+	uint32_t linesize, width, height;
+	int colorspace; /* 1 = BT.601, otherwise BT.709 (src/common.c:207-208) */
+	void *tex;      /* unused, as in the reference */
+};
+
+/* A batch of same-geometry planes (several sources, or a queue of frames of one source:
+ * the reference's 3-slot ring, src/common.h:46).  planes[i] is one BGRA8 plane. */
+struct scope_batch {
+	const uint8_t *const *planes;
+	uint32_t n_frames;
+	uint32_t linesize, width, height;
+	int planes_are_rgb; /* 0: planes hold U,Y,V,255; 1: planes hold B,G,R,A */
+	int colorspace;     /* used when K0 is fused */
+};
+
+struct scope_device_info {
+	char name[128];
+	char arch[32];
+	int device;
+	int compute_units;
+	int lds_bytes_per_cu;
+	int clock_khz;
+	uint64_t hbm_bytes;
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device`; owns a stream and grow-only device scratch. */
+int scope_ctx_create(int device, scope_ctx **out);
+void scope_ctx_destroy(scope_ctx *ctx);
+/* Run on the caller's hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+int scope_ctx_set_stream(scope_ctx *ctx, void *hip_stream);
+void *scope_ctx_get_stream(scope_ctx *ctx);
+int scope_ctx_sync(scope_ctx *ctx);
+int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
+/* Tunables for A/B measurements: "vss.merge" 0|1|2, "vss.unroll" 2|4|8, "his.unroll" 2|4|8,
+ * "wvs.unroll" 4|8|16, "slices" (0 = automatic partition of a frame over workgroups). */
+int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value);
+const char *scope_strerror(int status);
+const char *scope_last_error(scope_ctx *ctx);
+int scope_abi_version(void);
+
+/* ---- K0: RGB -> Y'CbCr plane ---------------------------------------------------------------
+ * Replaces the ConvertRGB_YUV601/709 pass of render_rgb_yuv (src/common.c:202-213,
+ * data/common.effect:23-61).  rgb and yuv are both host or both device (SCOPE_IN_DEVICE). */
+int scope_convert_rgb_yuv(scope_ctx *ctx, const uint8_t *rgb, uint32_t rgb_linesize, uint8_t *yuv,
+			  uint32_t yuv_linesize, uint32_t width, uint32_t height, int colorspace, uint32_t flags);
+
+/* ---- K1: vectorscope -----------------------------------------------------------------------
+ * Replaces vss_draw_vectorscope(dbuf, surface_data) (src/vectorscope.c:217-238).
+ * out = uint8[256][256].  Needs sd->yuv_data, or sd->rgb_data with SCOPE_FUSE_K0. */
+int scope_vectorscope(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t flags, uint8_t *out);
+
+/* ---- K2: waveform --------------------------------------------------------------------------
+ * Replaces wvs_draw_waveform(src, dbuf, surface_data) (src/waveform.c:220-257);
+ * `components` is src->components.  out = uint8[256][width][4]. */
+int scope_waveform(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, uint32_t flags,
+		   uint8_t *out);
+
+/* ---- K3: histogram counts ------------------------------------------------------------------
+ * The counting loop of his_draw_histogram (src/histogram.c:357-395).
+ * counts = uint32[256][4], slots R,G,B,unused. */
+int scope_histogram_counts(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, uint32_t flags,
+			   uint32_t *counts);
+
+/* ---- K3 + K3b: the whole of his_draw_histogram ---------------------------------------------
+ * Replaces his_draw_histogram(src, tex_buf, hi_max, surface_data) (src/histogram.c:357-418):
+ * counts on the GPU, then level + float/log conversion on the host with the C library's logf,
+ * as the reference does.  tex_buf = 4096 host bytes (float[256][4] on return), hi_max = uint32[3].
+ * SCOPE_OUT_DEVICE is not accepted here. */
+int scope_histogram(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, int logscale,
+		    int level_fixed_value, int level_ratio_value, uint32_t flags, uint8_t *tex_buf, uint32_t *hi_max);
+
+/* K3b alone on the host: his_calculate_max / his_fix_max_level / float conversion
+ * (src/histogram.c:330-355,397-417), in place on a counted table. */
+void scope_histogram_level(uint8_t *tex_buf, uint32_t *hi_max, uint32_t width, uint32_t height, uint32_t components,
+			   int logscale, int level_fixed_value, int level_ratio_value);
+
+/* ---- batched forms (one launch for up to 64 frames, any n_frames accepted) ------------------
+ * out tables are contiguous: uint8[n][65536], uint8[n][256][width][4], uint32[n][1024]. */
+int scope_vectorscope_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t flags, uint8_t *out);
+int scope_waveform_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
+			 uint8_t *out);
+int scope_histogram_counts_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
+				 uint32_t *counts);
+
+/* ---- multi-GPU glue ------------------------------------------------------------------------
+ * A row-tiled frame gives each GPU a clamped u8 partial table; saturating add of clamped
+ * partials is exact, so ranks widen to u32, all-reduce(sum) over RCCL, and clamp once.
+ * Both work on device pointers and enqueue on the context's stream. */
+int scope_table_widen_u8_u32(scope_ctx *ctx, const uint8_t *in, uint32_t *out, uint64_t n);
+int scope_table_clamp_u32_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, uint64_t n);
+/* Half the wire bytes: two bins per 32-bit word (lo | hi << 16); exact for up to 257 ranks
+ * (257 * 255 < 65536, so the halves never carry).  n_pairs = number of bins / 2. */
+int scope_table_pack_u8_u16x2(scope_ctx *ctx, const uint8_t *in, uint32_t *out, uint64_t n_pairs);
+int scope_table_unpack_clamp_u16x2_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, uint64_t n_pairs);
+
+/* ---- measurement ---------------------------------------------------------------------------
+ * With profiling on, every accumulation launch (the dominant kernel of a call, not the small
+ * partial-table reduction) is bracketed by HIP events on the context's stream.
+ * scope_ctx_kernel_ms() waits for the most recent one and returns its duration. */
+int scope_ctx_profile(scope_ctx *ctx, int enable);
+int scope_ctx_kernel_ms(scope_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,790 @@
+/*
+ * scope_api.hip -- the C-ABI of libscope_hip.so (include/scope_hip.h).
+ *
+ * Host-side glue only: argument checking, host<->HBM staging when the caller hands over host
+ * buffers (the reference's mapped staging surface, src/common.c:343-364), partitioning of a
+ * frame over the chip's workgroups, launching the kernels of scope_kernels.hip and combining
+ * their partial tables.  There is no CPU implementation of the path in this library: without a
+ * HIP device scope_ctx_create() fails with SCOPE_ENODEV and nothing else can be called.
+ */
+#include "../../include/scope_hip.h"
+#include "scope_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct scope_ctx {
+	int device;
+	int num_cu;
+	hipStream_t own_stream;
+	hipStream_t stream;
+	uint8_t *partial; /* partial tables of one launch */
+	size_t partial_bytes;
+	uint8_t *stage_in; /* host planes uploaded here */
+	size_t stage_in_bytes;
+	uint8_t *stage_out; /* tables on their way to a host buffer */
+	size_t stage_out_bytes;
+	ScopeTuning tn;
+	int slices_override;
+	int profile;
+	int have_timing;
+	hipEvent_t ev0, ev1;
+	char err[256];
+};
+
+namespace {
+
+int fail(scope_ctx *ctx, int status, const char *what, hipError_t e)
+{
+	if (ctx)
+		snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e));
+	return status;
+}
+
+#define HIP_TRY(ctx, call)                                      \
+	do {                                                    \
+		hipError_t e_ = (call);                         \
+		if (e_ != hipSuccess)                           \
+			return fail(ctx, SCOPE_EIO, #call, e_); \
+	} while (0)
+
+int grow(scope_ctx *ctx, uint8_t **buf, size_t *cap, size_t need)
+{
+	if (need <= *cap)
+		return SCOPE_OK;
+	if (*buf) {
+		/* the old buffer may still be in use by work queued on the stream */
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		HIP_TRY(ctx, hipFree(*buf));
+		*buf = NULL;
+		*cap = 0;
+	}
+	void *p = NULL;
+	hipError_t e = hipMalloc(&p, need);
+	if (e != hipSuccess)
+		return fail(ctx, SCOPE_ENOMEM, "hipMalloc", e);
+	*buf = (uint8_t *)p;
+	*cap = need;
+	return SCOPE_OK;
+}
+
+/* Accumulation launch, bracketed by events when profiling is on. */
+#define TIMED_LAUNCH(ctx, call)                                                \
+	do {                                                                   \
+		if ((ctx)->profile)                                            \
+			HIP_TRY(ctx, hipEventRecord((ctx)->ev0, (ctx)->stream)); \
+		HIP_TRY(ctx, call);                                            \
+		if ((ctx)->profile) {                                          \
+			HIP_TRY(ctx, hipEventRecord((ctx)->ev1, (ctx)->stream)); \
+			(ctx)->have_timing = 1;                                \
+		}                                                              \
+	} while (0)
+
+size_t round_up(size_t v, size_t a)
+{
+	return (v + a - 1) / a * a;
+}
+
+/* Geometry checks shared by every scope. */
+int check_geometry(scope_ctx *ctx, uint32_t linesize, uint32_t width, uint32_t height)
+{
+	if ((uint64_t)width * 4 > linesize)
+		return fail(ctx, SCOPE_EINVAL, "linesize < 4*width", hipSuccess);
+	if ((uint64_t)width * height >= (1ull << 31))
+		return fail(ctx, SCOPE_EINVAL, "frame larger than 2^31 pixels", hipSuccess);
+	return SCOPE_OK;
+}
+
+/* Puts up to SCOPE_MAX_FRAMES planes into HBM (no-op for device planes) and describes them. */
+int stage_planes(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
+		 uint32_t height, uint32_t flags, ScopeFrameSet *fs)
+{
+	fs->n_frames = n;
+	fs->width = width;
+	fs->height = height;
+	if (flags & SCOPE_IN_DEVICE) {
+		if (linesize & 3u)
+			return fail(ctx, SCOPE_EINVAL, "device plane pitch must be a multiple of 4", hipSuccess);
+		for (uint32_t i = 0; i < n; i++) {
+			if (((uintptr_t)planes[i]) & 3u)
+				return fail(ctx, SCOPE_EINVAL, "device plane must be 4-byte aligned", hipSuccess);
+			fs->plane[i] = planes[i];
+		}
+		fs->linesize = linesize;
+		return SCOPE_OK;
+	}
+	const size_t pitch = round_up((size_t)width * 4, 16);
+	const size_t plane_bytes = round_up(pitch * height, 256);
+	int st = grow(ctx, &ctx->stage_in, &ctx->stage_in_bytes, plane_bytes * n);
+	if (st)
+		return st;
+	for (uint32_t i = 0; i < n; i++) {
+		uint8_t *d = ctx->stage_in + plane_bytes * i;
+		HIP_TRY(ctx, hipMemcpy2DAsync(d, pitch, planes[i], linesize, (size_t)width * 4, height, hipMemcpyHostToDevice,
+					      ctx->stream));
+		fs->plane[i] = d;
+	}
+	fs->linesize = (uint32_t)pitch;
+	return SCOPE_OK;
+}
+
+/* Where the kernels should leave `bytes` of results, and how they reach the caller. */
+int result_begin(scope_ctx *ctx, void *user_out, size_t bytes, uint32_t flags, uint8_t **dev_out)
+{
+	if (flags & SCOPE_OUT_DEVICE) {
+		*dev_out = (uint8_t *)user_out;
+		return SCOPE_OK;
+	}
+	int st = grow(ctx, &ctx->stage_out, &ctx->stage_out_bytes, round_up(bytes, 256));
+	if (st)
+		return st;
+	*dev_out = ctx->stage_out;
+	return SCOPE_OK;
+}
+
+int result_end(scope_ctx *ctx, void *user_out, size_t bytes, uint32_t flags, const uint8_t *dev_out)
+{
+	if (!(flags & SCOPE_OUT_DEVICE)) {
+		HIP_TRY(ctx, hipMemcpyAsync(user_out, dev_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return SCOPE_OK;
+	}
+	if (!(flags & SCOPE_ASYNC))
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SCOPE_OK;
+}
+
+int check_flags(scope_ctx *ctx, uint32_t flags)
+{
+	if ((flags & SCOPE_ASYNC) && (flags & (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE)) != (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE))
+		return fail(ctx, SCOPE_EINVAL, "SCOPE_ASYNC needs device input and output", hipSuccess);
+	return SCOPE_OK;
+}
+
+/* How many workgroups share one frame so that one launch covers the chip once. */
+uint32_t pick_slices(const scope_ctx *ctx, uint32_t frames_in_launch, uint32_t units_per_frame)
+{
+	if (ctx->slices_override > 0)
+		return (uint32_t)ctx->slices_override > 256u ? 256u : (uint32_t)ctx->slices_override;
+	const uint32_t busy = frames_in_launch * units_per_frame;
+	uint32_t s = busy ? (uint32_t)ctx->num_cu / busy : 1;
+	if (s < 1)
+		s = 1;
+	if (s > 256)
+		s = 256;
+	return s;
+}
+
+/* waveform.c:228-234 == histogram.c:367-373.  Returns 1 and fills plane/fuse when a plane is
+ * selectable, 0 when `components` selects none, SCOPE_ENODATA when the selected one is NULL. */
+int pick_plane(const struct scope_surface_data *sd, uint32_t components, uint32_t flags, const uint8_t **plane, int *fuse)
+{
+	*fuse = 0;
+	if (components & 0x07u) {
+		*plane = sd->rgb_data;
+	} else if (components & 0x70u) {
+		*plane = sd->yuv_data;
+		if (!*plane && (flags & SCOPE_FUSE_K0)) {
+			*plane = sd->rgb_data;
+			*fuse = 1;
+		}
+	} else {
+		return 0;
+	}
+	return *plane ? 1 : SCOPE_ENODATA;
+}
+
+uint32_t channel_mask(uint32_t components)
+{
+	/* calc_b/g/r = components & 0x11/0x22/0x44 (waveform.c:236-238, histogram.c:375-377) */
+	return (components | (components >> 4)) & 7u;
+}
+
+int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
+		    uint32_t height, int fuse, int colorspace, uint32_t flags, uint8_t *out)
+{
+	int st = check_flags(ctx, flags);
+	if (!st)
+		st = check_geometry(ctx, linesize, width, height);
+	if (st)
+		return st;
+	uint8_t *dev_out = NULL;
+	st = result_begin(ctx, out, (size_t)n * SCOPE_VSS_BINS, flags, &dev_out);
+	if (st)
+		return st;
+	for (uint32_t f0 = 0; f0 < n; f0 += SCOPE_MAX_FRAMES) {
+		const uint32_t nf = (n - f0 < SCOPE_MAX_FRAMES) ? n - f0 : SCOPE_MAX_FRAMES;
+		ScopeFrameSet fs;
+		st = stage_planes(ctx, planes + f0, nf, linesize, width, height, flags, &fs);
+		if (st)
+			return st;
+		uint8_t *dst = dev_out + (size_t)f0 * SCOPE_VSS_BINS;
+		const uint32_t slices = pick_slices(ctx, nf, 1);
+		if (slices == 1) {
+			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, ctx->tn, ctx->stream));
+		} else {
+			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * SCOPE_VSS_BINS);
+			if (st)
+				return st;
+			TIMED_LAUNCH(ctx, scope_launch_vss(fs, slices, fuse, colorspace, ctx->partial, ctx->tn, ctx->stream));
+			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, slices, SCOPE_VSS_BINS, ctx->stream));
+		}
+		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* stage_in is reused by the next chunk */
+	}
+	return result_end(ctx, out, (size_t)n * SCOPE_VSS_BINS, flags, dev_out);
+}
+
+int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
+		 uint32_t height, uint32_t chmask, int fuse, int colorspace, uint32_t flags, uint8_t *out)
+{
+	int st = check_flags(ctx, flags);
+	if (!st)
+		st = check_geometry(ctx, linesize, width, height);
+	if (st)
+		return st;
+	if (width == 0)
+		return SCOPE_OK; /* empty table */
+	const size_t table = (size_t)SCOPE_WV_SIZE * width * 4;
+	uint8_t *dev_out = NULL;
+	st = result_begin(ctx, out, (size_t)n * table, flags, &dev_out);
+	if (st)
+		return st;
+	const uint32_t strips = (width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
+	for (uint32_t f0 = 0; f0 < n; f0 += SCOPE_MAX_FRAMES) {
+		const uint32_t nf = (n - f0 < SCOPE_MAX_FRAMES) ? n - f0 : SCOPE_MAX_FRAMES;
+		ScopeFrameSet fs;
+		st = stage_planes(ctx, planes + f0, nf, linesize, width, height, flags, &fs);
+		if (st)
+			return st;
+		uint8_t *dst = dev_out + (size_t)f0 * table;
+		uint32_t bands = pick_slices(ctx, nf, strips);
+		if (bands > 16)
+			bands = 16;
+		/* the partial tables are combined 16 bytes at a time */
+		if (bands > 1 && ((table & 15u) || (((uintptr_t)dst) & 15u)))
+			bands = 1;
+		if (bands == 1) {
+			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->tn, ctx->stream));
+		} else {
+			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * bands * table);
+			if (st)
+				return st;
+			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, bands, chmask, fuse, colorspace, ctx->partial, ctx->tn, ctx->stream));
+			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, bands, table, ctx->stream));
+		}
+		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return result_end(ctx, out, (size_t)n * table, flags, dev_out);
+}
+
+int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
+		  uint32_t height, uint32_t chmask, int fuse, int colorspace, uint32_t flags, uint32_t *counts)
+{
+	int st = check_flags(ctx, flags);
+	if (!st)
+		st = check_geometry(ctx, linesize, width, height);
+	if (st)
+		return st;
+	const size_t table = SCOPE_HIS_WORDS * sizeof(uint32_t);
+	uint8_t *dev_out = NULL;
+	st = result_begin(ctx, counts, (size_t)n * table, flags, &dev_out);
+	if (st)
+		return st;
+	for (uint32_t f0 = 0; f0 < n; f0 += SCOPE_MAX_FRAMES) {
+		const uint32_t nf = (n - f0 < SCOPE_MAX_FRAMES) ? n - f0 : SCOPE_MAX_FRAMES;
+		ScopeFrameSet fs;
+		st = stage_planes(ctx, planes + f0, nf, linesize, width, height, flags, &fs);
+		if (st)
+			return st;
+		uint32_t *dst = (uint32_t *)(dev_out + (size_t)f0 * table);
+		const uint32_t slices = pick_slices(ctx, nf, 1);
+		if (slices == 1) {
+			TIMED_LAUNCH(ctx, scope_launch_his(fs, 1, chmask, fuse, colorspace, dst, ctx->tn, ctx->stream));
+		} else {
+			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * table);
+			if (st)
+				return st;
+			TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, (uint32_t *)ctx->partial, ctx->tn,
+						      ctx->stream));
+			HIP_TRY(ctx, scope_launch_sum_reduce((const uint32_t *)ctx->partial, dst, nf, slices, SCOPE_HIS_WORDS,
+							     ctx->stream));
+		}
+		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return result_end(ctx, counts, (size_t)n * table, flags, dev_out);
+}
+
+/* A table of zeros, for the cases where the reference zero-fills and returns. */
+int zero_result(scope_ctx *ctx, void *out, size_t bytes, uint32_t flags)
+{
+	if (flags & SCOPE_OUT_DEVICE) {
+		HIP_TRY(ctx, hipMemsetAsync(out, 0, bytes, ctx->stream));
+		if (!(flags & SCOPE_ASYNC))
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	} else {
+		memset(out, 0, bytes);
+	}
+	return SCOPE_OK;
+}
+
+int enter(scope_ctx *ctx)
+{
+	if (!ctx)
+		return SCOPE_EINVAL;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	return SCOPE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int scope_abi_version(void)
+{
+	return SCOPE_ABI_VERSION;
+}
+
+const char *scope_strerror(int status)
+{
+	switch (status) {
+	case SCOPE_OK:
+		return "ok";
+	case SCOPE_EINVAL:
+		return "invalid argument";
+	case SCOPE_ENOMEM:
+		return "out of memory";
+	case SCOPE_ENODEV:
+		return "no usable HIP device";
+	case SCOPE_EIO:
+		return "HIP runtime error";
+	case SCOPE_ENODATA:
+		return "required plane is NULL";
+	default:
+		return "unknown status";
+	}
+}
+
+const char *scope_last_error(scope_ctx *ctx)
+{
+	return ctx ? ctx->err : "no context";
+}
+
+int scope_ctx_create(int device, scope_ctx **out)
+{
+	if (!out)
+		return SCOPE_EINVAL;
+	*out = NULL;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+		return SCOPE_ENODEV;
+	if (hipSetDevice(device) != hipSuccess)
+		return SCOPE_ENODEV;
+	scope_ctx *ctx = (scope_ctx *)calloc(1, sizeof *ctx);
+	if (!ctx)
+		return SCOPE_ENOMEM;
+	ctx->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+		free(ctx);
+		return SCOPE_ENODEV;
+	}
+	ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+		free(ctx);
+		return SCOPE_EIO;
+	}
+	ctx->stream = ctx->own_stream;
+	if (scope_kernels_init() != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+	    hipEventCreate(&ctx->ev1) != hipSuccess) {
+		(void)hipStreamDestroy(ctx->own_stream);
+		free(ctx);
+		return SCOPE_EIO;
+	}
+	ctx->tn.vss_merge = 1;
+	ctx->tn.vss_unroll = 4;
+	ctx->tn.his_unroll = 4;
+	ctx->tn.wvs_unroll = 8;
+	ctx->err[0] = 0;
+	*out = ctx;
+	return SCOPE_OK;
+}
+
+void scope_ctx_destroy(scope_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	if (ctx->partial)
+		(void)hipFree(ctx->partial);
+	if (ctx->stage_in)
+		(void)hipFree(ctx->stage_in);
+	if (ctx->stage_out)
+		(void)hipFree(ctx->stage_out);
+	if (ctx->ev0)
+		(void)hipEventDestroy(ctx->ev0);
+	if (ctx->ev1)
+		(void)hipEventDestroy(ctx->ev1);
+	(void)hipStreamDestroy(ctx->own_stream);
+	free(ctx);
+}
+
+int scope_ctx_set_stream(scope_ctx *ctx, void *hip_stream)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+	return SCOPE_OK;
+}
+
+void *scope_ctx_get_stream(scope_ctx *ctx)
+{
+	return ctx ? (void *)ctx->stream : NULL;
+}
+
+int scope_ctx_sync(scope_ctx *ctx)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SCOPE_OK;
+}
+
+int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!info)
+		return SCOPE_EINVAL;
+	hipDeviceProp_t prop;
+	HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+	memset(info, 0, sizeof *info);
+	snprintf(info->name, sizeof info->name, "%s", prop.name);
+	snprintf(info->arch, sizeof info->arch, "%s", prop.gcnArchName);
+	info->device = ctx->device;
+	info->compute_units = prop.multiProcessorCount;
+	info->lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+	info->clock_khz = prop.clockRate;
+	info->hbm_bytes = prop.totalGlobalMem;
+	return SCOPE_OK;
+}
+
+int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
+{
+	if (!ctx || !key)
+		return SCOPE_EINVAL;
+	if (!strcmp(key, "vss.merge"))
+		ctx->tn.vss_merge = value;
+	else if (!strcmp(key, "vss.unroll"))
+		ctx->tn.vss_unroll = value;
+	else if (!strcmp(key, "his.unroll"))
+		ctx->tn.his_unroll = value;
+	else if (!strcmp(key, "wvs.unroll"))
+		ctx->tn.wvs_unroll = value;
+	else if (!strcmp(key, "slices"))
+		ctx->slices_override = value;
+	else
+		return fail(ctx, SCOPE_EINVAL, key, hipSuccess);
+	return SCOPE_OK;
+}
+
+int scope_convert_rgb_yuv(scope_ctx *ctx, const uint8_t *rgb, uint32_t rgb_linesize, uint8_t *yuv,
+			  uint32_t yuv_linesize, uint32_t width, uint32_t height, int colorspace, uint32_t flags)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!rgb || !yuv)
+		return fail(ctx, SCOPE_EINVAL, "NULL plane", hipSuccess);
+	st = check_geometry(ctx, rgb_linesize, width, height);
+	if (!st)
+		st = check_geometry(ctx, yuv_linesize, width, height);
+	if (st)
+		return st;
+	if (width == 0 || height == 0)
+		return SCOPE_OK;
+	if (flags & SCOPE_IN_DEVICE) {
+		if (((uintptr_t)rgb | (uintptr_t)yuv | rgb_linesize | yuv_linesize) & 3u)
+			return fail(ctx, SCOPE_EINVAL, "device planes must be 4-byte aligned", hipSuccess);
+		HIP_TRY(ctx, scope_launch_k0(rgb, rgb_linesize, yuv, yuv_linesize, width, height, colorspace, ctx->stream));
+		if (!(flags & SCOPE_ASYNC))
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return SCOPE_OK;
+	}
+	ScopeFrameSet fs;
+	const uint8_t *one[1] = {rgb};
+	st = stage_planes(ctx, one, 1, rgb_linesize, width, height, 0, &fs);
+	if (st)
+		return st;
+	const size_t bytes = (size_t)fs.linesize * height;
+	st = grow(ctx, &ctx->stage_out, &ctx->stage_out_bytes, round_up(bytes, 256));
+	if (st)
+		return st;
+	HIP_TRY(ctx, scope_launch_k0(fs.plane[0], fs.linesize, ctx->stage_out, fs.linesize, width, height, colorspace,
+				     ctx->stream));
+	HIP_TRY(ctx, hipMemcpy2DAsync(yuv, yuv_linesize, ctx->stage_out, fs.linesize, (size_t)width * 4, height,
+				      hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SCOPE_OK;
+}
+
+int scope_vectorscope(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t flags, uint8_t *out)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!sd || !out)
+		return fail(ctx, SCOPE_EINVAL, "NULL argument", hipSuccess);
+	const uint8_t *plane = sd->yuv_data;
+	int fuse = 0;
+	if (!plane && (flags & SCOPE_FUSE_K0)) {
+		plane = sd->rgb_data;
+		fuse = 1;
+	}
+	if (!plane)
+		return SCOPE_ENODATA; /* vss_surface_cb returns without drawing, src/vectorscope.c:252 */
+	if (sd->width == 0 || sd->height == 0)
+		return zero_result(ctx, out, SCOPE_VSS_BINS, flags);
+	const uint8_t *one[1] = {plane};
+	return run_vectorscope(ctx, one, 1, sd->linesize, sd->width, sd->height, fuse, sd->colorspace, flags, out);
+}
+
+int scope_vectorscope_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t flags, uint8_t *out)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!b || !out || !b->planes || b->n_frames == 0)
+		return fail(ctx, SCOPE_EINVAL, "NULL or empty batch", hipSuccess);
+	for (uint32_t i = 0; i < b->n_frames; i++)
+		if (!b->planes[i])
+			return SCOPE_ENODATA;
+	if (b->width == 0 || b->height == 0)
+		return zero_result(ctx, out, (size_t)b->n_frames * SCOPE_VSS_BINS, flags);
+	return run_vectorscope(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, b->planes_are_rgb != 0,
+			       b->colorspace, flags, out);
+}
+
+int scope_waveform(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, uint32_t flags,
+		   uint8_t *out)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!sd || !out)
+		return fail(ctx, SCOPE_EINVAL, "NULL argument", hipSuccess);
+	const size_t table = (size_t)SCOPE_WV_SIZE * sd->width * 4;
+	const uint8_t *plane = NULL;
+	int fuse = 0;
+	const int sel = pick_plane(sd, components, flags, &plane, &fuse);
+	if (sel < 0)
+		return sel; /* wvs_surface_cb returns without drawing, src/waveform.c:276-281 */
+	if (sel == 0 || sd->height == 0 || sd->width == 0)
+		return table ? zero_result(ctx, out, table, flags) : SCOPE_OK; /* src/waveform.c:225-234 */
+	const uint8_t *one[1] = {plane};
+	return run_waveform(ctx, one, 1, sd->linesize, sd->width, sd->height, channel_mask(components), fuse,
+			    sd->colorspace, flags, out);
+}
+
+int scope_waveform_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
+			 uint8_t *out)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!b || !out || !b->planes || b->n_frames == 0)
+		return fail(ctx, SCOPE_EINVAL, "NULL or empty batch", hipSuccess);
+	for (uint32_t i = 0; i < b->n_frames; i++)
+		if (!b->planes[i])
+			return SCOPE_ENODATA;
+	const size_t table = (size_t)SCOPE_WV_SIZE * b->width * 4;
+	/* which plane kind the mask wants vs. what the batch holds */
+	const bool want_rgb = (components & 0x07u) != 0, want_yuv = !want_rgb && (components & 0x70u) != 0;
+	if ((!want_rgb && !want_yuv) || b->height == 0 || b->width == 0)
+		return table ? zero_result(ctx, out, (size_t)b->n_frames * table, flags) : SCOPE_OK;
+	if (want_rgb && !b->planes_are_rgb)
+		return SCOPE_ENODATA;
+	const int fuse = want_yuv && b->planes_are_rgb;
+	return run_waveform(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, channel_mask(components), fuse,
+			    b->colorspace, flags, out);
+}
+
+int scope_histogram_counts(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, uint32_t flags,
+			   uint32_t *counts)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!sd || !counts)
+		return fail(ctx, SCOPE_EINVAL, "NULL argument", hipSuccess);
+	const uint8_t *plane = NULL;
+	int fuse = 0;
+	const int sel = pick_plane(sd, components, flags, &plane, &fuse);
+	if (sel < 0)
+		return sel; /* his_surface_cb returns without drawing, src/histogram.c:436-441 */
+	if (sel == 0 || sd->height == 0 || sd->width == 0)
+		return zero_result(ctx, counts, SCOPE_HIS_WORDS * 4, flags); /* src/histogram.c:363-373 */
+	const uint8_t *one[1] = {plane};
+	return run_histogram(ctx, one, 1, sd->linesize, sd->width, sd->height, channel_mask(components), fuse,
+			     sd->colorspace, flags, counts);
+}
+
+int scope_histogram_counts_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
+				 uint32_t *counts)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!b || !counts || !b->planes || b->n_frames == 0)
+		return fail(ctx, SCOPE_EINVAL, "NULL or empty batch", hipSuccess);
+	for (uint32_t i = 0; i < b->n_frames; i++)
+		if (!b->planes[i])
+			return SCOPE_ENODATA;
+	const bool want_rgb = (components & 0x07u) != 0, want_yuv = !want_rgb && (components & 0x70u) != 0;
+	if ((!want_rgb && !want_yuv) || b->height == 0 || b->width == 0)
+		return zero_result(ctx, counts, (size_t)b->n_frames * SCOPE_HIS_WORDS * 4, flags);
+	if (want_rgb && !b->planes_are_rgb)
+		return SCOPE_ENODATA;
+	const int fuse = want_yuv && b->planes_are_rgb;
+	return run_histogram(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, channel_mask(components), fuse,
+			     b->colorspace, flags, counts);
+}
+
+void scope_histogram_level(uint8_t *tex_buf, uint32_t *hi_max, uint32_t width, uint32_t height, uint32_t components,
+			   int logscale, int level_fixed_value, int level_ratio_value)
+{
+	uint32_t n[SCOPE_HIS_WORDS];
+	float f[SCOPE_HIS_WORDS];
+	memcpy(n, tex_buf, sizeof n);
+
+	/* level: fixed pixel count, else per-mille of the frame, else per-channel peak
+	 * (src/histogram.c:397-402 with :330-355); slot j is enabled by mask 0x44 >> j */
+	uint32_t level = 0;
+	if (level_fixed_value > 0)
+		level = (uint32_t)level_fixed_value;
+	else if (level_ratio_value > 0)
+		level = (uint32_t)((uint64_t)width * height * (uint64_t)level_ratio_value / 1000u);
+	if (level_fixed_value > 0 || level_ratio_value > 0) {
+		for (int j = 0; j < 3; j++)
+			hi_max[j] = level ? level : 1u;
+	} else {
+		for (int j = 0; j < 3; j++) {
+			uint32_t peak = 1;
+			if (components & (0x44u >> j))
+				for (int v = 0; v < SCOPE_HI_SIZE; v++)
+					peak = n[4 * v + j] > peak ? n[4 * v + j] : peak;
+			hi_max[j] = peak;
+		}
+	}
+
+	/* float conversion in place (src/histogram.c:404-417) */
+	memcpy(f, n, sizeof f);
+	if (logscale) {
+		for (int j = 0; j < 3; j++) {
+			if (!(components & (0x44u >> j)))
+				continue;
+			const float scale = 1.0f / logf((float)(hi_max[j] + 1));
+			for (int v = 0; v < SCOPE_HI_SIZE; v++)
+				f[4 * v + j] = n[4 * v + j] ? logf((float)(n[4 * v + j] + 1)) * scale : 0.0f;
+			hi_max[j] = 1;
+		}
+	} else {
+		for (uint32_t i = 0; i < SCOPE_HIS_WORDS; i++)
+			f[i] = (float)n[i];
+	}
+	memcpy(tex_buf, f, sizeof f);
+}
+
+int scope_histogram(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, int logscale,
+		    int level_fixed_value, int level_ratio_value, uint32_t flags, uint8_t *tex_buf, uint32_t *hi_max)
+{
+	if (!ctx || !sd || !tex_buf || !hi_max || (flags & (SCOPE_OUT_DEVICE | SCOPE_ASYNC)))
+		return SCOPE_EINVAL;
+	uint32_t counts[SCOPE_HIS_WORDS];
+	const int st = scope_histogram_counts(ctx, sd, components, flags, counts);
+	if (st)
+		return st;
+	memcpy(tex_buf, counts, sizeof counts);
+	/* no selectable plane: the reference returns before the level pass (src/histogram.c:372-373) */
+	if (!(components & 0x77u))
+		return SCOPE_OK;
+	scope_histogram_level(tex_buf, hi_max, sd->width, sd->height, components, logscale, level_fixed_value,
+			      level_ratio_value);
+	return SCOPE_OK;
+}
+
+int scope_table_widen_u8_u32(scope_ctx *ctx, const uint8_t *in, uint32_t *out, uint64_t n)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!in || !out)
+		return SCOPE_EINVAL;
+	HIP_TRY(ctx, scope_launch_widen(in, out, n, ctx->stream));
+	return SCOPE_OK;
+}
+
+int scope_table_clamp_u32_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, uint64_t n)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!in || !out)
+		return SCOPE_EINVAL;
+	HIP_TRY(ctx, scope_launch_clamp(in, out, n, ctx->stream));
+	return SCOPE_OK;
+}
+
+int scope_table_pack_u8_u16x2(scope_ctx *ctx, const uint8_t *in, uint32_t *out, uint64_t n_pairs)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!in || !out)
+		return SCOPE_EINVAL;
+	HIP_TRY(ctx, scope_launch_pack16(in, out, n_pairs, ctx->stream));
+	return SCOPE_OK;
+}
+
+int scope_table_unpack_clamp_u16x2_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, uint64_t n_pairs)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!in || !out)
+		return SCOPE_EINVAL;
+	HIP_TRY(ctx, scope_launch_unpack16_clamp(in, out, n_pairs, ctx->stream));
+	return SCOPE_OK;
+}
+
+int scope_ctx_profile(scope_ctx *ctx, int enable)
+{
+	if (!ctx)
+		return SCOPE_EINVAL;
+	ctx->profile = enable != 0;
+	ctx->have_timing = 0;
+	return SCOPE_OK;
+}
+
+int scope_ctx_kernel_ms(scope_ctx *ctx, float *ms)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!ms || !ctx->have_timing)
+		return fail(ctx, SCOPE_EINVAL, "no timed launch yet", hipSuccess);
+	HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+	HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+	return SCOPE_OK;
+}
+
+} /* extern "C" */

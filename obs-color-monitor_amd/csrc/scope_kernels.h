@@ -1,0 +1,91 @@
+/*
+ * scope_kernels.h -- launch-side interface of the gfx950 scope-accumulation kernels.
+ *
+ * Internal to libscope_hip.so (the C-ABI is include/scope_hip.h).  Everything here works on
+ * DEVICE pointers and enqueues on a hipStream_t; no allocation, no synchronisation.
+ *
+ * Reference semantics implemented (all relative to /root/reference):
+ *   K0  data/common.effect:23-43      RGB -> Y'CbCr (fp32, no contraction, UNORM8 store)
+ *   K1  src/vectorscope.c:217-238     256x256 CbCr scatter, u8 saturating
+ *   K2  src/waveform.c:220-257        per-column 256-bin histograms, u8 saturating, alpha test
+ *   K3  src/histogram.c:357-395       3x256 u32 histogram, alpha test
+ */
+#ifndef SCOPE_KERNELS_H
+#define SCOPE_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SCOPE_MAX_FRAMES 64      /* frames per launch (pointers travel as kernel arguments) */
+#define SCOPE_VSS_BINS 65536u    /* VS_SIZE * VS_SIZE, src/vectorscope.c:26 */
+#define SCOPE_HIS_WORDS 1024u    /* HI_SIZE * 4, src/histogram.c:20 */
+#define SCOPE_WVS_ROWS 256u       /* WV_SIZE, src/waveform.c:20 */
+#define SCOPE_BLOCK 1024         /* threads per workgroup of every accumulation kernel */
+#define SCOPE_WVS_STRIP 64u      /* columns owned by one waveform workgroup (= one wave wide) */
+
+/* A batch of same-geometry BGRA8 planes resident in HBM. */
+struct ScopeFrameSet {
+	const uint8_t *plane[SCOPE_MAX_FRAMES];
+	uint32_t n_frames;
+	uint32_t linesize; /* bytes */
+	uint32_t width, height;
+};
+
+/* K0 matrix, rows U,Y,V; columns r,g,b (signed, so every term is an add). */
+struct ScopeK0 {
+	float ur, ug, ub;
+	float yr, yg, yb;
+	float vr, vg, vb;
+};
+
+/* Tunables the host may flip for A/B runs (scope_ctx_set_option). */
+struct ScopeTuning {
+	int vss_merge;  /* 0 none, 1 lane-local run merge, 2 = 1 + wave-uniform shortcut */
+	int vss_unroll; /* 16-byte loads in flight per lane: 2, 4 or 8 */
+	int his_unroll;
+	int wvs_unroll; /* rows in flight per lane: 4, 8 or 16 */
+	int reserved;
+};
+
+ScopeK0 scope_k0_matrix(int colorspace);
+
+/* Dynamic-LDS opt-in for every instantiation; call once per device before launching. */
+hipError_t scope_kernels_init(void);
+
+/* K0 standalone: src plane (B,G,R,A) -> dst plane (U,Y,V,255); replaces the ConvertRGB_YUV* pass
+ * of render_rgb_yuv (src/common.c:202-213). */
+hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *dst, uint32_t dst_linesize,
+			   uint32_t width, uint32_t height, int colorspace, hipStream_t st);
+
+/* K1.  dst = uint8[n_frames][slices][65536]; with slices > 1 the tables are clamped partials to
+ * be combined by scope_launch_sat_reduce.  fuse_k0: planes are RGB, U/V computed in-kernel. */
+hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
+			    const ScopeTuning &tn, hipStream_t st);
+
+/* K3.  dst = uint32[n_frames][slices][1024]; combine with scope_launch_sum_reduce when slices > 1.
+ * chmask bit c = count byte c of the texel (bit0 -> slot 2, bit1 -> slot 1, bit2 -> slot 0). */
+hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
+			    uint32_t *dst, const ScopeTuning &tn, hipStream_t st);
+
+/* K2.  dst = uint8[n_frames][bands][256][width][4]; combine with scope_launch_sat_reduce when
+ * bands > 1.  chmask as above (bit c -> byte c of the output texel). */
+hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
+			    uint8_t *dst, const ScopeTuning &tn, hipStream_t st);
+
+/* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256). */
+hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,
+				   hipStream_t st);
+
+/* out[f][i] = sum_s part[f][s][i], i < len. */
+hipError_t scope_launch_sum_reduce(const uint32_t *part, uint32_t *out, uint32_t n_frames, uint32_t slices,
+				   uint32_t len, hipStream_t st);
+
+/* Multi-GPU helpers: u8 table -> u32 (for the RCCL sum) and u32 -> u8 with the final clamp. */
+hipError_t scope_launch_widen(const uint8_t *in, uint32_t *out, uint64_t n, hipStream_t st);
+hipError_t scope_launch_clamp(const uint32_t *in, uint8_t *out, uint64_t n, hipStream_t st);
+/* Same idea at half the wire bytes: two bins per 32-bit word (lo | hi << 16).  A sum over up to
+ * 257 ranks of values <= 255 stays below 65536, so the halves never carry into each other. */
+hipError_t scope_launch_pack16(const uint8_t *in, uint32_t *out, uint64_t n_pairs, hipStream_t st);
+hipError_t scope_launch_unpack16_clamp(const uint32_t *in, uint8_t *out, uint64_t n_pairs, hipStream_t st);
+
+#endif

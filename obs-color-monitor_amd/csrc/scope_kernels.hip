@@ -1,0 +1,894 @@
+/*
+ * scope_kernels.hip -- hand-written gfx950 (CDNA4 / MI355X) kernels for obs-color-monitor's
+ * scope accumulation: K0 RGB->Y'CbCr, K1 vectorscope, K2 waveform, K3 histogram.
+ *
+ * Design (DESIGN.md has the full story):
+ *   * HBM-bound byte/integer work, no MFMA.  Every pixel is read from HBM exactly once with
+ *     coalesced loads (16 B/lane for K0/K1/K3, 4 B/lane = 256 B/wave row segments for K2).
+ *   * One 1024-thread workgroup per CU owns a private table in LDS (128 KiB u16-packed
+ *     256x256 for K1; 96 KiB lane-replicated 3x256 for K3; 32 KiB per channel column-strip
+ *     table for K2) and accumulates with LDS atomics; bank placement is chosen so that the
+ *     K2/K3 atomics are bank-conflict free by construction and K1's spread over all 32 banks
+ *     for clustered chroma.
+ *   * A table leaves the CU once, as a coalesced 16 B/lane store of clamped u8 (K1/K2) or
+ *     u32 (K3) partials; partial tables of one frame are combined by a tiny second kernel
+ *     (saturating add is exact: min(min(a,255)+min(b,255),255) == min(a+b,255)).
+ *
+ * Reference semantics (relative to /root/reference): data/common.effect:23-43,
+ * src/vectorscope.c:217-238, src/waveform.c:220-257, src/histogram.c:357-395.
+ *
+ * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (K0 must not be FMA-contracted).
+ */
+#include "scope_kernels.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+/* All LDS scratch lives in the dynamic region so its base stays 16-byte aligned. */
+extern __shared__ __attribute__((aligned(16))) u32 scope_lds[];
+
+/* ------------------------------------------------------------------------------------------
+ * K0: per-texel RGB -> Y'CbCr, bit-exact with oracle/scope_oracle.c:k0_texel
+ * ---------------------------------------------------------------------------------------- */
+
+/* byte/255 correctly rounded to fp32 without a divide: fma(b, hi, b*lo) with hi+lo ~= 1/255
+ * (checked exhaustively for the 256 inputs in tests/test_k0_constants.py). */
+__device__ __forceinline__ float scope_unorm8(u32 byte)
+{
+	const float b = (float)byte;
+	return __fmaf_rn(b, 0x1.010102p-8f, __fmul_rn(b, -0x1.fdfdfep-33f));
+}
+
+/* FLOAT -> UNORM8 store rule pinned by the build: floor(clamp01(x)*255 + 0.5). */
+__device__ __forceinline__ u32 scope_k0_quantise(float x)
+{
+	x = fminf(fmaxf(x, 0.0f), 1.0f);
+	return (u32)__fadd_rn(__fmul_rn(x, 255.0f), 0.5f);
+}
+
+/* px bytes B,G,R,A -> bytes U,Y,V,255 (data/common.effect:23-43; the shader returns
+ * float4(V,Y,U,1) into a BGRA target).  need_uv / need_y are wave-uniform. */
+__device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool need_uv, bool need_y)
+{
+	const float b = scope_unorm8(px & 0xffu);
+	const float g = scope_unorm8((px >> 8) & 0xffu);
+	const float r = scope_unorm8((px >> 16) & 0xffu);
+	u32 out = 0xff000000u;
+	if (need_uv) {
+		float u = __fmul_rn(k.ur, r);
+		u = __fadd_rn(u, __fmul_rn(k.ug, g));
+		u = __fadd_rn(u, __fmul_rn(k.ub, b));
+		u = __fadd_rn(u, 0.5f);
+		u = __fsub_rn(u, 0.00390625f);
+		float v = __fmul_rn(k.vr, r);
+		v = __fadd_rn(v, __fmul_rn(k.vg, g));
+		v = __fadd_rn(v, __fmul_rn(k.vb, b));
+		v = __fadd_rn(v, 0.5f);
+		out |= scope_k0_quantise(u) | (scope_k0_quantise(v) << 16);
+	}
+	if (need_y) {
+		float y = __fmul_rn(k.yr, r);
+		y = __fadd_rn(y, __fmul_rn(k.yg, g));
+		y = __fadd_rn(y, __fmul_rn(k.yb, b));
+		out |= scope_k0_quantise(y) << 8;
+	}
+	return out;
+}
+
+ScopeK0 scope_k0_matrix(int colorspace)
+{
+	/* src/common.c:207-208: colorspace == 1 -> 601, anything else -> 709 */
+	if (colorspace == 1)
+		return ScopeK0{-0.147643f, -0.289855f, +0.437500f, +0.299000f, +0.587000f,
+			       +0.114000f, +0.437500f, -0.366351f, -0.071147f};
+	return ScopeK0{-0.100643f, -0.338571f, +0.439216f, +0.212600f, +0.715200f,
+		       +0.072200f, +0.439216f, -0.398941f, -0.040273f};
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Pixel streaming: a workgroup walks chunks [c0, c1) of a (rows x ncols) grid of VECW-pixel
+ * cells, U loads in flight per lane.  Row pitch is honoured, so padded surfaces cost nothing.
+ * ---------------------------------------------------------------------------------------- */
+
+template <int VECW> struct ScopeVec;
+template <> struct ScopeVec<4> {
+	typedef uint4 type;
+};
+template <> struct ScopeVec<1> {
+	typedef u32 type;
+};
+
+__device__ __forceinline__ uint4 scope_load(const uint4 *p)
+{
+	return *p;
+}
+__device__ __forceinline__ u32 scope_load(const u32 *p)
+{
+	return *p;
+}
+
+template <int VECW, int U, typename F>
+__device__ __forceinline__ void scope_for_chunks(const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 c0,
+						 u32 c1, F &&fn)
+{
+	typedef typename ScopeVec<VECW>::type vec_t;
+	const u32 T = blockDim.x;
+	u32 c = c0 + threadIdx.x;
+	u32 row = c / ncols;
+	u32 col = c - row * ncols;
+	const u32 dq = T / ncols;
+	const u32 dr = T - dq * ncols;
+	while (c < c1) {
+		vec_t v[U];
+		bool ok[U];
+#pragma unroll
+		for (int k = 0; k < U; k++) {
+			ok[k] = (c + (u32)k * T) < c1;
+			if (ok[k]) {
+				const uint8_t *p = plane + (size_t)row * linesize + xbyte0 + (size_t)col * (4 * VECW);
+				v[k] = scope_load((const vec_t *)p);
+			}
+			row += dq;
+			col += dr;
+			if (col >= ncols) {
+				col -= ncols;
+				row += 1;
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			if (ok[k])
+				fn(v[k]);
+		c += (u32)U * T;
+	}
+}
+
+/* Slice s of S of `total` cells. */
+__device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
+{
+	return (u32)(((u64)total * s) / S);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K1 vectorscope
+ *
+ * LDS table: 32768 words, two u16 counters per word.  Bin idx = u + 256*row (row = 255 - v)
+ * lives in word  row*128 + ((u>>1) ^ ((row&3)<<3)),  half u&1.  The XOR rotates each row's
+ * eight-word groups so that a clustered chroma blob (a few u values, a few rows) spreads over
+ * all 32 LDS banks instead of piling onto the banks of u>>1.
+ *
+ * Counters are 16 bit: between two clamp passes a workgroup adds at most 65280 pixels, and
+ * every counter is <= 255 after a pass, so no counter can exceed 65535.  The clamp is exact
+ * because the reference saturates at 255 (src/vectorscope.c:233-234).
+ * ---------------------------------------------------------------------------------------- */
+
+#define VSS_WORDS 32768u
+#define VSS_EPOCH_PIXELS 65280u
+
+__device__ __forceinline__ u32 vss_bin(u32 px)
+{
+	/* byte0 = U, byte2 = V: idx = u + 256*(255 - v)   (src/vectorscope.c:228-232) */
+	return (px & 0xffu) | ((~px >> 8) & 0xff00u);
+}
+
+__device__ __forceinline__ void vss_add(u32 *tab, u32 idx, u32 n)
+{
+	const u32 row = idx >> 8;
+	const u32 word = (row << 7) + (((idx & 0xffu) >> 1) ^ ((row & 3u) << 3));
+	atomicAdd(&tab[word], n << ((idx & 1u) << 4));
+}
+
+template <int MERGE> __device__ __forceinline__ void vss_add_run4(u32 *tab, u32 i0, u32 i1, u32 i2, u32 i3)
+{
+	if (MERGE == 0) {
+		vss_add(tab, i0, 1);
+		vss_add(tab, i1, 1);
+		vss_add(tab, i2, 1);
+		vss_add(tab, i3, 1);
+		return;
+	}
+	/* fold runs of equal neighbours onto their first element */
+	u32 n0 = 1, n1 = 1, n2 = 1, n3 = 1;
+	if (i3 == i2) {
+		n2 += n3;
+		n3 = 0;
+	}
+	if (i2 == i1) {
+		n1 += n2;
+		n2 = 0;
+	}
+	if (i1 == i0) {
+		n0 += n1;
+		n1 = 0;
+	}
+	if (MERGE == 2) {
+		/* whole wave on one bin (flat areas): one lane adds for everybody */
+		const u32 first = __builtin_amdgcn_readfirstlane(i0);
+		const bool same = (n0 == 4) && (i0 == first);
+		if (__all(same)) {
+			const u64 active = __ballot(1);
+			const u32 lane = threadIdx.x & 63u;
+			if (lane == (u32)(__ffsll((long long)active) - 1))
+				vss_add(tab, first, 4u * (u32)__popcll(active));
+			return;
+		}
+	}
+	vss_add(tab, i0, n0);
+	if (n1)
+		vss_add(tab, i1, n1);
+	if (n2)
+		vss_add(tab, i2, n2);
+	if (n3)
+		vss_add(tab, i3, n3);
+}
+
+__device__ __forceinline__ u32 vss_clamp_word(u32 w)
+{
+	const u32 lo = min(w & 0xffffu, 255u);
+	const u32 hi = min(w >> 16, 255u);
+	return lo | (hi << 16);
+}
+
+__device__ __forceinline__ void vss_clamp_pass(u32 *tab)
+{
+	for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4) {
+		uint4 x = *(uint4 *)&tab[i];
+		if ((x.x | x.y | x.z | x.w) & 0xff00ff00u) {
+			x.x = vss_clamp_word(x.x);
+			x.y = vss_clamp_word(x.y);
+			x.z = vss_clamp_word(x.z);
+			x.w = vss_clamp_word(x.w);
+			*(uint4 *)&tab[i] = x;
+		}
+	}
+}
+
+__device__ __forceinline__ u32 vss_pack2(u32 wa, u32 wb)
+{
+	/* two words = four consecutive bins -> four clamped bytes */
+	return min(wa & 0xffffu, 255u) | (min(wa >> 16, 255u) << 8) | (min(wb & 0xffffu, 255u) << 16) |
+	       (min(wb >> 16, 255u) << 24);
+}
+
+template <int VECW, int U, int MERGE, bool FUSE>
+__device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
+					   u32 slice, u32 slices, const ScopeK0 &k0, u32 &since_clamp)
+{
+	if (ncols == 0)
+		return;
+	const u32 total = rows * ncols;
+	u32 c0 = scope_slice_begin(total, slice, slices);
+	const u32 c1 = scope_slice_begin(total, slice + 1, slices);
+	while (c0 < c1) {
+		const u32 room = (VSS_EPOCH_PIXELS - since_clamp) / VECW;
+		if (room == 0) {
+			__syncthreads();
+			vss_clamp_pass(tab);
+			__syncthreads();
+			since_clamp = 0;
+			continue;
+		}
+		const u32 e1 = (c1 - c0 > room) ? c0 + room : c1;
+		if (VECW == 4) {
+			scope_for_chunks<4, U>(plane, linesize, xbyte0, ncols, c0, e1, [&](const uint4 &q) {
+				u32 p0 = q.x, p1 = q.y, p2 = q.z, p3 = q.w;
+				if (FUSE) {
+					p0 = scope_k0_texel(p0, k0, true, false);
+					p1 = scope_k0_texel(p1, k0, true, false);
+					p2 = scope_k0_texel(p2, k0, true, false);
+					p3 = scope_k0_texel(p3, k0, true, false);
+				}
+				vss_add_run4<MERGE>(tab, vss_bin(p0), vss_bin(p1), vss_bin(p2), vss_bin(p3));
+			});
+		} else {
+			scope_for_chunks<1, U>(plane, linesize, xbyte0, ncols, c0, e1, [&](const u32 &q) {
+				u32 p0 = q;
+				if (FUSE)
+					p0 = scope_k0_texel(p0, k0, true, false);
+				vss_add(tab, vss_bin(p0), 1);
+			});
+		}
+		since_clamp += (e1 - c0) * VECW;
+		c0 = e1;
+	}
+}
+
+/* grid = n_frames * slices workgroups; unit = frame * slices + slice.
+ * Region A: ncols_a cells of 4 pixels from byte 0 of each row (16-byte aligned rows only);
+ * region B: ncols_b single pixels from byte xbyte_b (row tails, or whole rows when unaligned). */
+template <int U, int MERGE, bool FUSE>
+__global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
+							       u32 xbyte_b, ScopeK0 k0, uint8_t *dst)
+{
+	u32 *tab = scope_lds;
+	const u32 unit = blockIdx.x;
+	const u32 frame = unit / slices;
+	const u32 slice = unit - frame * slices;
+	const uint8_t *plane = fs.plane[frame];
+
+	const uint4 zero = make_uint4(0, 0, 0, 0);
+	for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4)
+		*(uint4 *)&tab[i] = zero;
+	__syncthreads();
+
+	u32 since_clamp = 0;
+	vss_region<4, U, MERGE, FUSE>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, k0, since_clamp);
+	vss_region<1, U, MERGE, FUSE>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, k0,
+					  since_clamp);
+	__syncthreads();
+
+	/* flush: 16 consecutive bins (= 8 words, one swizzled group) per lane per step */
+	uint4 *out = (uint4 *)(dst + (size_t)unit * SCOPE_VSS_BINS);
+	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x) {
+		const u32 row = g >> 4;
+		const u32 wbase = (row << 7) + (((g & 15u) << 3) ^ ((row & 3u) << 3));
+		const uint4 a = *(const uint4 *)&tab[wbase];
+		const uint4 b = *(const uint4 *)&tab[wbase + 4];
+		out[g] = make_uint4(vss_pack2(a.x, a.y), vss_pack2(a.z, a.w), vss_pack2(b.x, b.y), vss_pack2(b.z, b.w));
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K3 histogram
+ *
+ * LDS table: u32 [3 channels][256 values][32 replicas]; a lane always uses replica lane&31, so
+ * the 32 lanes of an LDS lane group hit 32 different banks whatever the pixel values are
+ * (flat frames included).  Counters are 32 bit and never saturate (src/histogram.c:388-393).
+ * ---------------------------------------------------------------------------------------- */
+
+#define HIS_WORDS (3u * 256u * 32u)
+
+__device__ __forceinline__ void his_add(u32 *tab, u32 px, u32 chmask, u32 rep)
+{
+	if ((px >> 24) == 0)
+		return; /* src/histogram.c:386-387 */
+	if (chmask & 1u)
+		atomicAdd(&tab[((0u * 256u + (px & 0xffu)) << 5) + rep], 1u);
+	if (chmask & 2u)
+		atomicAdd(&tab[((1u * 256u + ((px >> 8) & 0xffu)) << 5) + rep], 1u);
+	if (chmask & 4u)
+		atomicAdd(&tab[((2u * 256u + ((px >> 16) & 0xffu)) << 5) + rep], 1u);
+}
+
+template <int VECW, int U, bool FUSE>
+__device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
+					   u32 slice, u32 slices, u32 chmask, const ScopeK0 &k0)
+{
+	if (ncols == 0)
+		return;
+	const u32 total = rows * ncols;
+	const u32 c0 = scope_slice_begin(total, slice, slices);
+	const u32 c1 = scope_slice_begin(total, slice + 1, slices);
+	const u32 rep = threadIdx.x & 31u;
+	const bool need_uv = (chmask & 5u) != 0, need_y = (chmask & 2u) != 0;
+	if (VECW == 4) {
+		scope_for_chunks<4, U>(plane, linesize, xbyte0, ncols, c0, c1, [&](const uint4 &q) {
+			u32 p0 = q.x, p1 = q.y, p2 = q.z, p3 = q.w;
+			if (FUSE) {
+				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
+				p1 = scope_k0_texel(p1, k0, need_uv, need_y);
+				p2 = scope_k0_texel(p2, k0, need_uv, need_y);
+				p3 = scope_k0_texel(p3, k0, need_uv, need_y);
+			}
+			his_add(tab, p0, chmask, rep);
+			his_add(tab, p1, chmask, rep);
+			his_add(tab, p2, chmask, rep);
+			his_add(tab, p3, chmask, rep);
+		});
+	} else {
+		scope_for_chunks<1, U>(plane, linesize, xbyte0, ncols, c0, c1, [&](const u32 &q) {
+			u32 p0 = q;
+			if (FUSE)
+				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
+			his_add(tab, p0, chmask, rep);
+		});
+	}
+}
+
+template <int U, bool FUSE>
+__global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
+							       u32 xbyte_b, u32 chmask, ScopeK0 k0, u32 *dst)
+{
+	u32 *tab = scope_lds;
+	const u32 unit = blockIdx.x;
+	const u32 frame = unit / slices;
+	const u32 slice = unit - frame * slices;
+	const uint8_t *plane = fs.plane[frame];
+
+	const uint4 zero = make_uint4(0, 0, 0, 0);
+	for (u32 i = threadIdx.x * 4; i < HIS_WORDS; i += blockDim.x * 4)
+		*(uint4 *)&tab[i] = zero;
+	__syncthreads();
+
+	his_region<4, U, FUSE>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, chmask, k0);
+	his_region<1, U, FUSE>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, chmask, k0);
+	__syncthreads();
+
+	/* fold the 32 replicas; lane t starts at replica t so a lane group reads 32 banks */
+	u32 *out = dst + (size_t)unit * SCOPE_HIS_WORDS;
+	for (u32 t = threadIdx.x; t < SCOPE_HIS_WORDS; t += blockDim.x) {
+		const u32 value = t >> 2, slot = t & 3u;
+		u32 sum = 0;
+		if (slot < 3) {
+			const u32 ch = 2u - slot; /* slot 0 = R = byte2, 1 = G = byte1, 2 = B = byte0 */
+			const u32 base = (ch * 256u + value) << 5;
+			for (u32 j = 0; j < 32; j++)
+				sum += tab[base + ((j + value) & 31u)];
+		}
+		out[t] = sum;
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K2 waveform
+ *
+ * A workgroup owns a strip of 64 columns (one wave wide) over a band of rows; lane l owns
+ * column strip*64 + l.  Each wave loads whole 256-byte row segments (4 B/lane) and wave w of the
+ * workgroup takes rows w, w+16, ...  LDS table per enabled channel: 8192 words, word
+ * value*32 + (lane&31), half lane>>5 -- the 32 lanes of an LDS lane group always hit 32
+ * different banks and never the same address, so the atomics are conflict-free for any image.
+ * A column can receive at most `rows in band` (< 65536) increments, so 16 bits never overflow.
+ * ---------------------------------------------------------------------------------------- */
+
+#define WVS_CH_WORDS 8192u
+
+template <int U, bool FUSE>
+__global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, u32 chmask,
+							       ScopeK0 k0, uint8_t *dst)
+{
+	u32 *tab = scope_lds;
+	const u32 unit = blockIdx.x;
+	const u32 per_frame = strips * bands;
+	const u32 frame = unit / per_frame;
+	const u32 rem = unit - frame * per_frame;
+	const u32 band = rem / strips;
+	const u32 strip = rem - band * strips;
+	const uint8_t *plane = fs.plane[frame];
+	const u32 W = fs.width;
+
+	/* compact LDS slot of each enabled channel */
+	const u32 slot0 = 0;
+	const u32 slot1 = (chmask & 1u);
+	const u32 slot2 = slot1 + ((chmask >> 1) & 1u);
+	const u32 nch = slot2 + ((chmask >> 2) & 1u);
+
+	const uint4 zero = make_uint4(0, 0, 0, 0);
+	for (u32 i = threadIdx.x * 4; i < nch * WVS_CH_WORDS; i += blockDim.x * 4)
+		*(uint4 *)&tab[i] = zero;
+	__syncthreads();
+
+	const u32 lane = threadIdx.x & 63u;
+	const u32 wave = threadIdx.x >> 6;
+	const u32 nwaves = blockDim.x >> 6;
+	const u32 x = strip * SCOPE_WVS_STRIP + lane;
+	const u32 r0 = scope_slice_begin(fs.height, band, bands);
+	const u32 r1 = scope_slice_begin(fs.height, band + 1, bands);
+	const u32 rep = lane & 31u;
+	const u32 inc = (lane < 32u) ? 1u : 65536u;
+	const bool need_uv = (chmask & 5u) != 0, need_y = (chmask & 2u) != 0;
+
+	if (x < W) {
+		const uint8_t *col = plane + (size_t)x * 4;
+		for (u32 r = r0 + wave; r < r1; r += nwaves * U) {
+			u32 v[U];
+			bool ok[U];
+#pragma unroll
+			for (int k = 0; k < U; k++) {
+				const u32 rr = r + (u32)k * nwaves;
+				ok[k] = rr < r1;
+				if (ok[k])
+					v[k] = scope_load((const u32 *)(col + (size_t)rr * fs.linesize));
+			}
+#pragma unroll
+			for (int k = 0; k < U; k++) {
+				if (!ok[k])
+					continue;
+				u32 px = v[k];
+				if (FUSE)
+					px = scope_k0_texel(px, k0, need_uv, need_y);
+				if ((px >> 24) == 0)
+					continue; /* src/waveform.c:247-248 */
+				if (chmask & 1u)
+					atomicAdd(&tab[slot0 * WVS_CH_WORDS + ((px & 0xffu) << 5) + rep], inc);
+				if (chmask & 2u)
+					atomicAdd(&tab[slot1 * WVS_CH_WORDS + (((px >> 8) & 0xffu) << 5) + rep], inc);
+				if (chmask & 4u)
+					atomicAdd(&tab[slot2 * WVS_CH_WORDS + (((px >> 16) & 0xffu) << 5) + rep], inc);
+			}
+		}
+	}
+	__syncthreads();
+
+	/* flush: lane -> 4 adjacent columns of one output row (255 - value), 16 B per store.
+	 * Output texel bytes B,G,R,X = channels 0,1,2 and 0 (src/waveform.c:250-254; X never written). */
+	uint8_t *table = dst + ((size_t)frame * bands + band) * ((size_t)SCOPE_WVS_ROWS * W * 4);
+	const u32 xg = threadIdx.x & 15u; /* columns 4*xg .. 4*xg+3 of the strip */
+	const u32 shift = (xg >= 8u) ? 16u : 0u;
+	const u32 woff = (xg & 7u) << 2;
+	const u32 xo = strip * SCOPE_WVS_STRIP + (xg << 2);
+	const bool vec_ok = ((W & 3u) == 0) && ((((size_t)table) & 15u) == 0);
+	for (u32 value = threadIdx.x >> 4; value < 256u; value += blockDim.x >> 4) {
+		u32 o[4] = {0, 0, 0, 0};
+		if (chmask & 1u) {
+			const uint4 c = *(const uint4 *)&tab[slot0 * WVS_CH_WORDS + (value << 5) + woff];
+			o[0] |= min((c.x >> shift) & 0xffffu, 255u);
+			o[1] |= min((c.y >> shift) & 0xffffu, 255u);
+			o[2] |= min((c.z >> shift) & 0xffffu, 255u);
+			o[3] |= min((c.w >> shift) & 0xffffu, 255u);
+		}
+		if (chmask & 2u) {
+			const uint4 c = *(const uint4 *)&tab[slot1 * WVS_CH_WORDS + (value << 5) + woff];
+			o[0] |= min((c.x >> shift) & 0xffffu, 255u) << 8;
+			o[1] |= min((c.y >> shift) & 0xffffu, 255u) << 8;
+			o[2] |= min((c.z >> shift) & 0xffffu, 255u) << 8;
+			o[3] |= min((c.w >> shift) & 0xffffu, 255u) << 8;
+		}
+		if (chmask & 4u) {
+			const uint4 c = *(const uint4 *)&tab[slot2 * WVS_CH_WORDS + (value << 5) + woff];
+			o[0] |= min((c.x >> shift) & 0xffffu, 255u) << 16;
+			o[1] |= min((c.y >> shift) & 0xffffu, 255u) << 16;
+			o[2] |= min((c.z >> shift) & 0xffffu, 255u) << 16;
+			o[3] |= min((c.w >> shift) & 0xffffu, 255u) << 16;
+		}
+		u32 *orow = (u32 *)(table + ((size_t)(255u - value) * W + xo) * 4);
+		if (vec_ok && xo + 3 < W) {
+			*(uint4 *)orow = make_uint4(o[0], o[1], o[2], o[3]);
+		} else {
+			for (u32 j = 0; j < 4; j++)
+				if (xo + j < W)
+					orow[j] = o[j];
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * K0 standalone, partial-table reductions, multi-GPU helpers
+ * ---------------------------------------------------------------------------------------- */
+
+__global__ __launch_bounds__(256) void scope_k0_kernel(const uint8_t *src, u32 src_linesize, uint8_t *dst,
+						      u32 dst_linesize, u32 ncols_a, u32 ncols_b, u32 xbyte_b, u32 rows,
+						      ScopeK0 k0)
+{
+	const u32 stride = gridDim.x * blockDim.x;
+	const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (ncols_a) {
+		const u32 total = rows * ncols_a;
+		for (u32 c = gid; c < total; c += stride) {
+			const u32 row = c / ncols_a, col = c - row * ncols_a;
+			const uint4 q = *(const uint4 *)(src + (size_t)row * src_linesize + (size_t)col * 16);
+			uint4 o;
+			o.x = scope_k0_texel(q.x, k0, true, true);
+			o.y = scope_k0_texel(q.y, k0, true, true);
+			o.z = scope_k0_texel(q.z, k0, true, true);
+			o.w = scope_k0_texel(q.w, k0, true, true);
+			*(uint4 *)(dst + (size_t)row * dst_linesize + (size_t)col * 16) = o;
+		}
+	}
+	if (ncols_b) {
+		const u32 total = rows * ncols_b;
+		for (u32 c = gid; c < total; c += stride) {
+			const u32 row = c / ncols_b, col = c - row * ncols_b;
+			const u32 q = *(const u32 *)(src + (size_t)row * src_linesize + xbyte_b + (size_t)col * 4);
+			*(u32 *)(dst + (size_t)row * dst_linesize + xbyte_b + (size_t)col * 4) =
+				scope_k0_texel(q, k0, true, true);
+		}
+	}
+}
+
+/* out[f][i] = min(sum_s part[f][s][i], 255); 16 bytes per lane; slices <= 256 so the
+ * packed 16-bit lanes (max 256*255 = 65280) cannot overflow. */
+__global__ __launch_bounds__(256) void scope_sat_reduce_kernel(const uint8_t *part, uint8_t *out, u32 slices, u64 len16)
+{
+	const u32 frame = blockIdx.y;
+	const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= len16)
+		return;
+	const uint4 *p = (const uint4 *)part + (u64)frame * slices * len16 + g;
+	u32 ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};
+	for (u32 s = 0; s < slices; s++) {
+		const uint4 q = p[(u64)s * len16];
+		ev[0] += q.x & 0x00ff00ffu;
+		od[0] += (q.x >> 8) & 0x00ff00ffu;
+		ev[1] += q.y & 0x00ff00ffu;
+		od[1] += (q.y >> 8) & 0x00ff00ffu;
+		ev[2] += q.z & 0x00ff00ffu;
+		od[2] += (q.z >> 8) & 0x00ff00ffu;
+		ev[3] += q.w & 0x00ff00ffu;
+		od[3] += (q.w >> 8) & 0x00ff00ffu;
+	}
+	u32 r[4];
+	for (int j = 0; j < 4; j++)
+		r[j] = min(ev[j] & 0xffffu, 255u) | (min(od[j] & 0xffffu, 255u) << 8) | (min(ev[j] >> 16, 255u) << 16) |
+		       (min(od[j] >> 16, 255u) << 24);
+	((uint4 *)out)[(u64)frame * len16 + g] = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+__global__ __launch_bounds__(256) void scope_sum_reduce_kernel(const u32 *part, u32 *out, u32 slices, u32 len)
+{
+	const u32 frame = blockIdx.y;
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= len)
+		return;
+	const u32 *p = part + (size_t)frame * slices * len + i;
+	u32 sum = 0;
+	for (u32 s = 0; s < slices; s++)
+		sum += p[(size_t)s * len];
+	out[(size_t)frame * len + i] = sum;
+}
+
+__global__ __launch_bounds__(256) void scope_widen_kernel(const uint8_t *in, u32 *out, u64 n)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+		out[i] = in[i];
+}
+
+__global__ __launch_bounds__(256) void scope_clamp_kernel(const u32 *in, uint8_t *out, u64 n)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+		out[i] = (uint8_t)min(in[i], 255u);
+}
+
+__global__ __launch_bounds__(256) void scope_pack16_kernel(const uint8_t *in, u32 *out, u64 n_pairs)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += stride)
+		out[i] = (u32)in[2 * i] | ((u32)in[2 * i + 1] << 16);
+}
+
+__global__ __launch_bounds__(256) void scope_unpack16_clamp_kernel(const u32 *in, uint8_t *out, u64 n_pairs)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += stride) {
+		const u32 w = in[i];
+		out[2 * i] = (uint8_t)min(w & 0xffffu, 255u);
+		out[2 * i + 1] = (uint8_t)min(w >> 16, 255u);
+	}
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Launchers
+ * ---------------------------------------------------------------------------------------- */
+
+
+namespace {
+
+struct Regions {
+	u32 ncols_a, ncols_b, xbyte_b;
+};
+
+/* 16-byte cells where every row start is 16-byte aligned, single pixels elsewhere. */
+Regions split_regions(const ScopeFrameSet &fs)
+{
+	bool aligned = (fs.linesize & 15u) == 0;
+	for (u32 i = 0; i < fs.n_frames; i++)
+		aligned = aligned && (((uintptr_t)fs.plane[i]) & 15u) == 0;
+	Regions r;
+	if (aligned) {
+		r.ncols_a = fs.width / 4;
+		r.ncols_b = fs.width & 3u;
+		r.xbyte_b = r.ncols_a * 16;
+	} else {
+		r.ncols_a = 0;
+		r.ncols_b = fs.width;
+		r.xbyte_b = 0;
+	}
+	return r;
+}
+
+template <typename K> hipError_t allow_lds(K kernel, u32 bytes)
+{
+	return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+const u32 VSS_LDS_BYTES = VSS_WORDS * 4u;
+const u32 HIS_LDS_BYTES = HIS_WORDS * 4u;
+const u32 WVS_LDS_BYTES = 3u * WVS_CH_WORDS * 4u;
+
+template <int U, int MERGE, bool FUSE>
+hipError_t vss_go(const ScopeFrameSet &fs, u32 slices, const Regions &rg, const ScopeK0 &k0, uint8_t *dst, hipStream_t st)
+{
+	hipLaunchKernelGGL((scope_vss_kernel<U, MERGE, FUSE>), dim3(fs.n_frames * slices), dim3(SCOPE_BLOCK), VSS_LDS_BYTES,
+			   st, fs, slices, rg.ncols_a, rg.ncols_b, rg.xbyte_b, k0, dst);
+	return hipGetLastError();
+}
+
+template <int U, int MERGE>
+hipError_t vss_go_f(int fuse, const ScopeFrameSet &fs, u32 slices, const Regions &rg, const ScopeK0 &k0, uint8_t *dst,
+		    hipStream_t st)
+{
+	return fuse ? vss_go<U, MERGE, true>(fs, slices, rg, k0, dst, st)
+		    : vss_go<U, MERGE, false>(fs, slices, rg, k0, dst, st);
+}
+
+template <int U>
+hipError_t vss_go_m(int merge, int fuse, const ScopeFrameSet &fs, u32 slices, const Regions &rg, const ScopeK0 &k0,
+		    uint8_t *dst, hipStream_t st)
+{
+	switch (merge) {
+	case 0:
+		return vss_go_f<U, 0>(fuse, fs, slices, rg, k0, dst, st);
+	case 1:
+		return vss_go_f<U, 1>(fuse, fs, slices, rg, k0, dst, st);
+	default:
+		return vss_go_f<U, 2>(fuse, fs, slices, rg, k0, dst, st);
+	}
+}
+
+template <int U, bool FUSE>
+hipError_t his_go(const ScopeFrameSet &fs, u32 slices, const Regions &rg, u32 chmask, const ScopeK0 &k0, u32 *dst,
+		  hipStream_t st)
+{
+	hipLaunchKernelGGL((scope_his_kernel<U, FUSE>), dim3(fs.n_frames * slices), dim3(SCOPE_BLOCK), HIS_LDS_BYTES, st, fs,
+			   slices, rg.ncols_a, rg.ncols_b, rg.xbyte_b, chmask, k0, dst);
+	return hipGetLastError();
+}
+
+template <int U, bool FUSE>
+hipError_t wvs_go(const ScopeFrameSet &fs, u32 strips, u32 bands, u32 chmask, u32 lds, const ScopeK0 &k0, uint8_t *dst,
+		  hipStream_t st)
+{
+	hipLaunchKernelGGL((scope_wvs_kernel<U, FUSE>), dim3(fs.n_frames * strips * bands), dim3(SCOPE_BLOCK), lds, st, fs,
+			   strips, bands, chmask, k0, dst);
+	return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t scope_kernels_init(void)
+{
+	hipError_t e = hipSuccess;
+#define ALLOW(k, b)                          \
+	do {                                 \
+		if (e == hipSuccess)         \
+			e = allow_lds(k, b); \
+	} while (0)
+#define ALLOW_VSS(U)                                           \
+	ALLOW((scope_vss_kernel<U, 0, false>), VSS_LDS_BYTES); \
+	ALLOW((scope_vss_kernel<U, 1, false>), VSS_LDS_BYTES); \
+	ALLOW((scope_vss_kernel<U, 2, false>), VSS_LDS_BYTES); \
+	ALLOW((scope_vss_kernel<U, 0, true>), VSS_LDS_BYTES);  \
+	ALLOW((scope_vss_kernel<U, 1, true>), VSS_LDS_BYTES);  \
+	ALLOW((scope_vss_kernel<U, 2, true>), VSS_LDS_BYTES)
+	ALLOW_VSS(2);
+	ALLOW_VSS(4);
+	ALLOW_VSS(8);
+#define ALLOW_HIS(U)                                        \
+	ALLOW((scope_his_kernel<U, false>), HIS_LDS_BYTES); \
+	ALLOW((scope_his_kernel<U, true>), HIS_LDS_BYTES)
+	ALLOW_HIS(2);
+	ALLOW_HIS(4);
+	ALLOW_HIS(8);
+#define ALLOW_WVS(U)                                        \
+	ALLOW((scope_wvs_kernel<U, false>), WVS_LDS_BYTES); \
+	ALLOW((scope_wvs_kernel<U, true>), WVS_LDS_BYTES)
+	ALLOW_WVS(4);
+	ALLOW_WVS(8);
+	ALLOW_WVS(16);
+	return e;
+}
+
+hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *dst, uint32_t dst_linesize,
+			   uint32_t width, uint32_t height, int colorspace, hipStream_t st)
+{
+	const bool aligned =
+		((src_linesize | dst_linesize) & 15u) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15u) == 0;
+	const u32 ncols_a = aligned ? width / 4 : 0;
+	const u32 ncols_b = aligned ? (width & 3u) : width;
+	const u32 xbyte_b = ncols_a * 16;
+	const u64 cells = (u64)height * (ncols_a ? ncols_a : ncols_b);
+	u32 blocks = (u32)((cells + 255) / 256);
+	if (blocks > 256 * 8)
+		blocks = 256 * 8;
+	if (blocks == 0)
+		blocks = 1;
+	hipLaunchKernelGGL(scope_k0_kernel, dim3(blocks), dim3(256), 0, st, src, src_linesize, dst, dst_linesize, ncols_a,
+			   ncols_b, xbyte_b, height, scope_k0_matrix(colorspace));
+	return hipGetLastError();
+}
+
+hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
+			    const ScopeTuning &tn, hipStream_t st)
+{
+	const Regions rg = split_regions(fs);
+	const ScopeK0 k0 = scope_k0_matrix(colorspace);
+	if (tn.vss_unroll <= 2)
+		return vss_go_m<2>(tn.vss_merge, fuse_k0, fs, slices, rg, k0, dst, st);
+	if (tn.vss_unroll <= 4)
+		return vss_go_m<4>(tn.vss_merge, fuse_k0, fs, slices, rg, k0, dst, st);
+	return vss_go_m<8>(tn.vss_merge, fuse_k0, fs, slices, rg, k0, dst, st);
+}
+
+hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
+			    uint32_t *dst, const ScopeTuning &tn, hipStream_t st)
+{
+	const Regions rg = split_regions(fs);
+	const ScopeK0 k0 = scope_k0_matrix(colorspace);
+#define HIS_CASE(UU)                                                             \
+	(fuse_k0 ? his_go<UU, true>(fs, slices, rg, chmask, k0, dst, st)         \
+		 : his_go<UU, false>(fs, slices, rg, chmask, k0, dst, st))
+	if (tn.his_unroll <= 2)
+		return HIS_CASE(2);
+	if (tn.his_unroll <= 4)
+		return HIS_CASE(4);
+	return HIS_CASE(8);
+}
+
+hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
+			    uint8_t *dst, const ScopeTuning &tn, hipStream_t st)
+{
+	const ScopeK0 k0 = scope_k0_matrix(colorspace);
+	const u32 strips = (fs.width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
+	const u32 nch = (chmask & 1u) + ((chmask >> 1) & 1u) + ((chmask >> 2) & 1u);
+	const u32 lds = (nch ? nch : 1u) * WVS_CH_WORDS * 4u;
+#define WVS_CASE(UU)                                                                     \
+	(fuse_k0 ? wvs_go<UU, true>(fs, strips, bands, chmask, lds, k0, dst, st)         \
+		 : wvs_go<UU, false>(fs, strips, bands, chmask, lds, k0, dst, st))
+	if (tn.wvs_unroll <= 4)
+		return WVS_CASE(4);
+	if (tn.wvs_unroll <= 8)
+		return WVS_CASE(8);
+	return WVS_CASE(16);
+}
+
+hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,
+				   hipStream_t st)
+{
+	const u64 len16 = len / 16;
+	const u32 blocks = (u32)((len16 + 255) / 256);
+	hipLaunchKernelGGL(scope_sat_reduce_kernel, dim3(blocks, n_frames), dim3(256), 0, st, part, out, slices, len16);
+	return hipGetLastError();
+}
+
+hipError_t scope_launch_sum_reduce(const uint32_t *part, uint32_t *out, uint32_t n_frames, uint32_t slices,
+				   uint32_t len, hipStream_t st)
+{
+	hipLaunchKernelGGL(scope_sum_reduce_kernel, dim3((len + 255) / 256, n_frames), dim3(256), 0, st, part, out, slices,
+			   len);
+	return hipGetLastError();
+}
+
+hipError_t scope_launch_widen(const uint8_t *in, uint32_t *out, uint64_t n, hipStream_t st)
+{
+	u32 blocks = (u32)((n + 255) / 256);
+	if (blocks > 2048)
+		blocks = 2048;
+	if (!blocks)
+		blocks = 1;
+	hipLaunchKernelGGL(scope_widen_kernel, dim3(blocks), dim3(256), 0, st, in, out, (u64)n);
+	return hipGetLastError();
+}
+
+hipError_t scope_launch_clamp(const uint32_t *in, uint8_t *out, uint64_t n, hipStream_t st)
+{
+	u32 blocks = (u32)((n + 255) / 256);
+	if (blocks > 2048)
+		blocks = 2048;
+	if (!blocks)
+		blocks = 1;
+	hipLaunchKernelGGL(scope_clamp_kernel, dim3(blocks), dim3(256), 0, st, in, out, (u64)n);
+	return hipGetLastError();
+}
+
+hipError_t scope_launch_pack16(const uint8_t *in, uint32_t *out, uint64_t n_pairs, hipStream_t st)
+{
+	u32 blocks = (u32)((n_pairs + 255) / 256);
+	if (blocks > 2048)
+		blocks = 2048;
+	if (!blocks)
+		blocks = 1;
+	hipLaunchKernelGGL(scope_pack16_kernel, dim3(blocks), dim3(256), 0, st, in, out, (u64)n_pairs);
+	return hipGetLastError();
+}
+
+hipError_t scope_launch_unpack16_clamp(const uint32_t *in, uint8_t *out, uint64_t n_pairs, hipStream_t st)
+{
+	u32 blocks = (u32)((n_pairs + 255) / 256);
+	if (blocks > 2048)
+		blocks = 2048;
+	if (!blocks)
+		blocks = 1;
+	hipLaunchKernelGGL(scope_unpack16_clamp_kernel, dim3(blocks), dim3(256), 0, st, in, out, (u64)n_pairs);
+	return hipGetLastError();
+}

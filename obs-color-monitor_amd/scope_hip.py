@@ -1,0 +1,306 @@
+"""ctypes front end of libscope_hip.so (C-ABI: include/scope_hip.h).
+
+Used by the tests, bench.py and __graft_entry__.py to drive the product path exactly as a C host
+would: every call below is one C-ABI call.  There is no Python or CPU implementation of the path
+here -- if the shared library is missing or no HIP device is usable this module raises.
+
+Host buffers are numpy uint8 arrays shaped [height, linesize]; device buffers are anything with a
+``data_ptr()`` (torch tensors on the GPU), which PyTorch-ROCm provides together with streams and
+``torch.distributed``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libscope_hip.so")
+
+OK, EINVAL, ENOMEM, ENODEV, EIO, ENODATA = 0, -22, -12, -19, -5, -61
+IN_DEVICE, OUT_DEVICE, ASYNC, FUSE_K0 = 0x1, 0x2, 0x4, 0x8
+COMP_RGB, COMP_Y, COMP_UV, COMP_YUV = 0x07, 0x20, 0x50, 0x70
+
+# every symbol include/scope_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "scope_abi_version", "scope_strerror", "scope_last_error",
+    "scope_ctx_create", "scope_ctx_destroy", "scope_ctx_set_stream", "scope_ctx_get_stream", "scope_ctx_sync",
+    "scope_ctx_device_info", "scope_ctx_set_option",
+    "scope_convert_rgb_yuv",
+    "scope_vectorscope", "scope_waveform", "scope_histogram_counts", "scope_histogram", "scope_histogram_level",
+    "scope_vectorscope_batch", "scope_waveform_batch", "scope_histogram_counts_batch",
+    "scope_table_widen_u8_u32", "scope_table_clamp_u32_u8",
+    "scope_table_pack_u8_u16x2", "scope_table_unpack_clamp_u16x2_u8",
+    "scope_ctx_profile", "scope_ctx_kernel_ms",
+)
+
+
+class SurfaceData(C.Structure):
+    """struct scope_surface_data == struct cm_surface_data (src/common.h:24-30)."""
+
+    _fields_ = [
+        ("rgb_data", C.c_void_p),
+        ("yuv_data", C.c_void_p),
+        ("linesize", C.c_uint32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("colorspace", C.c_int),
+        ("tex", C.c_void_p),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("planes", C.POINTER(C.c_void_p)),
+        ("n_frames", C.c_uint32),
+        ("linesize", C.c_uint32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("planes_are_rgb", C.c_int),
+        ("colorspace", C.c_int),
+    ]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 128),
+        ("arch", C.c_char * 32),
+        ("device", C.c_int),
+        ("compute_units", C.c_int),
+        ("lds_bytes_per_cu", C.c_int),
+        ("clock_khz", C.c_int),
+        ("hbm_bytes", C.c_uint64),
+    ]
+
+
+class ScopeError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"scope_hip status {status}: {msg}")
+        self.status = status
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the scope path)")
+    L = C.CDLL(path)
+    vp, u32, i32, u64 = C.c_void_p, C.c_uint32, C.c_int, C.c_uint64
+    sig = {
+        "scope_abi_version": (i32, []),
+        "scope_strerror": (C.c_char_p, [i32]),
+        "scope_last_error": (C.c_char_p, [vp]),
+        "scope_ctx_create": (i32, [i32, C.POINTER(vp)]),
+        "scope_ctx_destroy": (None, [vp]),
+        "scope_ctx_set_stream": (i32, [vp, vp]),
+        "scope_ctx_get_stream": (vp, [vp]),
+        "scope_ctx_sync": (i32, [vp]),
+        "scope_ctx_device_info": (i32, [vp, C.POINTER(DeviceInfo)]),
+        "scope_ctx_set_option": (i32, [vp, C.c_char_p, i32]),
+        "scope_convert_rgb_yuv": (i32, [vp, vp, u32, vp, u32, u32, u32, i32, u32]),
+        "scope_vectorscope": (i32, [vp, C.POINTER(SurfaceData), u32, vp]),
+        "scope_waveform": (i32, [vp, C.POINTER(SurfaceData), u32, u32, vp]),
+        "scope_histogram_counts": (i32, [vp, C.POINTER(SurfaceData), u32, u32, vp]),
+        "scope_histogram": (i32, [vp, C.POINTER(SurfaceData), u32, i32, i32, i32, u32, vp, vp]),
+        "scope_histogram_level": (None, [vp, vp, u32, u32, u32, i32, i32, i32]),
+        "scope_vectorscope_batch": (i32, [vp, C.POINTER(Batch), u32, vp]),
+        "scope_waveform_batch": (i32, [vp, C.POINTER(Batch), u32, u32, vp]),
+        "scope_histogram_counts_batch": (i32, [vp, C.POINTER(Batch), u32, u32, vp]),
+        "scope_table_widen_u8_u32": (i32, [vp, vp, vp, u64]),
+        "scope_table_clamp_u32_u8": (i32, [vp, vp, vp, u64]),
+        "scope_table_pack_u8_u16x2": (i32, [vp, vp, vp, u64]),
+        "scope_table_unpack_clamp_u16x2_u8": (i32, [vp, vp, vp, u64]),
+        "scope_ctx_profile": (i32, [vp, i32]),
+        "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    return L
+
+
+def _hptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dptr(t):
+    return C.c_void_p(int(t.data_ptr())) if hasattr(t, "data_ptr") else C.c_void_p(int(t))
+
+
+class ScopeContext:
+    """One scope_ctx.  ``lib_path`` lets the CPU-emulation test build be driven by the same code."""
+
+    def __init__(self, device: int = 0, lib_path: str | None = None):
+        self.L = load_library(lib_path)
+        h = C.c_void_p()
+        st = self.L.scope_ctx_create(device, C.byref(h))
+        if st != OK:
+            raise ScopeError(st, self.L.scope_strerror(st).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.scope_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st, allow=()):
+        if st != OK and st not in allow:
+            raise ScopeError(st, f"{self.L.scope_strerror(st).decode()} ({self.L.scope_last_error(self.h).decode()})")
+        return st
+
+    # -- context -------------------------------------------------------------------------------
+    def device_info(self) -> dict:
+        di = DeviceInfo()
+        self._check(self.L.scope_ctx_device_info(self.h, C.byref(di)))
+        return {"name": di.name.decode(), "arch": di.arch.decode(), "device": di.device,
+                "compute_units": di.compute_units, "lds_bytes_per_cu": di.lds_bytes_per_cu,
+                "clock_khz": di.clock_khz, "hbm_bytes": int(di.hbm_bytes)}
+
+    def set_option(self, key: str, value: int):
+        self._check(self.L.scope_ctx_set_option(self.h, key.encode(), int(value)))
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self.L.scope_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def get_stream(self) -> int:
+        return int(self.L.scope_ctx_get_stream(self.h) or 0)
+
+    def sync(self):
+        self._check(self.L.scope_ctx_sync(self.h))
+
+    # -- host-buffer calls (the plugin's situation: a mapped staging surface) --------------------
+    @staticmethod
+    def _sd(rgb, yuv, width, colorspace):
+        ref = rgb if rgb is not None else yuv
+        h, ls = (ref.shape[0], ref.shape[1]) if ref is not None else (0, 0)
+        return SurfaceData(_hptr(rgb), _hptr(yuv), ls, width, h, colorspace, None)
+
+    def convert_rgb_yuv(self, rgb, width, colorspace=2, out_linesize=None):
+        h = rgb.shape[0]
+        out = np.full((h, out_linesize or rgb.shape[1]), 0xA5, dtype=np.uint8)
+        self._check(self.L.scope_convert_rgb_yuv(self.h, _hptr(rgb), rgb.shape[1], _hptr(out), out.shape[1], width, h,
+                                                 colorspace, 0))
+        return out
+
+    def vectorscope(self, yuv=None, rgb=None, width=0, colorspace=2, fuse_k0=False, out=None):
+        out = np.full((256, 256), 0xEE, dtype=np.uint8) if out is None else out
+        sd = self._sd(rgb, yuv, width, colorspace)
+        st = self._check(self.L.scope_vectorscope(self.h, C.byref(sd), FUSE_K0 if fuse_k0 else 0, _hptr(out)),
+                         allow=(ENODATA,))
+        return out, st
+
+    def waveform(self, rgb=None, yuv=None, width=0, components=COMP_RGB, colorspace=2, fuse_k0=False, out=None):
+        out = np.full((256, width, 4), 0xEE, dtype=np.uint8) if out is None else out
+        sd = self._sd(rgb, yuv, width, colorspace)
+        st = self._check(self.L.scope_waveform(self.h, C.byref(sd), components, FUSE_K0 if fuse_k0 else 0, _hptr(out)),
+                         allow=(ENODATA,))
+        return out, st
+
+    def histogram_counts(self, rgb=None, yuv=None, width=0, components=COMP_RGB, colorspace=2, fuse_k0=False):
+        out = np.full((256, 4), 0xEEEEEEEE, dtype=np.uint32)
+        sd = self._sd(rgb, yuv, width, colorspace)
+        st = self._check(self.L.scope_histogram_counts(self.h, C.byref(sd), components, FUSE_K0 if fuse_k0 else 0,
+                                                       out.ctypes.data_as(C.c_void_p)), allow=(ENODATA,))
+        return out, st
+
+    def histogram(self, rgb=None, yuv=None, width=0, components=COMP_RGB, logscale=0, level_fixed=0, level_ratio=0,
+                  colorspace=2, fuse_k0=False, hi_max_in=(0, 0, 0)):
+        tex = np.full(4096, 0xEE, dtype=np.uint8)
+        hi = np.array(hi_max_in, dtype=np.uint32)
+        sd = self._sd(rgb, yuv, width, colorspace)
+        st = self._check(self.L.scope_histogram(self.h, C.byref(sd), components, logscale, level_fixed, level_ratio,
+                                                FUSE_K0 if fuse_k0 else 0, _hptr(tex), hi.ctypes.data_as(C.c_void_p)),
+                         allow=(ENODATA,))
+        return tex.view(np.float32).reshape(256, 4), hi, st
+
+    def histogram_level(self, counts, width, height, components, logscale=0, level_fixed=0, level_ratio=0):
+        tex = np.ascontiguousarray(counts, dtype=np.uint32).copy().view(np.uint8).reshape(-1)
+        hi = np.zeros(3, dtype=np.uint32)
+        self.L.scope_histogram_level(_hptr(tex), hi.ctypes.data_as(C.c_void_p), width, height, components, logscale,
+                                     level_fixed, level_ratio)
+        return tex.view(np.float32).reshape(256, 4), hi
+
+    # -- batched calls, host or device planes ------------------------------------------------------
+    def _batch(self, plane_ptrs, linesize, width, height, planes_are_rgb, colorspace):
+        arr = (C.c_void_p * len(plane_ptrs))(*plane_ptrs)
+        b = Batch(C.cast(arr, C.POINTER(C.c_void_p)), len(plane_ptrs), linesize, width, height, int(planes_are_rgb),
+                  colorspace)
+        b._keep = arr
+        return b
+
+    def vectorscope_batch_host(self, frames, width, planes_are_rgb=False, colorspace=2):
+        n, (h, ls) = len(frames), frames[0].shape
+        out = np.full((n, 256, 256), 0xEE, dtype=np.uint8)
+        b = self._batch([f.ctypes.data for f in frames], ls, width, h, planes_are_rgb, colorspace)
+        self._check(self.L.scope_vectorscope_batch(self.h, C.byref(b), 0, _hptr(out)))
+        return out
+
+    def waveform_batch_host(self, frames, width, components, planes_are_rgb=True, colorspace=2):
+        n, (h, ls) = len(frames), frames[0].shape
+        out = np.full((n, 256, width, 4), 0xEE, dtype=np.uint8)
+        b = self._batch([f.ctypes.data for f in frames], ls, width, h, planes_are_rgb, colorspace)
+        st = self._check(self.L.scope_waveform_batch(self.h, C.byref(b), components, 0, _hptr(out)), allow=(ENODATA,))
+        return out, st
+
+    def histogram_counts_batch_host(self, frames, width, components, planes_are_rgb=True, colorspace=2):
+        n, (h, ls) = len(frames), frames[0].shape
+        out = np.full((n, 256, 4), 0xEEEEEEEE, dtype=np.uint32)
+        b = self._batch([f.ctypes.data for f in frames], ls, width, h, planes_are_rgb, colorspace)
+        st = self._check(self.L.scope_histogram_counts_batch(self.h, C.byref(b), components, 0,
+                                                             out.ctypes.data_as(C.c_void_p)), allow=(ENODATA,))
+        return out, st
+
+    def make_device_batch(self, frames_dev, linesize, width, height, planes_are_rgb=False, colorspace=2):
+        """frames_dev: device tensor [n, height, linesize] uint8 (or a list of plane tensors)."""
+        if hasattr(frames_dev, "data_ptr"):
+            base, n = int(frames_dev.data_ptr()), int(frames_dev.shape[0])
+            ptrs = [base + i * height * linesize for i in range(n)]
+        else:
+            ptrs = [int(t.data_ptr()) for t in frames_dev]
+        return self._batch(ptrs, linesize, width, height, planes_are_rgb, colorspace)
+
+    def vectorscope_batch_dev(self, batch, out_dev, sync=True):
+        self._check(self.L.scope_vectorscope_batch(self.h, C.byref(batch), IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC),
+                                                   _dptr(out_dev)))
+
+    def waveform_batch_dev(self, batch, components, out_dev, sync=True):
+        self._check(self.L.scope_waveform_batch(self.h, C.byref(batch), components,
+                                                IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC), _dptr(out_dev)))
+
+    def histogram_counts_batch_dev(self, batch, components, out_dev, sync=True):
+        self._check(self.L.scope_histogram_counts_batch(self.h, C.byref(batch), components,
+                                                        IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC), _dptr(out_dev)))
+
+    def convert_rgb_yuv_dev(self, rgb_dev, rgb_linesize, yuv_dev, yuv_linesize, width, height, colorspace=2, sync=True):
+        self._check(self.L.scope_convert_rgb_yuv(self.h, _dptr(rgb_dev), rgb_linesize, _dptr(yuv_dev), yuv_linesize,
+                                                 width, height, colorspace, IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC)))
+
+    def widen_dev(self, in_dev, out_dev, n):
+        self._check(self.L.scope_table_widen_u8_u32(self.h, _dptr(in_dev), _dptr(out_dev), n))
+
+    def clamp_dev(self, in_dev, out_dev, n):
+        self._check(self.L.scope_table_clamp_u32_u8(self.h, _dptr(in_dev), _dptr(out_dev), n))
+
+    def pack16_dev(self, in_dev, out_dev, n_pairs):
+        self._check(self.L.scope_table_pack_u8_u16x2(self.h, _dptr(in_dev), _dptr(out_dev), n_pairs))
+
+    def unpack16_clamp_dev(self, in_dev, out_dev, n_pairs):
+        self._check(self.L.scope_table_unpack_clamp_u16x2_u8(self.h, _dptr(in_dev), _dptr(out_dev), n_pairs))
+
+    def profile(self, enable: bool):
+        self._check(self.L.scope_ctx_profile(self.h, int(enable)))
+
+    def kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self.L.scope_ctx_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,183 @@
+"""Parity checks shared by the CPU-emulation tests and the -m gpu tests.
+
+Every function drives the product path through the C-ABI (via obs_color_monitor_amd.ScopeContext)
+and compares with oracle/ on the same seeded input.  Integer tables must be bit-exact.
+"""
+import numpy as np
+
+DISTS = {1: "uniform", 2: "concentrated", 3: "flat", 4: "bars", 5: "alpha_holes"}
+# (components) the reference UI exposes + single channels (BASELINE config 3) + odd masks
+COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
+
+
+def frames(oracle, w, h, dist, linesize=None, seed=0, colorspace=2):
+    rgb = oracle.fill_frame(w, h, dist, seed, linesize)
+    yuv = oracle.rgb_to_yuv(rgb, w, colorspace)
+    return rgb, yuv
+
+
+def assert_same(got, want, what):
+    if not np.array_equal(got, want):
+        bad = np.argwhere(np.asarray(got) != np.asarray(want))
+        first = tuple(bad[0])
+        raise AssertionError(f"{what}: {len(bad)} mismatching cells, first at {first}: "
+                             f"got {np.asarray(got)[first]} want {np.asarray(want)[first]}")
+
+
+def check_k0(ctx, oracle, w, h, dist, colorspace, linesize=None):
+    rgb = oracle.fill_frame(w, h, dist, 0, linesize)
+    want = oracle.rgb_to_yuv(rgb, w, colorspace)
+    got = ctx.convert_rgb_yuv(rgb, w, colorspace)
+    assert_same(got[:, : 4 * w], want[:, : 4 * w], f"K0 {w}x{h} d{dist} cs{colorspace}")
+
+
+def check_vectorscope(ctx, oracle, w, h, dist, linesize=None, fuse=False, colorspace=2):
+    rgb, yuv = frames(oracle, w, h, dist, linesize, colorspace=colorspace)
+    want = oracle.vectorscope(yuv, w)
+    if fuse:
+        got, st = ctx.vectorscope(rgb=rgb, width=w, colorspace=colorspace, fuse_k0=True)
+    else:
+        got, st = ctx.vectorscope(yuv=yuv, width=w)
+    assert st == 0
+    assert_same(got, want, f"vectorscope {w}x{h} d{dist} ls{linesize} fuse{fuse}")
+
+
+def check_waveform(ctx, oracle, w, h, dist, components, linesize=None, fuse=False, colorspace=2):
+    rgb, yuv = frames(oracle, w, h, dist, linesize, colorspace=colorspace)
+    want = oracle.waveform(rgb, yuv, w, components)
+    if fuse:
+        got, st = ctx.waveform(rgb=rgb, yuv=None, width=w, components=components, colorspace=colorspace, fuse_k0=True)
+    else:
+        got, st = ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=components)
+    assert st == 0
+    assert_same(got, want, f"waveform {w}x{h} d{dist} c{components:#x} ls{linesize} fuse{fuse}")
+
+
+def check_histogram_counts(ctx, oracle, w, h, dist, components, linesize=None, fuse=False, colorspace=2):
+    rgb, yuv = frames(oracle, w, h, dist, linesize, colorspace=colorspace)
+    want = oracle.histogram_counts(rgb, yuv, w, components)
+    if fuse:
+        got, st = ctx.histogram_counts(rgb=rgb, yuv=None, width=w, components=components, colorspace=colorspace,
+                                       fuse_k0=True)
+    else:
+        got, st = ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=components)
+    assert st == 0
+    assert_same(got, want, f"histogram {w}x{h} d{dist} c{components:#x} ls{linesize} fuse{fuse}")
+
+
+def check_histogram_full(ctx, oracle, w, h, dist, components, logscale, level_fixed, level_ratio):
+    """K3 + K3b.  Counts and hi_max are integers (bit-exact); the float table uses the same libm
+    logf on the same host as the oracle, so it is compared bit-exactly as well."""
+    rgb, yuv = frames(oracle, w, h, dist)
+    want_f, want_hi = oracle.histogram(rgb, yuv, w, components, logscale, level_fixed, level_ratio, (7, 8, 9))
+    got_f, got_hi, st = ctx.histogram(rgb=rgb, yuv=yuv, width=w, components=components, logscale=logscale,
+                                      level_fixed=level_fixed, level_ratio=level_ratio, hi_max_in=(7, 8, 9))
+    assert st == 0
+    assert_same(got_hi, want_hi, "hi_max")
+    assert_same(got_f.view(np.uint32), want_f.view(np.uint32), f"histogram float table c{components:#x} log{logscale}")
+
+
+def check_batches(ctx, oracle, w, h, n):
+    """n frames of mixed content in one batched call each."""
+    rgbs, yuvs = [], []
+    for i in range(n):
+        r, y = frames(oracle, w, h, 1 + i % 5, seed=1000 + i)
+        rgbs.append(r)
+        yuvs.append(y)
+    got = ctx.vectorscope_batch_host(yuvs, w, planes_are_rgb=False)
+    for i in range(n):
+        assert_same(got[i], oracle.vectorscope(yuvs[i], w), f"vectorscope batch frame {i}")
+    got = ctx.vectorscope_batch_host(rgbs, w, planes_are_rgb=True, colorspace=2)
+    for i in range(n):
+        assert_same(got[i], oracle.vectorscope(yuvs[i], w), f"vectorscope batch (fused K0) frame {i}")
+    got, st = ctx.waveform_batch_host(rgbs, w, 0x07, planes_are_rgb=True)
+    assert st == 0
+    for i in range(n):
+        assert_same(got[i], oracle.waveform(rgbs[i], None, w, 0x07), f"waveform batch frame {i}")
+    got, st = ctx.waveform_batch_host(rgbs, w, 0x20, planes_are_rgb=True, colorspace=2)
+    assert st == 0
+    for i in range(n):
+        assert_same(got[i], oracle.waveform(None, yuvs[i], w, 0x20), f"waveform batch luma (fused K0) frame {i}")
+    got, st = ctx.histogram_counts_batch_host(rgbs, w, 0x07, planes_are_rgb=True)
+    assert st == 0
+    for i in range(n):
+        assert_same(got[i], oracle.histogram_counts(rgbs[i], None, w, 0x07), f"histogram batch frame {i}")
+
+
+def check_error_behaviour(ctx, oracle):
+    """NULL planes leave the caller's table untouched (the reference's callbacks return early:
+    vectorscope.c:252, waveform.c:276-281, histogram.c:436-441); masks that select no plane give
+    a zeroed table (waveform.c:225-234, histogram.c:363-373)."""
+    import obs_color_monitor_amd as ocm
+
+    w, h = 32, 8
+    rgb, yuv = frames(oracle, w, h, 1)
+    out, st = ctx.vectorscope(yuv=None, rgb=rgb, width=w)  # no yuv, no FUSE flag
+    assert st == ocm.ENODATA and (out == 0xEE).all()
+    out, st = ctx.waveform(rgb=None, yuv=yuv, width=w, components=0x07)
+    assert st == ocm.ENODATA and (out == 0xEE).all()
+    out, st = ctx.waveform(rgb=rgb, yuv=None, width=w, components=0x20)
+    assert st == ocm.ENODATA and (out == 0xEE).all()
+    out, st = ctx.histogram_counts(rgb=None, yuv=yuv, width=w, components=0x07)
+    assert st == ocm.ENODATA and (out == 0xEEEEEEEE).all()
+    out, st = ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x08)
+    assert st == 0 and (out == 0).all()
+    out, st = ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=0x80)
+    assert st == 0 and (out == 0).all()
+    # the full histogram with an unselectable mask: zero table, hi_max untouched
+    f, hi, st = ctx.histogram(rgb=rgb, yuv=yuv, width=w, components=0x00, hi_max_in=(7, 8, 9))
+    assert st == 0 and (f.view(np.uint32) == 0).all() and tuple(hi) == (7, 8, 9)
+    # linesize smaller than the row is rejected
+    bad = np.zeros((4, 16), dtype=np.uint8)
+    with __import__("pytest").raises(ocm.ScopeError):
+        ctx.vectorscope(yuv=bad, width=8)
+
+
+def check_device_path(ctx, oracle, to_dev, to_host, w, h, linesize, n=2, offset=0):
+    """Device-resident planes/tables through the batched entry points (IN_DEVICE | OUT_DEVICE).
+    to_dev(np.ndarray) -> (handle, address); to_host(handle) -> np.ndarray.  `offset` shifts the
+    plane start by that many bytes (4-byte aligned but not 16) to force the unaligned pixel path."""
+    import numpy as np
+
+    rgbs, yuvs = [], []
+    for i in range(n):
+        r, y = frames(oracle, w, h, 1 + i % 5, linesize, seed=77 + i)
+        rgbs.append(r)
+        yuvs.append(y)
+
+    def upload(fr):
+        flat = np.concatenate([np.zeros(offset, np.uint8)] + [f.reshape(-1) for f in fr])
+        hnd, addr = to_dev(flat)
+        return hnd, [addr + offset + i * h * linesize for i in range(n)]
+
+    hy, py = upload(yuvs)
+    hr, pr = upload(rgbs)
+    by = ctx._batch(py, linesize, w, h, False, 2)
+    br = ctx._batch(pr, linesize, w, h, True, 2)
+
+    out_h, out_a = to_dev(np.full(n * 65536, 0xEE, np.uint8))
+    ctx.vectorscope_batch_dev(by, out_a)
+    got = to_host(out_h).reshape(n, 256, 256)
+    for i in range(n):
+        assert_same(got[i], oracle.vectorscope(yuvs[i], w), f"device vectorscope frame {i}")
+    ctx.vectorscope_batch_dev(br, out_a)
+    got = to_host(out_h).reshape(n, 256, 256)
+    for i in range(n):
+        assert_same(got[i], oracle.vectorscope(yuvs[i], w), f"device vectorscope fused frame {i}")
+
+    out_h, out_a = to_dev(np.full(n * 256 * w * 4, 0xEE, np.uint8))
+    ctx.waveform_batch_dev(br, 0x07, out_a)
+    got = to_host(out_h).reshape(n, 256, w, 4)
+    for i in range(n):
+        assert_same(got[i], oracle.waveform(rgbs[i], None, w, 0x07), f"device waveform frame {i}")
+    ctx.waveform_batch_dev(by, 0x70, out_a)
+    got = to_host(out_h).reshape(n, 256, w, 4)
+    for i in range(n):
+        assert_same(got[i], oracle.waveform(None, yuvs[i], w, 0x70), f"device waveform yuv frame {i}")
+
+    out_h, out_a = to_dev(np.full(n * 4096, 0xEE, np.uint8))
+    ctx.histogram_counts_batch_dev(br, 0x07, out_a)
+    got = to_host(out_h).view(np.uint32).reshape(n, 256, 4)
+    for i in range(n):
+        assert_same(got[i], oracle.histogram_counts(rgbs[i], None, w, 0x07), f"device histogram frame {i}")
+    return hy, hr

@@ -1,0 +1,121 @@
+"""Parity of the product sources against the oracle WITHOUT a GPU: csrc/*.hip compiled for the CPU
+by tests/emul (thread-per-GPU-thread executor).  Small frames only; the -m gpu tests repeat these
+on the real kernels and add the full BASELINE sizes."""
+import pytest
+
+import parity_cases as pc
+
+SMALL = [(64, 36, None), (70, 9, None), (33, 5, 140), (64, 8, 320), (1, 1, None), (130, 3, 524)]
+
+
+@pytest.mark.parametrize("dist", [1, 2, 3, 5])
+def test_vectorscope_distributions(emul_ctx, oracle, dist):
+    pc.check_vectorscope(emul_ctx, oracle, 64, 36, dist)
+
+
+@pytest.mark.parametrize("w,h,ls", SMALL)
+def test_vectorscope_geometry(emul_ctx, oracle, w, h, ls):
+    pc.check_vectorscope(emul_ctx, oracle, w, h, 1, ls)
+
+
+@pytest.mark.parametrize("merge", [0, 1, 2])
+def test_vectorscope_merge_variants(emul_ctx, oracle, merge):
+    emul_ctx.set_option("vss.merge", merge)
+    try:
+        pc.check_vectorscope(emul_ctx, oracle, 70, 9, 3)
+        pc.check_vectorscope(emul_ctx, oracle, 70, 9, 2)
+    finally:
+        emul_ctx.set_option("vss.merge", 1)
+
+
+def test_vectorscope_saturation_and_epochs(emul_ctx, oracle):
+    """One workgroup (slices=1) sees 262144 flat pixels: counters must survive four 65280-pixel
+    epochs with clamp passes in between and still report exactly 255."""
+    emul_ctx.set_option("slices", 1)
+    try:
+        for merge in (0, 1):
+            emul_ctx.set_option("vss.merge", merge)
+            pc.check_vectorscope(emul_ctx, oracle, 512, 512, 3)
+        pc.check_vectorscope(emul_ctx, oracle, 511, 300, 2, 2048)  # tails + epochs + pitch
+    finally:
+        emul_ctx.set_option("slices", 0)
+        emul_ctx.set_option("vss.merge", 1)
+
+
+@pytest.mark.parametrize("cs", [1, 2])
+def test_vectorscope_fused_k0(emul_ctx, oracle, cs):
+    pc.check_vectorscope(emul_ctx, oracle, 70, 9, 1, None, fuse=True, colorspace=cs)
+    pc.check_vectorscope(emul_ctx, oracle, 64, 8, 4, None, fuse=True, colorspace=cs)
+
+
+@pytest.mark.parametrize("comp", pc.COMPONENTS)
+def test_waveform_components(emul_ctx, oracle, comp):
+    pc.check_waveform(emul_ctx, oracle, 70, 9, 5, comp)
+
+
+@pytest.mark.parametrize("w,h,ls", SMALL)
+def test_waveform_geometry(emul_ctx, oracle, w, h, ls):
+    pc.check_waveform(emul_ctx, oracle, w, h, 1, 0x07, ls)
+
+
+def test_waveform_saturation_and_bands(emul_ctx, oracle):
+    pc.check_waveform(emul_ctx, oracle, 64, 600, 3, 0x07)  # every column saturates at 255
+    emul_ctx.set_option("slices", 5)  # five row bands -> partial tables + saturating reduce
+    try:
+        pc.check_waveform(emul_ctx, oracle, 64, 600, 2, 0x70)
+        pc.check_waveform(emul_ctx, oracle, 66, 40, 1, 0x07)  # width % 4 != 0: single band fallback
+    finally:
+        emul_ctx.set_option("slices", 0)
+
+
+def test_waveform_fused_k0(emul_ctx, oracle):
+    pc.check_waveform(emul_ctx, oracle, 70, 9, 1, 0x20, None, fuse=True, colorspace=1)
+    pc.check_waveform(emul_ctx, oracle, 70, 9, 1, 0x50, None, fuse=True, colorspace=2)
+
+
+@pytest.mark.parametrize("comp", pc.COMPONENTS)
+def test_histogram_components(emul_ctx, oracle, comp):
+    pc.check_histogram_counts(emul_ctx, oracle, 70, 9, 5, comp)
+
+
+@pytest.mark.parametrize("w,h,ls", SMALL)
+def test_histogram_geometry(emul_ctx, oracle, w, h, ls):
+    pc.check_histogram_counts(emul_ctx, oracle, w, h, 2, 0x07, ls)
+
+
+def test_histogram_fused_k0(emul_ctx, oracle):
+    pc.check_histogram_counts(emul_ctx, oracle, 70, 9, 1, 0x70, None, fuse=True, colorspace=2)
+
+
+@pytest.mark.parametrize("logscale,fixed,ratio", [(0, 0, 0), (1, 0, 0), (0, 100, 0), (1, 0, 250), (0, 0, 1), (1, 5, 9)])
+def test_histogram_level_pass(emul_ctx, oracle, logscale, fixed, ratio):
+    pc.check_histogram_full(emul_ctx, oracle, 64, 36, 2, 0x07, logscale, fixed, ratio)
+    pc.check_histogram_full(emul_ctx, oracle, 64, 36, 1, 0x20, logscale, fixed, ratio)
+
+
+@pytest.mark.parametrize("cs", [1, 2])
+def test_k0(emul_ctx, oracle, cs):
+    pc.check_k0(emul_ctx, oracle, 70, 9, 1, cs)
+    pc.check_k0(emul_ctx, oracle, 33, 5, 4, cs, 140)
+
+
+def test_batches(emul_ctx, oracle):
+    pc.check_batches(emul_ctx, oracle, 64, 12, 3)   # 3 frames x 2 slices on the 6 emulated CUs
+    pc.check_batches(emul_ctx, oracle, 66, 5, 7)    # more frames than CUs
+
+
+def test_error_behaviour(emul_ctx, oracle):
+    pc.check_error_behaviour(emul_ctx, oracle)
+
+
+def _np_dev(a):
+    """In the emulation "device memory" is host memory, so a numpy buffer is its own handle."""
+    import numpy as np
+
+    buf = np.ascontiguousarray(a).copy()
+    return buf, buf.ctypes.data
+
+
+@pytest.mark.parametrize("w,h,ls,off", [(64, 12, 256, 0), (35, 7, 140, 0), (64, 12, 256, 4), (35, 7, 148, 8)])
+def test_device_path_and_unaligned_rows(emul_ctx, oracle, w, h, ls, off):
+    pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, w, h, ls, n=2, offset=off)
