@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its config: Gpix/s of scope accumulation @3840x2160.
+
+  python bench.py --gpus N --steps K --warmup W         (N > 1: launched under torch.distributed.run)
+
+A *step* is one pass of the hot path over one batch of synthetic input: by default the 256x256
+CbCr vectorscope scatter (BASELINE configs[1]) over `--frames` (32) distinct 3840x2160 BGRA8 frames
+that are already resident in HBM (32 x 33 MB > the 256 MB Infinity Cache, so every step streams
+from HBM).  Frames are uniform-random RGB pushed through the K0 kernel, i.e. the staged Y'CbCr
+planes the reference's vss_draw_vectorscope reads.  Every step goes through the C-ABI of
+libscope_hip.so (no CPU path exists in the product).
+
+N > 1 ("weak"): every rank owns one 3840x2160 row tile of a frame N times as tall; the ranks'
+clamped 256x256 tables are summed over RCCL (two bins per int32 word) and clamped once, overlapped
+with the next step's accumulation.  value = all ranks' pixels / max-over-ranks time.
+
+Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+W4K, H4K = 3840, 2160
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32, help="distinct HBM-resident frames per step")
+    ap.add_argument("--workload", default="vectorscope", choices=["vectorscope", "vectorscope_rgb", "waveform", "histogram"])
+    ap.add_argument("--components", type=lambda s: int(s, 0), default=0x07)
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat"])
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import obs_color_monitor_amd as ocm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = ocm.ScopeContext(local_rank)  # raises without libscope_hip.so / a GPU: no fallback
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    info = ctx.device_info()
+
+    # ---- synthetic input, resident in HBM ------------------------------------------------------
+    n, w, h = args.frames, W4K, H4K
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x9E3779B9 + rank)
+    if args.dist == "uniform":
+        rgb = torch.randint(0, 256, (n, h, w, 4), dtype=torch.uint8, device="cuda", generator=g)
+    elif args.dist == "concentrated":
+        rgb = torch.randint(120, 136, (n, h, w, 4), dtype=torch.uint8, device="cuda", generator=g)
+    else:
+        rgb = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
+        rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0xD7, 0xCC, 0xC6
+    rgb[..., 3] = 255
+    rgb = rgb.view(n, h, w * 4)
+    yuv = torch.empty_like(rgb)
+    for i in range(n):
+        ctx.convert_rgb_yuv_dev(rgb[i], 4 * w, yuv[i], 4 * w, w, h, 2, sync=False)
+    ctx.sync()
+
+    wl = args.workload
+    if wl == "vectorscope":
+        batch = ctx.make_device_batch(yuv, 4 * w, w, h, planes_are_rgb=False)
+        table_bytes = 65536
+    elif wl == "vectorscope_rgb":
+        batch = ctx.make_device_batch(rgb, 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+        table_bytes = 65536
+    elif wl == "waveform":
+        batch = ctx.make_device_batch(rgb, 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+        table_bytes = 256 * w * 4
+    else:
+        batch = ctx.make_device_batch(rgb, 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+        table_bytes = 4096
+    tables = [torch.empty((n, table_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    reducer = None
+    if world > 1:
+        assert wl != "waveform", "multi-GPU waveform shards by column strip without a reduction; bench covers K1/K3"
+        from obs_color_monitor_amd.row_tiles import TableAllReduce
+
+        reducer = TableAllReduce(ctx, n * table_bytes, "cuda", "sum_u32" if wl == "histogram" else "sat_u8")
+    result_tables = [None]
+
+    def step(i):
+        buf = i & 1
+        if wl in ("vectorscope", "vectorscope_rgb"):
+            ctx.vectorscope_batch_dev(batch, tables[buf], sync=False)
+        elif wl == "waveform":
+            ctx.waveform_batch_dev(batch, args.components, tables[buf], sync=False)
+        else:
+            ctx.histogram_counts_batch_dev(batch, args.components, tables[buf], sync=False)
+        if reducer is not None:
+            reducer.submit(tables[buf])  # the previous step's collective overlapped this accumulation
+        else:
+            result_tables[0] = tables[buf]
+
+    def drain():
+        if reducer is not None:
+            result_tables[0] = reducer.drain()
+
+    # ---- warm-up, then the timed region --------------------------------------------------------
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = ctx.kernel_ms()
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity of what was just computed (untimed) ---------------------------------------------
+    import scope_oracle
+
+    o = scope_oracle.COracle()
+    final = result_tables[0].view(torch.uint8).view(n, table_bytes)
+    check_frames = sorted({0, n - 1})
+    parity = True
+    host_planes = {}
+    for f in check_frames:
+        src = yuv if wl == "vectorscope" else rgb
+        host_planes[f] = src[f].cpu().numpy()
+        if wl in ("vectorscope", "vectorscope_rgb"):
+            y = host_planes[f] if wl == "vectorscope" else o.rgb_to_yuv(host_planes[f], w, 2)
+            mine = o.vectorscope(y, w).astype(np.int32)
+        elif wl == "waveform":
+            c = args.components
+            mine = o.waveform(host_planes[f], o.rgb_to_yuv(host_planes[f], w, 2), w, c).astype(np.int32)
+        else:
+            mine = o.histogram_counts(host_planes[f], o.rgb_to_yuv(host_planes[f], w, 2), w, args.components)
+            mine = mine.astype(np.int64)
+        want = torch.from_numpy(mine.reshape(-1).astype(np.int64)).cuda()
+        if world > 1:
+            dist.all_reduce(want)
+        if wl != "histogram":
+            want = want.clamp(max=255)
+            got = final[f].to(torch.int64)
+        else:
+            got = final[f].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        parity = parity and bool(torch.equal(got, want))
+
+    # ---- the numbers ------------------------------------------------------------------------------
+    pix_per_step = world * n * w * h
+    value = pix_per_step * args.steps / elapsed / 1e9
+    algo_bytes = n * (4 * w * h + (table_bytes if wl != "histogram" else 4096))  # SURVEY.md 8(d), per launch
+    kern_avg_ms = kernel_ms / launches if launches else float("nan")
+    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches else float("nan")
+    result = {
+        "metric": "Gpix/s scope accumulation @3840×2160; achieved HBM GB/s vs peak",
+        "value": round(value, 3),
+        "unit": "Gpix/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8" if wl != "histogram" else "u32",
+        "data": "synthetic",
+        "parity": "bit-exact vs oracle" if parity else "MISMATCH vs oracle",
+        "config": {
+            "workload": {
+                "vectorscope": "vectorscope 256x256 CbCr scatter (K1) over staged Y'CbCr planes",
+                "vectorscope_rgb": "vectorscope with fused K0 over RGB planes",
+                "waveform": f"waveform per-column 256-bin (K2), components {args.components:#04x}",
+                "histogram": f"histogram 3x256 u32 (K3), components {args.components:#04x}",
+            }[wl] + f", 3840x2160 BGRA8, {n} distinct HBM-resident frames per step, {args.dist} RGB through K0",
+            "frames_per_step": n,
+            "width": w,
+            "height": h,
+            "input_distribution": args.dist,
+            "partition": "one frame batch per GPU" if world == 1 else f"{world} row tiles of 3840x2160 + RCCL sum of tables",
+            "device": info["name"],
+            "compute_units": info["compute_units"],
+            "options": args.option,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": {"vectorscope": "scope_vss_kernel", "vectorscope_rgb": "scope_vss_kernel", "waveform": "scope_wvs_kernel",
+                       "histogram": "scope_his_kernel"}[wl],
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "avg_launch_ms": round(kern_avg_ms, 5),
+            "launches_timed": launches,
+        },
+    }
+
+    # ---- CPU baseline: the oracle (port of the reference loop) on this host, bounded sample --------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        plane = host_planes[0]
+        plane_rgb = rgb[0].cpu().numpy()
+        plane_yuv = yuv[0].cpu().numpy()
+        t_end = time.perf_counter() + args.cpu_seconds
+        reps, t_start = 0, time.perf_counter()
+        while time.perf_counter() < t_end or reps < 3:
+            if wl in ("vectorscope", "vectorscope_rgb"):
+                o.vectorscope(plane_yuv, w)
+            elif wl == "waveform":
+                o.waveform(plane_rgb, plane_yuv, w, args.components)
+            else:
+                o.histogram_counts(plane_rgb, plane_yuv, w, args.components)
+            reps += 1
+        cpu_t = time.perf_counter() - t_start
+        result["cpu_baseline"] = {
+            "value": round(reps * w * h / cpu_t / 1e9, 4),
+            "unit": "Gpix/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{reps} passes of oracle {wl} (scope_oracle.c, gcc -O2, one thread as the reference's "
+                      f"single color-monitor thread) over frame 0 of the same batch, {cpu_t:.1f} s; "
+                      f"host has {os.cpu_count()} cores; excludes the reference's GPU->CPU readback",
+        }
+        del plane
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if not parity:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

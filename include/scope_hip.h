@@ -163,9 +163,10 @@ int scope_table_unpack_clamp_u16x2_u8(scope_ctx *ctx, const uint32_t *in, uint8_
 /* ---- measurement ---------------------------------------------------------------------------
  * With profiling on, every accumulation launch (the dominant kernel of a call, not the small
  * partial-table reduction) is bracketed by HIP events on the context's stream.
- * scope_ctx_kernel_ms() waits for the most recent one and returns its duration. */
+ * scope_ctx_kernel_ms() waits for them and returns how many launches were bracketed since
+ * profiling was switched on (the most recent 512 at most) and their summed duration. */
 int scope_ctx_profile(scope_ctx *ctx, int enable);
-int scope_ctx_kernel_ms(scope_ctx *ctx, float *ms);
+int scope_ctx_kernel_ms(scope_ctx *ctx, uint32_t *launches, float *total_ms);
 
 #ifdef __cplusplus
 }

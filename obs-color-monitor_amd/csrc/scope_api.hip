@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define SCOPE_PROFILE_SLOTS 512u
+
 struct scope_ctx {
 	int device;
 	int num_cu;
@@ -29,8 +31,8 @@ struct scope_ctx {
 	ScopeTuning tn;
 	int slices_override;
 	int profile;
-	int have_timing;
-	hipEvent_t ev0, ev1;
+	uint32_t timed; /* accumulation launches bracketed since profiling was switched on */
+	hipEvent_t ev[2 * SCOPE_PROFILE_SLOTS];
 	char err[256];
 };
 
@@ -71,15 +73,16 @@ int grow(scope_ctx *ctx, uint8_t **buf, size_t *cap, size_t need)
 }
 
 /* Accumulation launch, bracketed by events when profiling is on. */
-#define TIMED_LAUNCH(ctx, call)                                                \
-	do {                                                                   \
-		if ((ctx)->profile)                                            \
-			HIP_TRY(ctx, hipEventRecord((ctx)->ev0, (ctx)->stream)); \
-		HIP_TRY(ctx, call);                                            \
-		if ((ctx)->profile) {                                          \
-			HIP_TRY(ctx, hipEventRecord((ctx)->ev1, (ctx)->stream)); \
-			(ctx)->have_timing = 1;                                \
-		}                                                              \
+#define TIMED_LAUNCH(ctx, call)                                                                    \
+	do {                                                                                       \
+		const uint32_t slot_ = 2u * ((ctx)->timed % SCOPE_PROFILE_SLOTS);                  \
+		if ((ctx)->profile)                                                                \
+			HIP_TRY(ctx, hipEventRecord((ctx)->ev[slot_], (ctx)->stream));             \
+		HIP_TRY(ctx, call);                                                                \
+		if ((ctx)->profile) {                                                              \
+			HIP_TRY(ctx, hipEventRecord((ctx)->ev[slot_ + 1], (ctx)->stream));         \
+			(ctx)->timed++;                                                            \
+		}                                                                                  \
 	} while (0)
 
 size_t round_up(size_t v, size_t a)
@@ -399,10 +402,11 @@ int scope_ctx_create(int device, scope_ctx **out)
 		return SCOPE_EIO;
 	}
 	ctx->stream = ctx->own_stream;
-	if (scope_kernels_init() != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-	    hipEventCreate(&ctx->ev1) != hipSuccess) {
-		(void)hipStreamDestroy(ctx->own_stream);
-		free(ctx);
+	bool ok = scope_kernels_init() == hipSuccess;
+	for (uint32_t i = 0; ok && i < 2 * SCOPE_PROFILE_SLOTS; i++)
+		ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+	if (!ok) {
+		scope_ctx_destroy(ctx);
 		return SCOPE_EIO;
 	}
 	ctx->tn.vss_merge = 1;
@@ -426,10 +430,9 @@ void scope_ctx_destroy(scope_ctx *ctx)
 		(void)hipFree(ctx->stage_in);
 	if (ctx->stage_out)
 		(void)hipFree(ctx->stage_out);
-	if (ctx->ev0)
-		(void)hipEventDestroy(ctx->ev0);
-	if (ctx->ev1)
-		(void)hipEventDestroy(ctx->ev1);
+	for (uint32_t i = 0; i < 2 * SCOPE_PROFILE_SLOTS; i++)
+		if (ctx->ev[i])
+			(void)hipEventDestroy(ctx->ev[i]);
 	(void)hipStreamDestroy(ctx->own_stream);
 	free(ctx);
 }
@@ -771,19 +774,27 @@ int scope_ctx_profile(scope_ctx *ctx, int enable)
 	if (!ctx)
 		return SCOPE_EINVAL;
 	ctx->profile = enable != 0;
-	ctx->have_timing = 0;
+	ctx->timed = 0;
 	return SCOPE_OK;
 }
 
-int scope_ctx_kernel_ms(scope_ctx *ctx, float *ms)
+int scope_ctx_kernel_ms(scope_ctx *ctx, uint32_t *launches, float *total_ms)
 {
 	int st = enter(ctx);
 	if (st)
 		return st;
-	if (!ms || !ctx->have_timing)
-		return fail(ctx, SCOPE_EINVAL, "no timed launch yet", hipSuccess);
-	HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-	HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+	if (!launches || !total_ms)
+		return fail(ctx, SCOPE_EINVAL, "NULL argument", hipSuccess);
+	const uint32_t n = ctx->timed < SCOPE_PROFILE_SLOTS ? ctx->timed : SCOPE_PROFILE_SLOTS;
+	float sum = 0.0f;
+	for (uint32_t i = 0; i < n; i++) {
+		float ms = 0.0f;
+		HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2 * i + 1]));
+		HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+		sum += ms;
+	}
+	*launches = n;
+	*total_ms = sum;
 	return SCOPE_OK;
 }
 

@@ -112,7 +112,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_table_pack_u8_u16x2": (i32, [vp, vp, vp, u64]),
         "scope_table_unpack_clamp_u16x2_u8": (i32, [vp, vp, vp, u64]),
         "scope_ctx_profile": (i32, [vp, i32]),
-        "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
+        "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
@@ -300,7 +300,8 @@ class ScopeContext:
     def profile(self, enable: bool):
         self._check(self.L.scope_ctx_profile(self.h, int(enable)))
 
-    def kernel_ms(self) -> float:
-        ms = C.c_float()
-        self._check(self.L.scope_ctx_kernel_ms(self.h, C.byref(ms)))
-        return float(ms.value)
+    def kernel_ms(self):
+        """(number of bracketed accumulation launches, their summed duration in ms)."""
+        n, ms = C.c_uint32(), C.c_float()
+        self._check(self.L.scope_ctx_kernel_ms(self.h, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)

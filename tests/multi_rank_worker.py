@@ -1,0 +1,64 @@
+"""Worker for tests/test_multi_rank.py: one rank of a row-tiled frame, gloo backend, emulated kernels.
+
+Launched by torch.distributed.run with --nproc-per-node 2.  Each rank reduces ITS row tile of the same
+seeded frame through the C-ABI (CPU emulation build), the tables are all-reduced with the package's
+TableAllReduce (the code bench.py uses over RCCL), and every rank compares with the oracle's table of the
+WHOLE frame."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+import obs_color_monitor_amd as ocm  # noqa: E402
+import scope_oracle  # noqa: E402
+from obs_color_monitor_amd.row_tiles import TableAllReduce, tile_rows  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    o = scope_oracle.COracle()
+    ctx = ocm.ScopeContext(0, os.path.join(ROOT, "tests", "emul", "libscope_emul.so"))
+    w, h = 96, 50
+    red = TableAllReduce(ctx, 65536, "cpu", "sat_u8")
+    red32 = TableAllReduce(ctx, 4096, "cpu", "sum_u32")
+    results, results32, wants, wants32 = [], [], [], []
+    for step, dist_kind in enumerate((3, 2, 1)):  # three frames through the double-buffered reducer
+        rgb = o.fill_frame(w, h, dist_kind, 5 + step)
+        yuv = o.rgb_to_yuv(rgb, w, 2)
+        wants.append(o.vectorscope(yuv, w))
+        wants32.append(o.histogram_counts(rgb, yuv, w, 0x07))
+        r0, r1 = tile_rows(h, rank, world)
+        part, st = ctx.vectorscope(yuv=np.ascontiguousarray(yuv[r0:r1]), width=w)
+        assert st == 0
+        done = red.submit(torch.from_numpy(part.reshape(-1)))
+        if done is not None:
+            results.append(done.clone())
+        cnt, st = ctx.histogram_counts(rgb=np.ascontiguousarray(rgb[r0:r1]), yuv=None, width=w, components=0x07)
+        assert st == 0
+        done = red32.submit(torch.from_numpy(cnt.view(np.int32).reshape(-1)))
+        if done is not None:
+            results32.append(done.clone())
+    results.append(red.drain().clone())
+    results32.append(red32.drain().clone())
+    assert len(results) == 3 and len(results32) == 3
+    for got, want in zip(results, wants):
+        assert np.array_equal(got.numpy().reshape(256, 256), want), "row-tiled vectorscope != whole frame"
+    for got, want in zip(results32, wants32):
+        assert np.array_equal(got.numpy().view(np.uint32).reshape(256, 4), want), "row-tiled histogram != whole frame"
+    # a flat frame saturates on every rank: clamped partials 255 + 255 must still give 255
+    assert wants[0].max() == 255
+    dist.barrier()
+    if rank == 0:
+        print("MULTI_RANK_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

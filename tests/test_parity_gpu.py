@@ -1,0 +1,265 @@
+"""-m gpu: the real gfx950 kernels through the C-ABI against the oracle, bit-exact.
+
+Small cases mirror tests/test_parity_emul.py; the rest are BASELINE.json's full sizes
+(1280x720 histogram, 3840x2160 vectorscope / waveform / histogram, 7680x4320 row-tiled vectorscope),
+an exhaustive K0 check over all 2^24 colours, and size-independent properties.
+"""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [(64, 36, None), (70, 9, None), (33, 5, 140), (64, 8, 320), (1, 1, None), (130, 3, 524), (256, 144, None)]
+
+
+def _torch_dev():
+    import torch
+
+    def to_dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return t, int(t.data_ptr())
+
+    def to_host(t):
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+    return to_dev, to_host
+
+
+# ---------------------------------------------------------------------------------- small cases --
+
+
+@pytest.mark.parametrize("dist", [1, 2, 3, 4, 5])
+def test_vectorscope_distributions(hip_ctx, oracle, dist):
+    pc.check_vectorscope(hip_ctx, oracle, 256, 144, dist)
+
+
+@pytest.mark.parametrize("w,h,ls", SMALL)
+def test_geometry_all_scopes(hip_ctx, oracle, w, h, ls):
+    pc.check_vectorscope(hip_ctx, oracle, w, h, 1, ls)
+    pc.check_waveform(hip_ctx, oracle, w, h, 1, 0x07, ls)
+    pc.check_histogram_counts(hip_ctx, oracle, w, h, 2, 0x07, ls)
+    pc.check_k0(hip_ctx, oracle, w, h, 1, 2, ls)
+
+
+@pytest.mark.parametrize("merge", [0, 1, 2])
+@pytest.mark.parametrize("unroll", [2, 4, 8])
+def test_vectorscope_variants(hip_ctx, oracle, merge, unroll):
+    hip_ctx.set_option("vss.merge", merge)
+    hip_ctx.set_option("vss.unroll", unroll)
+    try:
+        for dist in (1, 2, 3, 4):
+            pc.check_vectorscope(hip_ctx, oracle, 640, 360, dist)
+        pc.check_vectorscope(hip_ctx, oracle, 70, 9, 3)
+    finally:
+        hip_ctx.set_option("vss.merge", 1)
+        hip_ctx.set_option("vss.unroll", 4)
+
+
+@pytest.mark.parametrize("slices", [1, 2, 7, 256])
+def test_partition_independence(hip_ctx, oracle, slices):
+    """Any split of a frame over workgroups gives the same tables (saturating/plain sums commute)."""
+    hip_ctx.set_option("slices", slices)
+    try:
+        pc.check_vectorscope(hip_ctx, oracle, 640, 360, 2)
+        pc.check_vectorscope(hip_ctx, oracle, 640, 360, 3)
+        pc.check_histogram_counts(hip_ctx, oracle, 640, 360, 5, 0x07)
+        pc.check_waveform(hip_ctx, oracle, 640, 360, 3, 0x07)
+        pc.check_waveform(hip_ctx, oracle, 330, 200, 5, 0x70)
+    finally:
+        hip_ctx.set_option("slices", 0)
+
+
+def test_vectorscope_epochs_single_workgroup(hip_ctx, oracle):
+    """One workgroup sees > 65280 pixels of one bin: 16-bit LDS counters + clamp passes stay exact."""
+    hip_ctx.set_option("slices", 1)
+    try:
+        for merge in (0, 1, 2):
+            hip_ctx.set_option("vss.merge", merge)
+            pc.check_vectorscope(hip_ctx, oracle, 1280, 720, 3)
+            pc.check_vectorscope(hip_ctx, oracle, 1279, 300, 2, 5120)
+    finally:
+        hip_ctx.set_option("slices", 0)
+        hip_ctx.set_option("vss.merge", 1)
+
+
+@pytest.mark.parametrize("comp", pc.COMPONENTS)
+def test_component_masks(hip_ctx, oracle, comp):
+    pc.check_waveform(hip_ctx, oracle, 330, 77, 5, comp)
+    pc.check_histogram_counts(hip_ctx, oracle, 330, 77, 5, comp)
+
+
+@pytest.mark.parametrize("unroll", [4, 8, 16])
+def test_waveform_unroll(hip_ctx, oracle, unroll):
+    hip_ctx.set_option("wvs.unroll", unroll)
+    try:
+        pc.check_waveform(hip_ctx, oracle, 640, 360, 1, 0x07)
+        pc.check_waveform(hip_ctx, oracle, 64, 700, 3, 0x07)
+    finally:
+        hip_ctx.set_option("wvs.unroll", 8)
+
+
+@pytest.mark.parametrize("cs", [1, 2])
+def test_fused_k0(hip_ctx, oracle, cs):
+    pc.check_vectorscope(hip_ctx, oracle, 640, 360, 1, None, fuse=True, colorspace=cs)
+    pc.check_vectorscope(hip_ctx, oracle, 640, 360, 4, None, fuse=True, colorspace=cs)
+    pc.check_waveform(hip_ctx, oracle, 640, 360, 1, 0x70, None, fuse=True, colorspace=cs)
+    pc.check_histogram_counts(hip_ctx, oracle, 640, 360, 1, 0x70, None, fuse=True, colorspace=cs)
+
+
+@pytest.mark.parametrize("logscale,fixed,ratio", [(0, 0, 0), (1, 0, 0), (0, 100, 0), (1, 0, 250), (0, 0, 1), (1, 5, 9)])
+def test_histogram_level_pass(hip_ctx, oracle, logscale, fixed, ratio):
+    pc.check_histogram_full(hip_ctx, oracle, 640, 360, 2, 0x07, logscale, fixed, ratio)
+    pc.check_histogram_full(hip_ctx, oracle, 640, 360, 1, 0x20, logscale, fixed, ratio)
+
+
+def test_batches_and_error_behaviour(hip_ctx, oracle):
+    pc.check_batches(hip_ctx, oracle, 320, 180, 5)
+    pc.check_batches(hip_ctx, oracle, 66, 5, 70)  # more than SCOPE_MAX_FRAMES: two launches
+    pc.check_error_behaviour(hip_ctx, oracle)
+
+
+@pytest.mark.parametrize("w,h,ls,off", [(640, 360, 2560, 0), (35, 7, 140, 0), (640, 36, 2560, 4), (35, 7, 148, 8)])
+def test_device_path_and_unaligned_rows(hip_ctx, oracle, w, h, ls, off):
+    to_dev, to_host = _torch_dev()
+    pc.check_device_path(hip_ctx, oracle, to_dev, to_host, w, h, ls, n=3, offset=off)
+
+
+# -------------------------------------------------------------------------------- K0 exhaustive --
+
+
+@pytest.mark.parametrize("cs", [1, 2])
+def test_k0_all_colours(hip_ctx, oracle, cs):
+    """Every one of the 2^24 RGB triples through the K0 kernel == the oracle's fp32 evaluation
+    (this also covers the division-free byte/255 used on the GPU)."""
+    v = np.arange(1 << 24, dtype=np.uint32) | np.uint32(0xFF000000)
+    rgb = v.view(np.uint8).reshape(4096, 4096 * 4)
+    want = oracle.rgb_to_yuv(rgb, 4096, cs)
+    got = hip_ctx.convert_rgb_yuv(rgb, 4096, cs)
+    pc.assert_same(got, want, f"K0 exhaustive cs{cs}")
+
+
+# ---------------------------------------------------------------------------------- full sizes ---
+
+
+def test_config1_histogram_720p(hip_ctx, oracle):
+    """BASELINE config 1: 256-bin RGB histogram over one 1280x720 frame (counts + level pass)."""
+    pc.check_histogram_counts(hip_ctx, oracle, 1280, 720, 1, 0x07)
+    pc.check_histogram_full(hip_ctx, oracle, 1280, 720, 1, 0x07, 0, 0, 0)
+    pc.check_histogram_full(hip_ctx, oracle, 1280, 720, 2, 0x07, 1, 0, 0)
+
+
+@pytest.mark.parametrize("dist", [1, 2, 3, 4, 5])
+def test_config2_vectorscope_4k(hip_ctx, oracle, dist):
+    pc.check_vectorscope(hip_ctx, oracle, 3840, 2160, dist)
+
+
+def test_config2_vectorscope_4k_fused_and_padded(hip_ctx, oracle):
+    pc.check_vectorscope(hip_ctx, oracle, 3840, 2160, 1, None, fuse=True, colorspace=2)
+    pc.check_vectorscope(hip_ctx, oracle, 3840, 2160, 2, None, fuse=True, colorspace=1)
+    pc.check_vectorscope(hip_ctx, oracle, 3840, 2160, 1, 3840 * 4 + 256)
+
+
+@pytest.mark.parametrize("comp", [0x20, 0x04, 0x02, 0x01, 0x07, 0x50, 0x70])
+def test_config3_waveform_4k(hip_ctx, oracle, comp):
+    pc.check_waveform(hip_ctx, oracle, 3840, 2160, 1 if comp != 0x07 else 5, comp)
+
+
+def test_config3_waveform_4k_concentrated_and_flat(hip_ctx, oracle):
+    pc.check_waveform(hip_ctx, oracle, 3840, 2160, 2, 0x07)
+    pc.check_waveform(hip_ctx, oracle, 3840, 2160, 3, 0x70)
+
+
+def test_histogram_4k(hip_ctx, oracle):
+    for dist in (1, 2, 3, 5):
+        pc.check_histogram_counts(hip_ctx, oracle, 3840, 2160, dist, 0x07)
+    pc.check_histogram_counts(hip_ctx, oracle, 3840, 2160, 1, 0x70)
+
+
+def test_config4_vectorscope_8k_row_tiles(hip_ctx, oracle):
+    """BASELINE config 4 on one GPU: a 7680x4320 frame as 8 row tiles of 540 rows; the tiles'
+    clamped tables, packed two-per-word, summed (what the RCCL all-reduce does) and clamped once
+    equal the whole-frame table.  Also the whole frame in one call."""
+    import torch
+
+    w, h, tiles = 7680, 4320, 8
+    rgb, yuv = pc.frames(oracle, w, h, 2)
+    want = oracle.vectorscope(yuv, w)
+    got, st = hip_ctx.vectorscope(yuv=yuv, width=w)
+    assert st == 0
+    pc.assert_same(got, want, "8K vectorscope, one call")
+
+    acc = torch.zeros(32768, dtype=torch.int32, device="cuda")
+    for t in range(tiles):
+        tile = yuv[t * h // tiles:(t + 1) * h // tiles]
+        part, st = hip_ctx.vectorscope(yuv=tile, width=w)
+        assert st == 0
+        d = torch.from_numpy(part.reshape(-1)).cuda()
+        packed = torch.empty(32768, dtype=torch.int32, device="cuda")
+        hip_ctx.pack16_dev(d, packed, 32768)
+        hip_ctx.sync()
+        acc += packed
+    out = torch.empty(65536, dtype=torch.uint8, device="cuda")
+    hip_ctx.unpack16_clamp_dev(acc, out, 32768)
+    hip_ctx.sync()
+    pc.assert_same(out.cpu().numpy().reshape(256, 256), want, "8K vectorscope, 8 row tiles + packed sum + clamp")
+
+
+def test_batched_device_4k(hip_ctx, oracle):
+    """Eight distinct 4K frames resident in HBM, one batched launch per scope."""
+    import torch
+
+    w, h, n = 3840, 2160, 8
+    rgbs, yuvs = [], []
+    for i in range(n):
+        r, y = pc.frames(oracle, w, h, 1 + i % 5, seed=31 + i)
+        rgbs.append(r)
+        yuvs.append(y)
+    dy = torch.from_numpy(np.stack(yuvs)).cuda()
+    dr = torch.from_numpy(np.stack(rgbs)).cuda()
+    by = hip_ctx.make_device_batch(dy, 4 * w, w, h, planes_are_rgb=False)
+    br = hip_ctx.make_device_batch(dr, 4 * w, w, h, planes_are_rgb=True)
+
+    out = torch.empty((n, 256, 256), dtype=torch.uint8, device="cuda")
+    hip_ctx.vectorscope_batch_dev(by, out)
+    got = out.cpu().numpy()
+    for i in range(n):
+        pc.assert_same(got[i], oracle.vectorscope(yuvs[i], w), f"batched 4K vectorscope frame {i}")
+
+    out = torch.empty((n, 256, 4), dtype=torch.int32, device="cuda")
+    hip_ctx.histogram_counts_batch_dev(br, 0x07, out)
+    got = out.cpu().numpy().view(np.uint32)
+    for i in range(n):
+        pc.assert_same(got[i], oracle.histogram_counts(rgbs[i], None, w, 0x07), f"batched 4K histogram frame {i}")
+
+    out = torch.empty((n, 256, w, 4), dtype=torch.uint8, device="cuda")
+    hip_ctx.waveform_batch_dev(br, 0x07, out)
+    got = out.cpu().numpy()
+    for i in range(0, n, 3):
+        pc.assert_same(got[i], oracle.waveform(rgbs[i], None, w, 0x07), f"batched 4K waveform frame {i}")
+
+
+# ---------------------------------------------------------------------------------- properties ---
+
+
+def test_properties_full_size(hip_ctx, oracle):
+    """Size-independent checks at 4K that do not need the oracle's tables."""
+    w, h = 3840, 2160
+    rgb, yuv = pc.frames(oracle, w, h, 5)
+    counts, st = hip_ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=0x07)
+    visible = int((rgb[:, : 4 * w].reshape(h, w, 4)[..., 3] != 0).sum())
+    assert st == 0 and [int(counts[:, j].sum()) for j in range(4)] == [visible, visible, visible, 0]
+    # idempotence / determinism: same call twice -> same table
+    a, _ = hip_ctx.vectorscope(yuv=yuv, width=w)
+    b, _ = hip_ctx.vectorscope(yuv=yuv, width=w)
+    assert np.array_equal(a, b)
+    # a vectorscope never exceeds 255 and is monotone under adding pixels: top half <= whole
+    top, _ = hip_ctx.vectorscope(yuv=yuv[: h // 2], width=w)
+    assert (top <= a).all()
+    # waveform columns: luma table of a flat frame has exactly one non-zero row, all 255
+    flat_rgb, flat_yuv = pc.frames(oracle, w, h, 3)
+    wv, _ = hip_ctx.waveform(rgb=flat_rgb, yuv=flat_yuv, width=w, components=0x20)
+    rows = np.nonzero(wv[..., 1].any(axis=1))[0]
+    assert list(rows) == [255 - 204] and (wv[255 - 204, :, 1] == 255).all() and not wv[..., (0, 2, 3)].any()

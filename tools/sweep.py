@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Kernel-variant sweep on one MI355X (tuning aid, not the bench contract).
+
+Every line times the accumulation kernel alone with the C-ABI's HIP-event bracket
+(scope_ctx_profile / scope_ctx_kernel_ms) over distinct HBM-resident 3840x2160 frames and reports
+ms per launch, algorithmic GB/s (SURVEY.md 8(d) bytes) and Gpix/s.  Output: one JSON object per line
+on stdout-file, human table on stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import obs_color_monitor_amd as ocm  # noqa: E402
+
+W, H = 3840, 2160
+
+
+def make_frames(ctx, n, dist, seed=1):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    if dist == "uniform":
+        rgb = torch.randint(0, 256, (n, H, W, 4), dtype=torch.uint8, device="cuda", generator=g)
+    elif dist == "concentrated":
+        rgb = torch.randint(120, 136, (n, H, W, 4), dtype=torch.uint8, device="cuda", generator=g)
+    elif dist == "flat":
+        rgb = torch.empty((n, H, W, 4), dtype=torch.uint8, device="cuda")
+        rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0xD7, 0xCC, 0xC6
+    elif dist == "gradient":  # smooth ramps + 2 LSB of noise: natural-image-like neighbour correlation
+        xs = torch.arange(W, device="cuda").view(1, 1, W)
+        ys = torch.arange(H, device="cuda").view(1, H, 1)
+        noise = torch.randint(0, 4, (n, H, W, 3), dtype=torch.int32, device="cuda", generator=g)
+        rgb = torch.empty((n, H, W, 4), dtype=torch.uint8, device="cuda")
+        rgb[..., 0] = ((xs * 255 // W) + noise[..., 0]).clamp(0, 255).to(torch.uint8)
+        rgb[..., 1] = ((ys * 255 // H) + noise[..., 1]).clamp(0, 255).to(torch.uint8)
+        rgb[..., 2] = (((xs + ys) * 255 // (W + H)) + noise[..., 2]).clamp(0, 255).to(torch.uint8)
+    else:
+        raise ValueError(dist)
+    rgb[..., 3] = 255
+    rgb = rgb.view(n, H, W * 4)
+    yuv = torch.empty_like(rgb)
+    for i in range(n):
+        ctx.convert_rgb_yuv_dev(rgb[i], 4 * W, yuv[i], 4 * W, W, H, 2, sync=False)
+    ctx.sync()
+    return rgb, yuv
+
+
+def timed(ctx, fn, reps=6, warm=2):
+    for _ in range(warm):
+        fn()
+    ctx.sync()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    n, ms = ctx.kernel_ms()
+    ctx.profile(False)
+    return ms / max(n, 1), wall, n // reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/sweep.jsonl")
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    out = open(args.out, "w")
+
+    ctx = ocm.ScopeContext(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    info = ctx.device_info()
+    print(f"# {info}", file=sys.stderr)
+    n = args.frames
+
+    def emit(rec):
+        out.write(json.dumps(rec) + "\n")
+        out.flush()
+        print("  ".join(f"{k}={v}" for k, v in rec.items()), file=sys.stderr, flush=True)
+
+    def report(tag, kern_ms, wall_ms, launches, nframes, table_bytes, **kw):
+        algo = nframes * (4 * W * H + table_bytes) / max(launches, 1) if launches else 0
+        emit(dict(tag=tag, **kw, frames=nframes, launches_per_call=launches, kernel_ms=round(kern_ms, 4),
+                  wall_ms_per_call=round(wall_ms, 4),
+                  gbps=round(algo / (kern_ms * 1e-3) / 1e9, 1) if kern_ms else None,
+                  gpix_wall=round(nframes * W * H / (wall_ms * 1e-3) / 1e9, 1)))
+
+    # ---- reference points: what the chip does on a plain stream of the same bytes ------------------
+    a = torch.empty(n * H * W, dtype=torch.int32, device="cuda")
+    b = torch.empty_like(a)
+    for name, fn, bytes_moved in (("d2d_copy(read+write)", lambda: b.copy_(a), 2 * a.numel() * 4),
+                                  ("torch_sum(read)", lambda: a.sum(), a.numel() * 4)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        emit(dict(tag="ref", what=name, ms=round(ms, 4), gbps=round(bytes_moved / (ms * 1e-3) / 1e9, 1)))
+    del a, b
+
+    dists = ["uniform", "concentrated", "flat", "gradient"] if not args.quick else ["uniform", "flat"]
+    data = {d: make_frames(ctx, n, d) for d in dists}
+    tab = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
+
+    # ---- A: vectorscope, batch launch, merge x unroll x distribution --------------------------------
+    for d in dists:
+        rgb, yuv = data[d]
+        batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
+        for merge in (0, 1, 2):
+            for unroll in (2, 4, 8):
+                ctx.set_option("vss.merge", merge)
+                ctx.set_option("vss.unroll", unroll)
+                k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
+                report("vss_batch", k, wall, l, n, 65536, dist=d, merge=merge, unroll=unroll)
+    ctx.set_option("vss.merge", 1)
+    ctx.set_option("vss.unroll", 4)
+
+    # ---- B: how many workgroups share a frame (units per launch = frames * slices) ------------------
+    rgb, yuv = data["uniform"]
+    batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
+    for slices in (1, 2, 4, 8, 16, 32, 64):
+        ctx.set_option("slices", slices)
+        k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
+        report("vss_slices", k, wall, l, n, 65536, dist="uniform", slices=slices)
+    ctx.set_option("slices", 0)
+
+    # ---- C: one frame per call (the reference's per-callback situation), frames rotate ---------------
+    singles = [ctx.make_device_batch(yuv[i:i + 1], 4 * W, W, H, planes_are_rgb=False) for i in range(n)]
+    for slices in (256, 128, 64, 32):
+        ctx.set_option("slices", slices)
+
+        def run_all():
+            for i in range(n):
+                ctx.vectorscope_batch_dev(singles[i], tab[i], sync=False)
+        k, wall, l = timed(ctx, run_all, reps=3, warm=1)
+        report("vss_single", k, wall, l, n, 65536, dist="uniform", slices=slices)
+    ctx.set_option("slices", 0)
+
+    # ---- D: fused K0 ---------------------------------------------------------------------------------
+    for d in dists[:2]:
+        rgb, yuv = data[d]
+        batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+        k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch_rgb, tab, sync=False))
+        report("vss_fused_k0", k, wall, l, n, 65536, dist=d)
+
+    # ---- E: histogram ----------------------------------------------------------------------------------
+    cnt = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+    for d in dists:
+        rgb, yuv = data[d]
+        batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+        for unroll in (2, 4, 8):
+            ctx.set_option("his.unroll", unroll)
+            for comp in (0x07, 0x02):
+                k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt, sync=False))
+                report("his_batch", k, wall, l, n, 4096, dist=d, unroll=unroll, comp=hex(comp))
+    ctx.set_option("his.unroll", 4)
+
+    # ---- F: waveform ------------------------------------------------------------------------------------
+    nw = min(n, 16)
+    wtab = torch.empty((nw, 256 * W * 4), dtype=torch.uint8, device="cuda")
+    for d in dists:
+        rgb, yuv = data[d]
+        batch_rgb = ctx.make_device_batch(rgb[:nw], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+        batch_yuv = ctx.make_device_batch(yuv[:nw], 4 * W, W, H, planes_are_rgb=False)
+        for unroll in (4, 8, 16):
+            ctx.set_option("wvs.unroll", unroll)
+            for comp, bt in ((0x07, batch_rgb), (0x04, batch_rgb), (0x20, batch_yuv)):
+                k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(bt, comp, wtab, sync=False), reps=4)
+                report("wvs_batch", k, wall, l, nw, 256 * W * 4, dist=d, unroll=unroll, comp=hex(comp))
+    ctx.set_option("wvs.unroll", 8)
+    # single-frame waveform (row bands + saturating reduce)
+    rgb, yuv = data["uniform"]
+    one = ctx.make_device_batch(rgb[:1], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+    k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(one, 0x07, wtab[0], sync=False))
+    report("wvs_single", k, wall, l, 1, 256 * W * 4, dist="uniform")
+
+    out.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
