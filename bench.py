@@ -38,12 +38,14 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-seconds", type=float, default=0.5,
+                    help="untimed run of the same step before the warm-up so the GPU clocks (DVFS) leave idle")
     ap.add_argument("--frames", type=int, default=32, help="distinct HBM-resident frames per step")
     ap.add_argument("--workload", default="vectorscope", choices=["vectorscope", "vectorscope_rgb", "waveform", "histogram"])
     ap.add_argument("--components", type=lambda s: int(s, 0), default=0x07)
-    ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat"])
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "gradient"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
@@ -73,21 +75,9 @@ def main():
 
     # ---- synthetic input, resident in HBM ------------------------------------------------------
     n, w, h = args.frames, W4K, H4K
-    g = torch.Generator(device="cuda")
-    g.manual_seed(0x9E3779B9 + rank)
-    if args.dist == "uniform":
-        rgb = torch.randint(0, 256, (n, h, w, 4), dtype=torch.uint8, device="cuda", generator=g)
-    elif args.dist == "concentrated":
-        rgb = torch.randint(120, 136, (n, h, w, 4), dtype=torch.uint8, device="cuda", generator=g)
-    else:
-        rgb = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
-        rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0xD7, 0xCC, 0xC6
-    rgb[..., 3] = 255
-    rgb = rgb.view(n, h, w * 4)
-    yuv = torch.empty_like(rgb)
-    for i in range(n):
-        ctx.convert_rgb_yuv_dev(rgb[i], 4 * w, yuv[i], 4 * w, w, h, 2, sync=False)
-    ctx.sync()
+    from obs_color_monitor_amd.synth import make_frames
+
+    rgb, yuv = make_frames(torch, ctx, n, w, h, args.dist, 0x9E3779B9 + rank)
 
     wl = args.workload
     if wl == "vectorscope":
@@ -128,7 +118,13 @@ def main():
         if reducer is not None:
             result_tables[0] = reducer.drain()
 
-    # ---- warm-up, then the timed region --------------------------------------------------------
+    # ---- clock settle (setup), warm-up, then the timed region ----------------------------------------
+    t_settle = time.perf_counter() + args.settle_seconds
+    while time.perf_counter() < t_settle:
+        for i in range(8):
+            step(i)
+        drain()
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     drain()

@@ -409,10 +409,13 @@ int scope_ctx_create(int device, scope_ctx **out)
 		scope_ctx_destroy(ctx);
 		return SCOPE_EIO;
 	}
-	ctx->tn.vss_merge = 1;
+	ctx->tn.vss_merge = 2;
 	ctx->tn.vss_unroll = 4;
+	ctx->tn.vss_hash = 1;
+	ctx->tn.vss_groups_log2 = 2;
 	ctx->tn.his_unroll = 4;
 	ctx->tn.wvs_unroll = 8;
+	ctx->tn.nt_loads = 0;
 	ctx->err[0] = 0;
 	*out = ctx;
 	return SCOPE_OK;
@@ -489,6 +492,12 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.vss_merge = value;
 	else if (!strcmp(key, "vss.unroll"))
 		ctx->tn.vss_unroll = value;
+	else if (!strcmp(key, "vss.hash"))
+		ctx->tn.vss_hash = value;
+	else if (!strcmp(key, "vss.groups"))
+		ctx->tn.vss_groups_log2 = value;
+	else if (!strcmp(key, "nt"))
+		ctx->tn.nt_loads = value;
 	else if (!strcmp(key, "his.unroll"))
 		ctx->tn.his_unroll = value;
 	else if (!strcmp(key, "wvs.unroll"))

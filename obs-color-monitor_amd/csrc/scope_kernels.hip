@@ -86,61 +86,36 @@ ScopeK0 scope_k0_matrix(int colorspace)
 }
 
 /* ------------------------------------------------------------------------------------------
- * Pixel streaming: a workgroup walks chunks [c0, c1) of a (rows x ncols) grid of VECW-pixel
- * cells, U loads in flight per lane.  Row pitch is honoured, so padded surfaces cost nothing.
+ * Pixel streaming
+ *
+ * A workgroup walks cells [c0, c1) of a (rows x ncols) grid of VECW-pixel cells.  The 64 lanes of a
+ * wave are split into G = 2^glog2 lane groups and the cell range into G contiguous streams; lane
+ * group g of every wave walks stream g, so one wave instruction touches G image regions that lie
+ * far apart (each still a contiguous 1024/G-byte run, i.e. whole 128-byte lines for G <= 8).
+ * Neighbouring pixels of natural video share their chroma, and LDS atomics on one address
+ * serialise at ~4 clk per lane (profiles/round1/lds_atomic_microbench.txt); spreading a wave over
+ * G regions divides that multiplicity without giving up coalescing.
+ *
+ * Loads are double-buffered: the U loads of batch b+1 are in flight while batch b is binned, and
+ * `before_batch` (uniform; may contain barriers) runs between issue and use, so the vectorscope's
+ * clamp passes do not drain the memory pipeline.  Row pitch is honoured.
  * ---------------------------------------------------------------------------------------- */
+
+typedef u32 scope_v4 __attribute__((vector_size(16)));
 
 template <int VECW> struct ScopeVec;
 template <> struct ScopeVec<4> {
-	typedef uint4 type;
+	typedef scope_v4 type;
 };
 template <> struct ScopeVec<1> {
 	typedef u32 type;
 };
 
-__device__ __forceinline__ uint4 scope_load(const uint4 *p)
+template <bool NT, typename V> __device__ __forceinline__ V scope_load(const V *p)
 {
+	if (NT)
+		return __builtin_nontemporal_load(p);
 	return *p;
-}
-__device__ __forceinline__ u32 scope_load(const u32 *p)
-{
-	return *p;
-}
-
-template <int VECW, int U, typename F>
-__device__ __forceinline__ void scope_for_chunks(const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 c0,
-						 u32 c1, F &&fn)
-{
-	typedef typename ScopeVec<VECW>::type vec_t;
-	const u32 T = blockDim.x;
-	u32 c = c0 + threadIdx.x;
-	u32 row = c / ncols;
-	u32 col = c - row * ncols;
-	const u32 dq = T / ncols;
-	const u32 dr = T - dq * ncols;
-	while (c < c1) {
-		vec_t v[U];
-		bool ok[U];
-#pragma unroll
-		for (int k = 0; k < U; k++) {
-			ok[k] = (c + (u32)k * T) < c1;
-			if (ok[k]) {
-				const uint8_t *p = plane + (size_t)row * linesize + xbyte0 + (size_t)col * (4 * VECW);
-				v[k] = scope_load((const vec_t *)p);
-			}
-			row += dq;
-			col += dr;
-			if (col >= ncols) {
-				col -= ncols;
-				row += 1;
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < U; k++)
-			if (ok[k])
-				fn(v[k]);
-		c += (u32)U * T;
-	}
 }
 
 /* Slice s of S of `total` cells. */
@@ -149,13 +124,87 @@ __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
 	return (u32)(((u64)total * s) / S);
 }
 
+template <int VECW, int U, bool NT, typename Hook, typename F>
+__device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 c0, u32 c1,
+					     u32 glog2, Hook &&before_batch, F &&fn)
+{
+	typedef typename ScopeVec<VECW>::type vec_t;
+	if (c0 >= c1)
+		return;
+	const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const u32 lg = 64u >> glog2;            /* lanes per group */
+	const u32 g = lane >> (6u - glog2);     /* my group = my stream */
+	const u32 tg = blockDim.x >> glog2;     /* lanes of the workgroup on one stream */
+	const u32 len = c1 - c0;
+	const u32 s0 = c0 + (u32)(((u64)len * g) >> glog2);
+	const u32 s1 = c0 + (u32)(((u64)len * (g + 1)) >> glog2);
+	const u32 longest = (len + (1u << glog2) - 1u) >> glog2;
+	const u32 step = (u32)U * tg;
+	const u32 batches = (longest + step - 1u) / step;
+
+	u32 c = s0 + wave * lg + (lane & (lg - 1u));
+	u32 row = c / ncols;
+	u32 col = c - row * ncols;
+	const u32 dq = tg / ncols;
+	const u32 dr = tg - dq * ncols;
+
+	vec_t cur[U], nxt[U];
+	bool cur_ok[U], nxt_ok[U];
+#pragma unroll
+	for (int k = 0; k < U; k++) {
+		cur_ok[k] = (c + (u32)k * tg) < s1;
+		if (cur_ok[k])
+			cur[k] = scope_load<NT>((const vec_t *)(plane + (size_t)row * linesize + xbyte0 + (size_t)col * (4 * VECW)));
+		row += dq;
+		col += dr;
+		if (col >= ncols) {
+			col -= ncols;
+			row += 1;
+		}
+	}
+	for (u32 b = 0; b < batches; b++) {
+		c += step;
+		if (b + 1 < batches) {
+#pragma unroll
+			for (int k = 0; k < U; k++) {
+				nxt_ok[k] = (c + (u32)k * tg) < s1;
+				if (nxt_ok[k])
+					nxt[k] = scope_load<NT>(
+						(const vec_t *)(plane + (size_t)row * linesize + xbyte0 + (size_t)col * (4 * VECW)));
+				row += dq;
+				col += dr;
+				if (col >= ncols) {
+					col -= ncols;
+					row += 1;
+				}
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < U; k++)
+				nxt_ok[k] = false;
+		}
+		before_batch((u32)U * blockDim.x * VECW); /* upper bound of the pixels this batch adds */
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			if (cur_ok[k])
+				fn(cur[k]);
+#pragma unroll
+		for (int k = 0; k < U; k++) {
+			cur[k] = nxt[k];
+			cur_ok[k] = nxt_ok[k];
+		}
+	}
+}
+
 /* ------------------------------------------------------------------------------------------
  * K1 vectorscope
  *
- * LDS table: 32768 words, two u16 counters per word.  Bin idx = u + 256*row (row = 255 - v)
- * lives in word  row*128 + ((u>>1) ^ ((row&3)<<3)),  half u&1.  The XOR rotates each row's
- * eight-word groups so that a clustered chroma blob (a few u values, a few rows) spreads over
- * all 32 LDS banks instead of piling onto the banks of u>>1.
+ * LDS table: 32768 words, two u16 counters per word.  Bin (u, row) with row = 255 - v lives in
+ *   HASH 1: word row*128 + ((u & 127) ^ rev5(row)), half u >> 7
+ *   HASH 0: word row*128 + ((u >> 1) ^ ((row & 3) << 3)), half u & 1        (first version, kept for A/B)
+ * rev5 = the low five bits of the row, bit-reversed.  With HASH 1 neighbouring u share neither a
+ * word nor a bank, and 2^k consecutive rows are offset by multiples of 32/2^k banks, so a chroma
+ * cluster of up to 32 (u, row) cells in any aligned w x h = 32 box lands on 32 different banks.
  *
  * Counters are 16 bit: between two clamp passes a workgroup adds at most 65280 pixels, and
  * every counter is <= 255 after a pass, so no counter can exceed 65535.  The clamp is exact
@@ -171,20 +220,42 @@ __device__ __forceinline__ u32 vss_bin(u32 px)
 	return (px & 0xffu) | ((~px >> 8) & 0xff00u);
 }
 
-__device__ __forceinline__ void vss_add(u32 *tab, u32 idx, u32 n)
+__device__ __forceinline__ u32 vss_rev5(u32 row)
 {
-	const u32 row = idx >> 8;
-	const u32 word = (row << 7) + (((idx & 0xffu) >> 1) ^ ((row & 3u) << 3));
-	atomicAdd(&tab[word], n << ((idx & 1u) << 4));
+	return __brev(row) >> 27;
 }
 
-template <int MERGE> __device__ __forceinline__ void vss_add_run4(u32 *tab, u32 i0, u32 i1, u32 i2, u32 i3)
+template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 idx, u32 n)
+{
+	const u32 row = idx >> 8;
+	if (HASH == 1) {
+		const u32 word = (row << 7) + ((idx & 127u) ^ vss_rev5(row));
+		atomicAdd(&tab[word], n << ((idx >> 3) & 16u));
+	} else {
+		const u32 word = (row << 7) + (((idx & 0xffu) >> 1) ^ ((row & 3u) << 3));
+		atomicAdd(&tab[word], n << ((idx & 1u) << 4));
+	}
+}
+
+/* one clamped bin out of the table */
+template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, u32 row, u32 u, u32 x5)
+{
+	u32 w;
+	if (HASH == 1) {
+		w = tab[(row << 7) + ((u & 127u) ^ x5)] >> ((u >> 3) & 16u);
+	} else {
+		w = tab[(row << 7) + ((u >> 1) ^ ((row & 3u) << 3))] >> ((u & 1u) << 4);
+	}
+	return min(w & 0xffffu, 255u);
+}
+
+template <int MERGE, int HASH> __device__ __forceinline__ void vss_add_run4(u32 *tab, u32 i0, u32 i1, u32 i2, u32 i3)
 {
 	if (MERGE == 0) {
-		vss_add(tab, i0, 1);
-		vss_add(tab, i1, 1);
-		vss_add(tab, i2, 1);
-		vss_add(tab, i3, 1);
+		vss_add<HASH>(tab, i0, 1);
+		vss_add<HASH>(tab, i1, 1);
+		vss_add<HASH>(tab, i2, 1);
+		vss_add<HASH>(tab, i3, 1);
 		return;
 	}
 	/* fold runs of equal neighbours onto their first element */
@@ -209,17 +280,17 @@ template <int MERGE> __device__ __forceinline__ void vss_add_run4(u32 *tab, u32 
 			const u64 active = __ballot(1);
 			const u32 lane = threadIdx.x & 63u;
 			if (lane == (u32)(__ffsll((long long)active) - 1))
-				vss_add(tab, first, 4u * (u32)__popcll(active));
+				vss_add<HASH>(tab, first, 4u * (u32)__popcll(active));
 			return;
 		}
 	}
-	vss_add(tab, i0, n0);
+	vss_add<HASH>(tab, i0, n0);
 	if (n1)
-		vss_add(tab, i1, n1);
+		vss_add<HASH>(tab, i1, n1);
 	if (n2)
-		vss_add(tab, i2, n2);
+		vss_add<HASH>(tab, i2, n2);
 	if (n3)
-		vss_add(tab, i3, n3);
+		vss_add<HASH>(tab, i3, n3);
 }
 
 __device__ __forceinline__ u32 vss_clamp_word(u32 w)
@@ -243,62 +314,52 @@ __device__ __forceinline__ void vss_clamp_pass(u32 *tab)
 	}
 }
 
-__device__ __forceinline__ u32 vss_pack2(u32 wa, u32 wb)
-{
-	/* two words = four consecutive bins -> four clamped bytes */
-	return min(wa & 0xffffu, 255u) | (min(wa >> 16, 255u) << 8) | (min(wb & 0xffffu, 255u) << 16) |
-	       (min(wb >> 16, 255u) << 24);
-}
-
-template <int VECW, int U, int MERGE, bool FUSE>
+template <int VECW, int U, bool NT, int MERGE, bool FUSE, int HASH>
 __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
-					   u32 slice, u32 slices, const ScopeK0 &k0, u32 &since_clamp)
+					   u32 slice, u32 slices, u32 glog2, const ScopeK0 &k0, u32 &since_clamp)
 {
 	if (ncols == 0)
 		return;
 	const u32 total = rows * ncols;
-	u32 c0 = scope_slice_begin(total, slice, slices);
+	const u32 c0 = scope_slice_begin(total, slice, slices);
 	const u32 c1 = scope_slice_begin(total, slice + 1, slices);
-	while (c0 < c1) {
-		const u32 room = (VSS_EPOCH_PIXELS - since_clamp) / VECW;
-		if (room == 0) {
+	auto epoch = [&](u32 px) {
+		/* uniform across the workgroup: everybody takes the same branch */
+		if (since_clamp + px > VSS_EPOCH_PIXELS) {
 			__syncthreads();
 			vss_clamp_pass(tab);
 			__syncthreads();
 			since_clamp = 0;
-			continue;
 		}
-		const u32 e1 = (c1 - c0 > room) ? c0 + room : c1;
-		if (VECW == 4) {
-			scope_for_chunks<4, U>(plane, linesize, xbyte0, ncols, c0, e1, [&](const uint4 &q) {
-				u32 p0 = q.x, p1 = q.y, p2 = q.z, p3 = q.w;
-				if (FUSE) {
-					p0 = scope_k0_texel(p0, k0, true, false);
-					p1 = scope_k0_texel(p1, k0, true, false);
-					p2 = scope_k0_texel(p2, k0, true, false);
-					p3 = scope_k0_texel(p3, k0, true, false);
-				}
-				vss_add_run4<MERGE>(tab, vss_bin(p0), vss_bin(p1), vss_bin(p2), vss_bin(p3));
-			});
-		} else {
-			scope_for_chunks<1, U>(plane, linesize, xbyte0, ncols, c0, e1, [&](const u32 &q) {
-				u32 p0 = q;
-				if (FUSE)
-					p0 = scope_k0_texel(p0, k0, true, false);
-				vss_add(tab, vss_bin(p0), 1);
-			});
-		}
-		since_clamp += (e1 - c0) * VECW;
-		c0 = e1;
+		since_clamp += px;
+	};
+	if (VECW == 4) {
+		scope_stream<4, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, [&](const scope_v4 &q) {
+			u32 p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+			if (FUSE) {
+				p0 = scope_k0_texel(p0, k0, true, false);
+				p1 = scope_k0_texel(p1, k0, true, false);
+				p2 = scope_k0_texel(p2, k0, true, false);
+				p3 = scope_k0_texel(p3, k0, true, false);
+			}
+			vss_add_run4<MERGE, HASH>(tab, vss_bin(p0), vss_bin(p1), vss_bin(p2), vss_bin(p3));
+		});
+	} else {
+		scope_stream<1, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, [&](const u32 &q) {
+			u32 p0 = q;
+			if (FUSE)
+				p0 = scope_k0_texel(p0, k0, true, false);
+			vss_add<HASH>(tab, vss_bin(p0), 1);
+		});
 	}
 }
 
 /* grid = n_frames * slices workgroups; unit = frame * slices + slice.
  * Region A: ncols_a cells of 4 pixels from byte 0 of each row (16-byte aligned rows only);
  * region B: ncols_b single pixels from byte xbyte_b (row tails, or whole rows when unaligned). */
-template <int U, int MERGE, bool FUSE>
+template <int U, bool NT, int MERGE, bool FUSE, int HASH>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
-							       u32 xbyte_b, ScopeK0 k0, uint8_t *dst)
+							       u32 xbyte_b, u32 glog2, ScopeK0 k0, uint8_t *dst)
 {
 	u32 *tab = scope_lds;
 	const u32 unit = blockIdx.x;
@@ -312,19 +373,23 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	__syncthreads();
 
 	u32 since_clamp = 0;
-	vss_region<4, U, MERGE, FUSE>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, k0, since_clamp);
-	vss_region<1, U, MERGE, FUSE>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, k0,
-					  since_clamp);
+	vss_region<4, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, glog2, k0,
+						 since_clamp);
+	vss_region<1, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, glog2,
+						 k0, since_clamp);
 	__syncthreads();
 
-	/* flush: 16 consecutive bins (= 8 words, one swizzled group) per lane per step */
+	/* flush: 16 consecutive bins of one row per lane per step, one coalesced 16-byte store */
 	uint4 *out = (uint4 *)(dst + (size_t)unit * SCOPE_VSS_BINS);
 	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x) {
-		const u32 row = g >> 4;
-		const u32 wbase = (row << 7) + (((g & 15u) << 3) ^ ((row & 3u) << 3));
-		const uint4 a = *(const uint4 *)&tab[wbase];
-		const uint4 b = *(const uint4 *)&tab[wbase + 4];
-		out[g] = make_uint4(vss_pack2(a.x, a.y), vss_pack2(a.z, a.w), vss_pack2(b.x, b.y), vss_pack2(b.z, b.w));
+		const u32 row = g >> 4, u0 = (g & 15u) << 4, x5 = vss_rev5(row);
+		u32 o[4];
+#pragma unroll
+		for (u32 j = 0; j < 4; j++)
+			o[j] = vss_read_bin<HASH>(tab, row, u0 + 4 * j, x5) | (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 1, x5) << 8) |
+			       (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 2, x5) << 16) |
+			       (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 3, x5) << 24);
+		out[g] = make_uint4(o[0], o[1], o[2], o[3]);
 	}
 }
 
@@ -350,7 +415,7 @@ __device__ __forceinline__ void his_add(u32 *tab, u32 px, u32 chmask, u32 rep)
 		atomicAdd(&tab[((2u * 256u + ((px >> 16) & 0xffu)) << 5) + rep], 1u);
 }
 
-template <int VECW, int U, bool FUSE>
+template <int VECW, int U, bool NT, bool FUSE>
 __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
 					   u32 slice, u32 slices, u32 chmask, const ScopeK0 &k0)
 {
@@ -361,9 +426,10 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 	const u32 c1 = scope_slice_begin(total, slice + 1, slices);
 	const u32 rep = threadIdx.x & 31u;
 	const bool need_uv = (chmask & 5u) != 0, need_y = (chmask & 2u) != 0;
+	auto nothing = [](u32) {};
 	if (VECW == 4) {
-		scope_for_chunks<4, U>(plane, linesize, xbyte0, ncols, c0, c1, [&](const uint4 &q) {
-			u32 p0 = q.x, p1 = q.y, p2 = q.z, p3 = q.w;
+		scope_stream<4, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing, [&](const scope_v4 &q) {
+			u32 p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
 			if (FUSE) {
 				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
 				p1 = scope_k0_texel(p1, k0, need_uv, need_y);
@@ -376,7 +442,7 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 			his_add(tab, p3, chmask, rep);
 		});
 	} else {
-		scope_for_chunks<1, U>(plane, linesize, xbyte0, ncols, c0, c1, [&](const u32 &q) {
+		scope_stream<1, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing, [&](const u32 &q) {
 			u32 p0 = q;
 			if (FUSE)
 				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
@@ -385,7 +451,7 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 	}
 }
 
-template <int U, bool FUSE>
+template <int U, bool NT, bool FUSE>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
 							       u32 xbyte_b, u32 chmask, ScopeK0 k0, u32 *dst)
 {
@@ -400,8 +466,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
 		*(uint4 *)&tab[i] = zero;
 	__syncthreads();
 
-	his_region<4, U, FUSE>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, chmask, k0);
-	his_region<1, U, FUSE>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, chmask, k0);
+	his_region<4, U, NT, FUSE>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, chmask, k0);
+	his_region<1, U, NT, FUSE>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, chmask, k0);
 	__syncthreads();
 
 	/* fold the 32 replicas; lane t starts at replica t so a lane group reads 32 banks */
@@ -432,7 +498,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
 
 #define WVS_CH_WORDS 8192u
 
-template <int U, bool FUSE>
+template <int U, bool NT, bool FUSE>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, u32 chmask,
 							       ScopeK0 k0, uint8_t *dst)
 {
@@ -468,22 +534,33 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 	const bool need_uv = (chmask & 5u) != 0, need_y = (chmask & 2u) != 0;
 
 	if (x < W) {
+		/* wave w takes rows r0+w, r0+w+nwaves, ...; U rows in flight while the previous U are binned */
 		const uint8_t *col = plane + (size_t)x * 4;
-		for (u32 r = r0 + wave; r < r1; r += nwaves * U) {
-			u32 v[U];
-			bool ok[U];
+		const u32 stride = nwaves * (u32)U;
+		u32 cur[U], nxt[U];
+		bool cur_ok[U], nxt_ok[U];
+		u32 r = r0 + wave;
+#pragma unroll
+		for (int k = 0; k < U; k++) {
+			const u32 rr = r + (u32)k * nwaves;
+			cur_ok[k] = rr < r1;
+			if (cur_ok[k])
+				cur[k] = scope_load<NT>((const u32 *)(col + (size_t)rr * fs.linesize));
+		}
+		while (r < r1) {
+			r += stride;
 #pragma unroll
 			for (int k = 0; k < U; k++) {
 				const u32 rr = r + (u32)k * nwaves;
-				ok[k] = rr < r1;
-				if (ok[k])
-					v[k] = scope_load((const u32 *)(col + (size_t)rr * fs.linesize));
+				nxt_ok[k] = rr < r1;
+				if (nxt_ok[k])
+					nxt[k] = scope_load<NT>((const u32 *)(col + (size_t)rr * fs.linesize));
 			}
 #pragma unroll
 			for (int k = 0; k < U; k++) {
-				if (!ok[k])
+				if (!cur_ok[k])
 					continue;
-				u32 px = v[k];
+				u32 px = cur[k];
 				if (FUSE)
 					px = scope_k0_texel(px, k0, need_uv, need_y);
 				if ((px >> 24) == 0)
@@ -494,6 +571,11 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 					atomicAdd(&tab[slot1 * WVS_CH_WORDS + (((px >> 8) & 0xffu) << 5) + rep], inc);
 				if (chmask & 4u)
 					atomicAdd(&tab[slot2 * WVS_CH_WORDS + (((px >> 16) & 0xffu) << 5) + rep], inc);
+			}
+#pragma unroll
+			for (int k = 0; k < U; k++) {
+				cur[k] = nxt[k];
+				cur_ok[k] = nxt_ok[k];
 			}
 		}
 	}
@@ -677,61 +759,118 @@ Regions split_regions(const ScopeFrameSet &fs)
 	return r;
 }
 
-template <typename K> hipError_t allow_lds(K kernel, u32 bytes)
-{
-	return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 const u32 VSS_LDS_BYTES = VSS_WORDS * 4u;
 const u32 HIS_LDS_BYTES = HIS_WORDS * 4u;
 const u32 WVS_LDS_BYTES = 3u * WVS_CH_WORDS * 4u;
 
-template <int U, int MERGE, bool FUSE>
-hipError_t vss_go(const ScopeFrameSet &fs, u32 slices, const Regions &rg, const ScopeK0 &k0, uint8_t *dst, hipStream_t st)
+/* Every kernel variant is launched through one of these; `allow` only raises the dynamic-LDS limit
+ * (scope_kernels_init walks all variants once with allow = true). */
+struct VssArgs {
+	const ScopeFrameSet *fs;
+	u32 slices, glog2;
+	Regions rg;
+	ScopeK0 k0;
+	uint8_t *dst;
+	hipStream_t st;
+};
+
+template <int U, bool NT, int MERGE, bool FUSE, int HASH> hipError_t vss_variant(const VssArgs *a)
 {
-	hipLaunchKernelGGL((scope_vss_kernel<U, MERGE, FUSE>), dim3(fs.n_frames * slices), dim3(SCOPE_BLOCK), VSS_LDS_BYTES,
-			   st, fs, slices, rg.ncols_a, rg.ncols_b, rg.xbyte_b, k0, dst);
+	if (!a)
+		return hipFuncSetAttribute((const void *)scope_vss_kernel<U, NT, MERGE, FUSE, HASH>,
+					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)VSS_LDS_BYTES);
+	hipLaunchKernelGGL((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK),
+			   VSS_LDS_BYTES, a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->k0,
+			   a->dst);
 	return hipGetLastError();
 }
 
-template <int U, int MERGE>
-hipError_t vss_go_f(int fuse, const ScopeFrameSet &fs, u32 slices, const Regions &rg, const ScopeK0 &k0, uint8_t *dst,
-		    hipStream_t st)
+template <int U, bool NT, int MERGE, bool FUSE> hipError_t vss_pick_hash(int hash, const VssArgs *a)
 {
-	return fuse ? vss_go<U, MERGE, true>(fs, slices, rg, k0, dst, st)
-		    : vss_go<U, MERGE, false>(fs, slices, rg, k0, dst, st);
+	return hash ? vss_variant<U, NT, MERGE, FUSE, 1>(a) : vss_variant<U, NT, MERGE, FUSE, 0>(a);
+}
+template <int U, bool NT, int MERGE> hipError_t vss_pick_fuse(int fuse, int hash, const VssArgs *a)
+{
+	return fuse ? vss_pick_hash<U, NT, MERGE, true>(hash, a) : vss_pick_hash<U, NT, MERGE, false>(hash, a);
+}
+template <int U, bool NT> hipError_t vss_pick_merge(int merge, int fuse, int hash, const VssArgs *a)
+{
+	if (merge <= 0)
+		return vss_pick_fuse<U, NT, 0>(fuse, hash, a);
+	if (merge == 1)
+		return vss_pick_fuse<U, NT, 1>(fuse, hash, a);
+	return vss_pick_fuse<U, NT, 2>(fuse, hash, a);
+}
+template <int U> hipError_t vss_pick_nt(int nt, int merge, int fuse, int hash, const VssArgs *a)
+{
+	return nt ? vss_pick_merge<U, true>(merge, fuse, hash, a) : vss_pick_merge<U, false>(merge, fuse, hash, a);
+}
+hipError_t vss_pick(int unroll, int nt, int merge, int fuse, int hash, const VssArgs *a)
+{
+	return unroll <= 2 ? vss_pick_nt<2>(nt, merge, fuse, hash, a) : vss_pick_nt<4>(nt, merge, fuse, hash, a);
 }
 
-template <int U>
-hipError_t vss_go_m(int merge, int fuse, const ScopeFrameSet &fs, u32 slices, const Regions &rg, const ScopeK0 &k0,
-		    uint8_t *dst, hipStream_t st)
-{
-	switch (merge) {
-	case 0:
-		return vss_go_f<U, 0>(fuse, fs, slices, rg, k0, dst, st);
-	case 1:
-		return vss_go_f<U, 1>(fuse, fs, slices, rg, k0, dst, st);
-	default:
-		return vss_go_f<U, 2>(fuse, fs, slices, rg, k0, dst, st);
-	}
-}
+struct HisArgs {
+	const ScopeFrameSet *fs;
+	u32 slices, chmask;
+	Regions rg;
+	ScopeK0 k0;
+	u32 *dst;
+	hipStream_t st;
+};
 
-template <int U, bool FUSE>
-hipError_t his_go(const ScopeFrameSet &fs, u32 slices, const Regions &rg, u32 chmask, const ScopeK0 &k0, u32 *dst,
-		  hipStream_t st)
+template <int U, bool NT, bool FUSE> hipError_t his_variant(const HisArgs *a)
 {
-	hipLaunchKernelGGL((scope_his_kernel<U, FUSE>), dim3(fs.n_frames * slices), dim3(SCOPE_BLOCK), HIS_LDS_BYTES, st, fs,
-			   slices, rg.ncols_a, rg.ncols_b, rg.xbyte_b, chmask, k0, dst);
+	if (!a)
+		return hipFuncSetAttribute((const void *)scope_his_kernel<U, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+					   (int)HIS_LDS_BYTES);
+	hipLaunchKernelGGL((scope_his_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), HIS_LDS_BYTES,
+			   a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->chmask, a->k0, a->dst);
 	return hipGetLastError();
 }
-
-template <int U, bool FUSE>
-hipError_t wvs_go(const ScopeFrameSet &fs, u32 strips, u32 bands, u32 chmask, u32 lds, const ScopeK0 &k0, uint8_t *dst,
-		  hipStream_t st)
+template <int U, bool NT> hipError_t his_pick_fuse(int fuse, const HisArgs *a)
 {
-	hipLaunchKernelGGL((scope_wvs_kernel<U, FUSE>), dim3(fs.n_frames * strips * bands), dim3(SCOPE_BLOCK), lds, st, fs,
-			   strips, bands, chmask, k0, dst);
+	return fuse ? his_variant<U, NT, true>(a) : his_variant<U, NT, false>(a);
+}
+template <int U> hipError_t his_pick_nt(int nt, int fuse, const HisArgs *a)
+{
+	return nt ? his_pick_fuse<U, true>(fuse, a) : his_pick_fuse<U, false>(fuse, a);
+}
+hipError_t his_pick(int unroll, int nt, int fuse, const HisArgs *a)
+{
+	return unroll <= 2 ? his_pick_nt<2>(nt, fuse, a) : his_pick_nt<4>(nt, fuse, a);
+}
+
+struct WvsArgs {
+	const ScopeFrameSet *fs;
+	u32 strips, bands, chmask, lds;
+	ScopeK0 k0;
+	uint8_t *dst;
+	hipStream_t st;
+};
+
+template <int U, bool NT, bool FUSE> hipError_t wvs_variant(const WvsArgs *a)
+{
+	if (!a)
+		return hipFuncSetAttribute((const void *)scope_wvs_kernel<U, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+					   (int)WVS_LDS_BYTES);
+	hipLaunchKernelGGL((scope_wvs_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->strips * a->bands), dim3(SCOPE_BLOCK),
+			   a->lds, a->st, *a->fs, a->strips, a->bands, a->chmask, a->k0, a->dst);
 	return hipGetLastError();
+}
+template <int U, bool NT> hipError_t wvs_pick_fuse(int fuse, const WvsArgs *a)
+{
+	return fuse ? wvs_variant<U, NT, true>(a) : wvs_variant<U, NT, false>(a);
+}
+template <int U> hipError_t wvs_pick_nt(int nt, int fuse, const WvsArgs *a)
+{
+	return nt ? wvs_pick_fuse<U, true>(fuse, a) : wvs_pick_fuse<U, false>(fuse, a);
+}
+hipError_t wvs_pick(int unroll, int nt, int fuse, const WvsArgs *a)
+{
+	if (unroll <= 4)
+		return wvs_pick_nt<4>(nt, fuse, a);
+	return wvs_pick_nt<8>(nt, fuse, a);
 }
 
 } // namespace
@@ -739,33 +878,18 @@ hipError_t wvs_go(const ScopeFrameSet &fs, u32 strips, u32 bands, u32 chmask, u3
 hipError_t scope_kernels_init(void)
 {
 	hipError_t e = hipSuccess;
-#define ALLOW(k, b)                          \
-	do {                                 \
-		if (e == hipSuccess)         \
-			e = allow_lds(k, b); \
-	} while (0)
-#define ALLOW_VSS(U)                                           \
-	ALLOW((scope_vss_kernel<U, 0, false>), VSS_LDS_BYTES); \
-	ALLOW((scope_vss_kernel<U, 1, false>), VSS_LDS_BYTES); \
-	ALLOW((scope_vss_kernel<U, 2, false>), VSS_LDS_BYTES); \
-	ALLOW((scope_vss_kernel<U, 0, true>), VSS_LDS_BYTES);  \
-	ALLOW((scope_vss_kernel<U, 1, true>), VSS_LDS_BYTES);  \
-	ALLOW((scope_vss_kernel<U, 2, true>), VSS_LDS_BYTES)
-	ALLOW_VSS(2);
-	ALLOW_VSS(4);
-	ALLOW_VSS(8);
-#define ALLOW_HIS(U)                                        \
-	ALLOW((scope_his_kernel<U, false>), HIS_LDS_BYTES); \
-	ALLOW((scope_his_kernel<U, true>), HIS_LDS_BYTES)
-	ALLOW_HIS(2);
-	ALLOW_HIS(4);
-	ALLOW_HIS(8);
-#define ALLOW_WVS(U)                                        \
-	ALLOW((scope_wvs_kernel<U, false>), WVS_LDS_BYTES); \
-	ALLOW((scope_wvs_kernel<U, true>), WVS_LDS_BYTES)
-	ALLOW_WVS(4);
-	ALLOW_WVS(8);
-	ALLOW_WVS(16);
+	for (int unroll = 2; unroll <= 4; unroll += 2)
+		for (int nt = 0; nt < 2; nt++)
+			for (int fuse = 0; fuse < 2; fuse++) {
+				for (int merge = 0; merge < 3; merge++)
+					for (int hash = 0; hash < 2; hash++)
+						if (e == hipSuccess)
+							e = vss_pick(unroll, nt, merge, fuse, hash, NULL);
+				if (e == hipSuccess)
+					e = his_pick(unroll, nt, fuse, NULL);
+				if (e == hipSuccess)
+					e = wvs_pick(unroll * 2, nt, fuse, NULL);
+			}
 	return e;
 }
 
@@ -791,45 +915,27 @@ hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *d
 hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
 			    const ScopeTuning &tn, hipStream_t st)
 {
-	const Regions rg = split_regions(fs);
-	const ScopeK0 k0 = scope_k0_matrix(colorspace);
-	if (tn.vss_unroll <= 2)
-		return vss_go_m<2>(tn.vss_merge, fuse_k0, fs, slices, rg, k0, dst, st);
-	if (tn.vss_unroll <= 4)
-		return vss_go_m<4>(tn.vss_merge, fuse_k0, fs, slices, rg, k0, dst, st);
-	return vss_go_m<8>(tn.vss_merge, fuse_k0, fs, slices, rg, k0, dst, st);
+	u32 glog2 = tn.vss_groups_log2 < 0 ? 0u : (u32)tn.vss_groups_log2;
+	if (glog2 > 3)
+		glog2 = 3; /* lane groups of >= 8 lanes: every request still covers a whole 128-byte line */
+	const VssArgs a = {&fs, slices, glog2, split_regions(fs), scope_k0_matrix(colorspace), dst, st};
+	return vss_pick(tn.vss_unroll, tn.nt_loads, tn.vss_merge, fuse_k0, tn.vss_hash, &a);
 }
 
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
 			    uint32_t *dst, const ScopeTuning &tn, hipStream_t st)
 {
-	const Regions rg = split_regions(fs);
-	const ScopeK0 k0 = scope_k0_matrix(colorspace);
-#define HIS_CASE(UU)                                                             \
-	(fuse_k0 ? his_go<UU, true>(fs, slices, rg, chmask, k0, dst, st)         \
-		 : his_go<UU, false>(fs, slices, rg, chmask, k0, dst, st))
-	if (tn.his_unroll <= 2)
-		return HIS_CASE(2);
-	if (tn.his_unroll <= 4)
-		return HIS_CASE(4);
-	return HIS_CASE(8);
+	const HisArgs a = {&fs, slices, chmask, split_regions(fs), scope_k0_matrix(colorspace), dst, st};
+	return his_pick(tn.his_unroll, tn.nt_loads, fuse_k0, &a);
 }
 
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
 			    uint8_t *dst, const ScopeTuning &tn, hipStream_t st)
 {
-	const ScopeK0 k0 = scope_k0_matrix(colorspace);
 	const u32 strips = (fs.width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
 	const u32 nch = (chmask & 1u) + ((chmask >> 1) & 1u) + ((chmask >> 2) & 1u);
-	const u32 lds = (nch ? nch : 1u) * WVS_CH_WORDS * 4u;
-#define WVS_CASE(UU)                                                                     \
-	(fuse_k0 ? wvs_go<UU, true>(fs, strips, bands, chmask, lds, k0, dst, st)         \
-		 : wvs_go<UU, false>(fs, strips, bands, chmask, lds, k0, dst, st))
-	if (tn.wvs_unroll <= 4)
-		return WVS_CASE(4);
-	if (tn.wvs_unroll <= 8)
-		return WVS_CASE(8);
-	return WVS_CASE(16);
+	const WvsArgs a = {&fs, strips, bands, chmask, (nch ? nch : 1u) * WVS_CH_WORDS * 4u, scope_k0_matrix(colorspace), dst, st};
+	return wvs_pick(tn.wvs_unroll, tn.nt_loads, fuse_k0, &a);
 }
 
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,

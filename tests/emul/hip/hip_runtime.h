@@ -30,6 +30,14 @@
 #define __shared__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define __builtin_nontemporal_load(p) (*(p))
+static inline uint32_t __brev(uint32_t v)
+{
+	uint32_t r = 0;
+	for (int i = 0; i < 32; i++)
+		r |= ((v >> i) & 1u) << (31 - i);
+	return r;
+}
 
 /* ---- vector / launch types ---------------------------------------------------------------- */
 struct alignas(16) uint4 {

@@ -10,6 +10,26 @@ DISTS = {1: "uniform", 2: "concentrated", 3: "flat", 4: "bars", 5: "alpha_holes"
 COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
 
 
+DEFAULTS = {"vss.merge": 2, "vss.unroll": 4, "vss.hash": 1, "vss.groups": 2, "his.unroll": 4, "wvs.unroll": 8,
+            "nt": 0, "slices": 0}
+
+
+class options:
+    """with options(ctx, **{"vss.merge": 0}): ...  -- tunables restored to the defaults afterwards."""
+
+    def __init__(self, ctx, **kv):
+        self.ctx, self.kv = ctx, kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.ctx.set_option(k, v)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            self.ctx.set_option(k, DEFAULTS[k])
+
+
 def frames(oracle, w, h, dist, linesize=None, seed=0, colorspace=2):
     rgb = oracle.fill_frame(w, h, dist, seed, linesize)
     yuv = oracle.rgb_to_yuv(rgb, w, colorspace)

@@ -19,27 +19,31 @@ def test_vectorscope_geometry(emul_ctx, oracle, w, h, ls):
 
 
 @pytest.mark.parametrize("merge", [0, 1, 2])
-def test_vectorscope_merge_variants(emul_ctx, oracle, merge):
-    emul_ctx.set_option("vss.merge", merge)
-    try:
+@pytest.mark.parametrize("hash_", [0, 1])
+def test_vectorscope_merge_and_hash_variants(emul_ctx, oracle, merge, hash_):
+    with pc.options(emul_ctx, **{"vss.merge": merge, "vss.hash": hash_}):
         pc.check_vectorscope(emul_ctx, oracle, 70, 9, 3)
+        pc.check_vectorscope(emul_ctx, oracle, 70, 9, 1)
+
+
+@pytest.mark.parametrize("groups", [0, 1, 2, 3])
+@pytest.mark.parametrize("unroll", [2, 4])
+def test_vectorscope_lane_groups(emul_ctx, oracle, groups, unroll):
+    """Lane groups walk separate streams of the slice; every split must cover each pixel once."""
+    with pc.options(emul_ctx, **{"vss.groups": groups, "vss.unroll": unroll, "nt": groups & 1}):
         pc.check_vectorscope(emul_ctx, oracle, 70, 9, 2)
-    finally:
-        emul_ctx.set_option("vss.merge", 1)
+        pc.check_vectorscope(emul_ctx, oracle, 33, 5, 1, 140)
+        pc.check_vectorscope(emul_ctx, oracle, 3, 2, 1)
 
 
 def test_vectorscope_saturation_and_epochs(emul_ctx, oracle):
     """One workgroup (slices=1) sees 262144 flat pixels: counters must survive four 65280-pixel
     epochs with clamp passes in between and still report exactly 255."""
-    emul_ctx.set_option("slices", 1)
-    try:
-        for merge in (0, 1):
-            emul_ctx.set_option("vss.merge", merge)
+    for merge, hash_, groups in ((0, 1, 2), (1, 0, 0), (2, 1, 3)):
+        with pc.options(emul_ctx, **{"slices": 1, "vss.merge": merge, "vss.hash": hash_, "vss.groups": groups}):
             pc.check_vectorscope(emul_ctx, oracle, 512, 512, 3)
+    with pc.options(emul_ctx, slices=1):
         pc.check_vectorscope(emul_ctx, oracle, 511, 300, 2, 2048)  # tails + epochs + pitch
-    finally:
-        emul_ctx.set_option("slices", 0)
-        emul_ctx.set_option("vss.merge", 1)
 
 
 @pytest.mark.parametrize("cs", [1, 2])
@@ -60,12 +64,11 @@ def test_waveform_geometry(emul_ctx, oracle, w, h, ls):
 
 def test_waveform_saturation_and_bands(emul_ctx, oracle):
     pc.check_waveform(emul_ctx, oracle, 64, 600, 3, 0x07)  # every column saturates at 255
-    emul_ctx.set_option("slices", 5)  # five row bands -> partial tables + saturating reduce
-    try:
+    with pc.options(emul_ctx, slices=5):  # five row bands -> partial tables + saturating reduce
         pc.check_waveform(emul_ctx, oracle, 64, 600, 2, 0x70)
         pc.check_waveform(emul_ctx, oracle, 66, 40, 1, 0x07)  # width % 4 != 0: single band fallback
-    finally:
-        emul_ctx.set_option("slices", 0)
+    with pc.options(emul_ctx, **{"wvs.unroll": 4, "nt": 1}):
+        pc.check_waveform(emul_ctx, oracle, 70, 100, 5, 0x07)
 
 
 def test_waveform_fused_k0(emul_ctx, oracle):

@@ -45,44 +45,45 @@ def test_geometry_all_scopes(hip_ctx, oracle, w, h, ls):
 
 
 @pytest.mark.parametrize("merge", [0, 1, 2])
-@pytest.mark.parametrize("unroll", [2, 4, 8])
-def test_vectorscope_variants(hip_ctx, oracle, merge, unroll):
-    hip_ctx.set_option("vss.merge", merge)
-    hip_ctx.set_option("vss.unroll", unroll)
-    try:
+@pytest.mark.parametrize("unroll", [2, 4])
+@pytest.mark.parametrize("hash_", [0, 1])
+def test_vectorscope_variants(hip_ctx, oracle, merge, unroll, hash_):
+    with pc.options(hip_ctx, **{"vss.merge": merge, "vss.unroll": unroll, "vss.hash": hash_}):
         for dist in (1, 2, 3, 4):
             pc.check_vectorscope(hip_ctx, oracle, 640, 360, dist)
         pc.check_vectorscope(hip_ctx, oracle, 70, 9, 3)
-    finally:
-        hip_ctx.set_option("vss.merge", 1)
-        hip_ctx.set_option("vss.unroll", 4)
+
+
+@pytest.mark.parametrize("groups", [0, 1, 2, 3])
+@pytest.mark.parametrize("nt", [0, 1])
+def test_vectorscope_lane_groups_and_nt_loads(hip_ctx, oracle, groups, nt):
+    with pc.options(hip_ctx, **{"vss.groups": groups, "nt": nt}):
+        for dist in (1, 3, 4):
+            pc.check_vectorscope(hip_ctx, oracle, 640, 360, dist)
+        pc.check_vectorscope(hip_ctx, oracle, 33, 5, 1, 140)
+        pc.check_vectorscope(hip_ctx, oracle, 1279, 300, 2, 5120)
+        pc.check_histogram_counts(hip_ctx, oracle, 640, 360, 5, 0x07)
+        pc.check_waveform(hip_ctx, oracle, 640, 360, 5, 0x07)
 
 
 @pytest.mark.parametrize("slices", [1, 2, 7, 256])
 def test_partition_independence(hip_ctx, oracle, slices):
     """Any split of a frame over workgroups gives the same tables (saturating/plain sums commute)."""
-    hip_ctx.set_option("slices", slices)
-    try:
+    with pc.options(hip_ctx, slices=slices):
         pc.check_vectorscope(hip_ctx, oracle, 640, 360, 2)
         pc.check_vectorscope(hip_ctx, oracle, 640, 360, 3)
         pc.check_histogram_counts(hip_ctx, oracle, 640, 360, 5, 0x07)
         pc.check_waveform(hip_ctx, oracle, 640, 360, 3, 0x07)
         pc.check_waveform(hip_ctx, oracle, 330, 200, 5, 0x70)
-    finally:
-        hip_ctx.set_option("slices", 0)
 
 
 def test_vectorscope_epochs_single_workgroup(hip_ctx, oracle):
     """One workgroup sees > 65280 pixels of one bin: 16-bit LDS counters + clamp passes stay exact."""
-    hip_ctx.set_option("slices", 1)
-    try:
-        for merge in (0, 1, 2):
-            hip_ctx.set_option("vss.merge", merge)
-            pc.check_vectorscope(hip_ctx, oracle, 1280, 720, 3)
-            pc.check_vectorscope(hip_ctx, oracle, 1279, 300, 2, 5120)
-    finally:
-        hip_ctx.set_option("slices", 0)
-        hip_ctx.set_option("vss.merge", 1)
+    for merge in (0, 1, 2):
+        for hash_ in (0, 1):
+            with pc.options(hip_ctx, **{"slices": 1, "vss.merge": merge, "vss.hash": hash_, "vss.groups": merge}):
+                pc.check_vectorscope(hip_ctx, oracle, 1280, 720, 3)
+                pc.check_vectorscope(hip_ctx, oracle, 1279, 300, 2, 5120)
 
 
 @pytest.mark.parametrize("comp", pc.COMPONENTS)
@@ -91,14 +92,11 @@ def test_component_masks(hip_ctx, oracle, comp):
     pc.check_histogram_counts(hip_ctx, oracle, 330, 77, 5, comp)
 
 
-@pytest.mark.parametrize("unroll", [4, 8, 16])
+@pytest.mark.parametrize("unroll", [4, 8])
 def test_waveform_unroll(hip_ctx, oracle, unroll):
-    hip_ctx.set_option("wvs.unroll", unroll)
-    try:
+    with pc.options(hip_ctx, **{"wvs.unroll": unroll}):
         pc.check_waveform(hip_ctx, oracle, 640, 360, 1, 0x07)
         pc.check_waveform(hip_ctx, oracle, 64, 700, 3, 0x07)
-    finally:
-        hip_ctx.set_option("wvs.unroll", 8)
 
 
 @pytest.mark.parametrize("cs", [1, 2])

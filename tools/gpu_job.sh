@@ -13,10 +13,21 @@ for s in $stages; do
   case $s in
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; rc=$? ;;
     tests) timeout 900 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; rc=$? ;;
-    bench) timeout 600 python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err; rc=$? ;;
+    bench) timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; rc=$? ;;
     sweep) timeout 900 python tools/sweep.py --out $out/sweep.jsonl > $out/sweep.out 2> $out/sweep.log; rc=$? ;;
-    prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof -o vss -- \
-             python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu) > $out/prof.log 2>&1; rc=$? ;;
+    prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof -o vss -- \
+             python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu) > $out/prof.log 2>&1; rc=$? ;;
+    lds)   timeout 300 ./tools/lds_atomic_bench > $out/lds_atomic.txt 2>&1; rc=$? ;;
+    sweepq) timeout 900 python tools/sweep.py --quick --out $out/sweep.jsonl > $out/sweep.out 2> $out/sweep.log; rc=$? ;;
+    pmc)   # PMC passes on their own (no --stats / sys-trace), per the MI355X guide
+           for d in uniform gradient; do
+             (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY \
+                --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq_$d -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --settle-seconds 0.2 --no-cpu --dist $d $BENCH_EXTRA) > $out/pmc_sq_$d.log 2>&1
+             (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE \
+                --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq2_$d -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --settle-seconds 0.2 --no-cpu --dist $d $BENCH_EXTRA) > $out/pmc_sq2_$d.log 2>&1
+           done; rc=$?
+           python tools/pmc_summary.py $out/pmc_sq_uniform $out/pmc_sq_gradient $out/pmc_sq2_uniform $out/pmc_sq2_gradient > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt ;;
+    trace) (python tools/lds_trace_gen.py /tmp/lds_traces.bin 2> $out/lds_trace_model.txt && timeout 300 ./tools/lds_trace_bench /tmp/lds_traces.bin > $out/lds_trace.txt 2>&1); rc=$?; paste -d'|' $out/lds_trace_model.txt $out/lds_trace.txt | cut -c1-200 > $out/lds_trace_both.txt ;;
     *) echo "unknown stage $s"; rc=99 ;;
   esac
   echo "== stage $s rc=$rc $(( $(date +%s) - t0 ))s" | tee -a $out/job.log
@@ -25,4 +36,7 @@ tail -5 $out/smoke.log $out/tests.log 2>/dev/null
 cat $out/bench.json 2>/dev/null
 tail -3 $out/bench.err 2>/dev/null
 grep -E "vss_batch|ref" $out/sweep.log 2>/dev/null | head -50
+cat $out/lds_atomic.txt 2>/dev/null
+cat $out/lds_trace.txt 2>/dev/null
 find $out/prof -name "*stats*" 2>/dev/null | head
+for f in $(find $out/prof -name "*kernel_stats.csv" 2>/dev/null); do head -8 $f; done

@@ -23,35 +23,12 @@ W, H = 3840, 2160
 
 
 def make_frames(ctx, n, dist, seed=1):
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    if dist == "uniform":
-        rgb = torch.randint(0, 256, (n, H, W, 4), dtype=torch.uint8, device="cuda", generator=g)
-    elif dist == "concentrated":
-        rgb = torch.randint(120, 136, (n, H, W, 4), dtype=torch.uint8, device="cuda", generator=g)
-    elif dist == "flat":
-        rgb = torch.empty((n, H, W, 4), dtype=torch.uint8, device="cuda")
-        rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0xD7, 0xCC, 0xC6
-    elif dist == "gradient":  # smooth ramps + 2 LSB of noise: natural-image-like neighbour correlation
-        xs = torch.arange(W, device="cuda").view(1, 1, W)
-        ys = torch.arange(H, device="cuda").view(1, H, 1)
-        noise = torch.randint(0, 4, (n, H, W, 3), dtype=torch.int32, device="cuda", generator=g)
-        rgb = torch.empty((n, H, W, 4), dtype=torch.uint8, device="cuda")
-        rgb[..., 0] = ((xs * 255 // W) + noise[..., 0]).clamp(0, 255).to(torch.uint8)
-        rgb[..., 1] = ((ys * 255 // H) + noise[..., 1]).clamp(0, 255).to(torch.uint8)
-        rgb[..., 2] = (((xs + ys) * 255 // (W + H)) + noise[..., 2]).clamp(0, 255).to(torch.uint8)
-    else:
-        raise ValueError(dist)
-    rgb[..., 3] = 255
-    rgb = rgb.view(n, H, W * 4)
-    yuv = torch.empty_like(rgb)
-    for i in range(n):
-        ctx.convert_rgb_yuv_dev(rgb[i], 4 * W, yuv[i], 4 * W, W, H, 2, sync=False)
-    ctx.sync()
-    return rgb, yuv
+    from obs_color_monitor_amd.synth import make_frames as mk
+
+    return mk(torch, ctx, n, W, H, dist, seed)
 
 
-def timed(ctx, fn, reps=6, warm=2):
+def timed(ctx, fn, reps=20, warm=5):
     for _ in range(warm):
         fn()
     ctx.sync()
@@ -96,6 +73,11 @@ def main():
     # ---- reference points: what the chip does on a plain stream of the same bytes ------------------
     a = torch.empty(n * H * W, dtype=torch.int32, device="cuda")
     b = torch.empty_like(a)
+    t_end = time.perf_counter() + 0.7
+    while time.perf_counter() < t_end:
+        for _ in range(16):
+            b.copy_(a)
+        torch.cuda.synchronize()
     for name, fn, bytes_moved in (("d2d_copy(read+write)", lambda: b.copy_(a), 2 * a.numel() * 4),
                                   ("torch_sum(read)", lambda: a.sum(), a.numel() * 4)):
         for _ in range(2):
@@ -103,30 +85,47 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(20):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        ms = e0.elapsed_time(e1) / 20
         emit(dict(tag="ref", what=name, ms=round(ms, 4), gbps=round(bytes_moved / (ms * 1e-3) / 1e9, 1)))
     del a, b
 
-    dists = ["uniform", "concentrated", "flat", "gradient"] if not args.quick else ["uniform", "flat"]
+    dists = ["uniform", "concentrated", "flat", "gradient"] if not args.quick else ["uniform", "gradient"]
     data = {d: make_frames(ctx, n, d) for d in dists}
     tab = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
+    # let the clocks leave idle before anything is timed
+    warm_batch = ctx.make_device_batch(data[dists[0]][1], 4 * W, W, H, planes_are_rgb=False)
+    t_end = time.perf_counter() + 0.7
+    while time.perf_counter() < t_end:
+        for _ in range(16):
+            ctx.vectorscope_batch_dev(warm_batch, tab, sync=False)
+        ctx.sync()
 
-    # ---- A: vectorscope, batch launch, merge x unroll x distribution --------------------------------
+    # ---- A: vectorscope, batch launch: merge x lane groups x hash x unroll x nt x distribution ---------
+    defaults = {"vss.merge": 2, "vss.unroll": 4, "vss.hash": 1, "vss.groups": 2, "nt": 0}
+
+    def vss_run(batch, d, **opt):
+        for k, v in {**defaults, **opt}.items():
+            ctx.set_option(k, v)
+        k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
+        report("vss_batch", k, wall, l, n, 65536, dist=d, **{kk.replace("vss.", ""): vv for kk, vv in {**defaults, **opt}.items()})
+
     for d in dists:
         rgb, yuv = data[d]
         batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
         for merge in (0, 1, 2):
-            for unroll in (2, 4, 8):
-                ctx.set_option("vss.merge", merge)
-                ctx.set_option("vss.unroll", unroll)
-                k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
-                report("vss_batch", k, wall, l, n, 65536, dist=d, merge=merge, unroll=unroll)
-    ctx.set_option("vss.merge", 1)
-    ctx.set_option("vss.unroll", 4)
+            for groups in (0, 2, 3):
+                for hash_ in (0, 1):
+                    vss_run(batch, d, **{"vss.merge": merge, "vss.groups": groups, "vss.hash": hash_})
+        for unroll in (2, 4):
+            for nt in (0, 1):
+                vss_run(batch, d, **{"vss.unroll": unroll, "nt": nt})
+        vss_run(batch, d, **{"vss.groups": 1})
+    for k, v in defaults.items():
+        ctx.set_option(k, v)
 
     # ---- B: how many workgroups share a frame (units per launch = frames * slices) ------------------
     rgb, yuv = data["uniform"]
@@ -161,12 +160,15 @@ def main():
     for d in dists:
         rgb, yuv = data[d]
         batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-        for unroll in (2, 4, 8):
-            ctx.set_option("his.unroll", unroll)
-            for comp in (0x07, 0x02):
-                k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt, sync=False))
-                report("his_batch", k, wall, l, n, 4096, dist=d, unroll=unroll, comp=hex(comp))
+        for unroll in (2, 4):
+            for nt in (0, 1):
+                ctx.set_option("his.unroll", unroll)
+                ctx.set_option("nt", nt)
+                for comp in (0x07, 0x02):
+                    k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt, sync=False))
+                    report("his_batch", k, wall, l, n, 4096, dist=d, unroll=unroll, nt=nt, comp=hex(comp))
     ctx.set_option("his.unroll", 4)
+    ctx.set_option("nt", 0)
 
     # ---- F: waveform ------------------------------------------------------------------------------------
     nw = min(n, 16)
@@ -175,12 +177,15 @@ def main():
         rgb, yuv = data[d]
         batch_rgb = ctx.make_device_batch(rgb[:nw], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
         batch_yuv = ctx.make_device_batch(yuv[:nw], 4 * W, W, H, planes_are_rgb=False)
-        for unroll in (4, 8, 16):
-            ctx.set_option("wvs.unroll", unroll)
-            for comp, bt in ((0x07, batch_rgb), (0x04, batch_rgb), (0x20, batch_yuv)):
-                k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(bt, comp, wtab, sync=False), reps=4)
-                report("wvs_batch", k, wall, l, nw, 256 * W * 4, dist=d, unroll=unroll, comp=hex(comp))
+        for unroll in (4, 8):
+            for nt in (0, 1):
+                ctx.set_option("wvs.unroll", unroll)
+                ctx.set_option("nt", nt)
+                for comp, bt in ((0x07, batch_rgb), (0x04, batch_rgb), (0x20, batch_yuv)):
+                    k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(bt, comp, wtab, sync=False), reps=10)
+                    report("wvs_batch", k, wall, l, nw, 256 * W * 4, dist=d, unroll=unroll, nt=nt, comp=hex(comp))
     ctx.set_option("wvs.unroll", 8)
+    ctx.set_option("nt", 0)
     # single-frame waveform (row bands + saturating reduce)
     rgb, yuv = data["uniform"]
     one = ctx.make_device_batch(rgb[:1], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
