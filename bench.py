@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32, help="distinct HBM-resident frames per step")
     ap.add_argument("--workload", default="vectorscope", choices=["vectorscope", "vectorscope_rgb", "waveform", "histogram"])
     ap.add_argument("--components", type=lambda s: int(s, 0), default=0x07)
-    ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "gradient"])
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "ramp", "natural"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
@@ -67,7 +67,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = ocm.ScopeContext(local_rank)  # raises without libscope_hip.so / a GPU: no fallback
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one explicit (non-default) stream for torch AND the C-ABI: generation, kernels, RCCL and the HIP
+    # events that time the kernels are all ordered on it (a NULL handle would mean "ctx's own stream")
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
     for kv in args.option:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
@@ -78,6 +82,7 @@ def main():
     from obs_color_monitor_amd.synth import make_frames
 
     rgb, yuv = make_frames(torch, ctx, n, w, h, args.dist, 0x9E3779B9 + rank)
+    torch.cuda.synchronize()
 
     wl = args.workload
     if wl == "vectorscope":

@@ -148,52 +148,49 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	const u32 dq = tg / ncols;
 	const u32 dr = tg - dq * ncols;
 
-	vec_t cur[U], nxt[U];
-	bool cur_ok[U], nxt_ok[U];
-#pragma unroll
-	for (int k = 0; k < U; k++) {
-		cur_ok[k] = (c + (u32)k * tg) < s1;
-		if (cur_ok[k])
-			cur[k] = scope_load<NT>((const vec_t *)(plane + (size_t)row * linesize + xbyte0 + (size_t)col * (4 * VECW)));
-		row += dq;
-		col += dr;
-		if (col >= ncols) {
-			col -= ncols;
-			row += 1;
-		}
-	}
-	for (u32 b = 0; b < batches; b++) {
-		c += step;
+	/* Loads are unconditional (lanes past their stream re-read the slice's first cell) so that the
+	 * compiler can count them, and the two register sets A/B are used ping-pong without copies:
+	 * the wait before binning a batch is vmcnt(U) and the next batch stays in flight. */
+	const u32 row0 = c0 / ncols;
+	const size_t safe_off = (size_t)row0 * linesize + xbyte0 + (size_t)(c0 - row0 * ncols) * (4 * VECW);
+	vec_t va[U], vb[U];
+	bool oka[U], okb[U];
+
+#define SCOPE_ISSUE(v, ok)                                                                             \
+	do {                                                                                           \
+		_Pragma("unroll") for (int k = 0; k < U; k++)                                          \
+		{                                                                                      \
+			ok[k] = (c + (u32)k * tg) < s1;                                                \
+			const size_t off = (size_t)row * linesize + xbyte0 + (size_t)col * (4 * VECW); \
+			v[k] = scope_load<NT>((const vec_t *)(plane + (ok[k] ? off : safe_off)));      \
+			row += dq;                                                                     \
+			col += dr;                                                                     \
+			if (col >= ncols) {                                                            \
+				col -= ncols;                                                          \
+				row += 1;                                                              \
+			}                                                                              \
+		}                                                                                      \
+		c += step;                                                                             \
+	} while (0)
+#define SCOPE_BIN(v, ok)                                                  \
+	do {                                                              \
+		before_batch((u32)U * blockDim.x * VECW);                 \
+		_Pragma("unroll") for (int k = 0; k < U; k++) if (ok[k]) fn(v[k]); \
+	} while (0)
+
+	SCOPE_ISSUE(va, oka);
+	for (u32 b = 0; b < batches; b += 2) {
+		if (b + 1 < batches)
+			SCOPE_ISSUE(vb, okb);
+		SCOPE_BIN(va, oka); /* upper bound of the pixels a batch adds: U * blockDim * VECW */
 		if (b + 1 < batches) {
-#pragma unroll
-			for (int k = 0; k < U; k++) {
-				nxt_ok[k] = (c + (u32)k * tg) < s1;
-				if (nxt_ok[k])
-					nxt[k] = scope_load<NT>(
-						(const vec_t *)(plane + (size_t)row * linesize + xbyte0 + (size_t)col * (4 * VECW)));
-				row += dq;
-				col += dr;
-				if (col >= ncols) {
-					col -= ncols;
-					row += 1;
-				}
-			}
-		} else {
-#pragma unroll
-			for (int k = 0; k < U; k++)
-				nxt_ok[k] = false;
-		}
-		before_batch((u32)U * blockDim.x * VECW); /* upper bound of the pixels this batch adds */
-#pragma unroll
-		for (int k = 0; k < U; k++)
-			if (cur_ok[k])
-				fn(cur[k]);
-#pragma unroll
-		for (int k = 0; k < U; k++) {
-			cur[k] = nxt[k];
-			cur_ok[k] = nxt_ok[k];
+			if (b + 2 < batches)
+				SCOPE_ISSUE(va, oka);
+			SCOPE_BIN(vb, okb);
 		}
 	}
+#undef SCOPE_ISSUE
+#undef SCOPE_BIN
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -533,51 +530,59 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 	const u32 inc = (lane < 32u) ? 1u : 65536u;
 	const bool need_uv = (chmask & 5u) != 0, need_y = (chmask & 2u) != 0;
 
-	if (x < W) {
-		/* wave w takes rows r0+w, r0+w+nwaves, ...; U rows in flight while the previous U are binned */
+	if (x < W && r0 < r1) {
+		/* wave w takes rows r0+w, r0+w+nwaves, ...; two register sets of U rows are used ping-pong,
+		 * loads unconditional (clamped to r0) so the waits are counted: see scope_stream */
 		const uint8_t *col = plane + (size_t)x * 4;
 		const u32 stride = nwaves * (u32)U;
-		u32 cur[U], nxt[U];
-		bool cur_ok[U], nxt_ok[U];
+		u32 va[U], vb[U];
+		bool oka[U], okb[U];
 		u32 r = r0 + wave;
-#pragma unroll
-		for (int k = 0; k < U; k++) {
-			const u32 rr = r + (u32)k * nwaves;
-			cur_ok[k] = rr < r1;
-			if (cur_ok[k])
-				cur[k] = scope_load<NT>((const u32 *)(col + (size_t)rr * fs.linesize));
+
+#define WVS_ISSUE(v, ok)                                                                                     \
+	do {                                                                                                 \
+		_Pragma("unroll") for (int k = 0; k < U; k++)                                                \
+		{                                                                                            \
+			const u32 rr = r + (u32)k * nwaves;                                                  \
+			ok[k] = rr < r1;                                                                     \
+			v[k] = scope_load<NT>((const u32 *)(col + (size_t)(ok[k] ? rr : r0) * fs.linesize)); \
+		}                                                                                            \
+		r += stride;                                                                                 \
+	} while (0)
+#define WVS_BIN(v, ok)                                                                                       \
+	do {                                                                                                 \
+		_Pragma("unroll") for (int k = 0; k < U; k++)                                                \
+		{                                                                                            \
+			u32 px = v[k];                                                                       \
+			if (FUSE)                                                                            \
+				px = scope_k0_texel(px, k0, need_uv, need_y);                                \
+			if (ok[k] && (px >> 24) != 0) { /* src/waveform.c:247-248 */                         \
+				if (chmask & 1u)                                                             \
+					atomicAdd(&tab[slot0 * WVS_CH_WORDS + ((px & 0xffu) << 5) + rep], inc); \
+				if (chmask & 2u)                                                             \
+					atomicAdd(&tab[slot1 * WVS_CH_WORDS + (((px >> 8) & 0xffu) << 5) + rep], inc); \
+				if (chmask & 4u)                                                             \
+					atomicAdd(&tab[slot2 * WVS_CH_WORDS + (((px >> 16) & 0xffu) << 5) + rep], inc); \
+			}                                                                                    \
+		}                                                                                            \
+	} while (0)
+
+		const u32 my_rows = (r1 - r0 > wave) ? (r1 - r0 - wave + nwaves - 1) / nwaves : 0;
+		const u32 batches = (my_rows + (u32)U - 1) / (u32)U;
+		if (batches)
+			WVS_ISSUE(va, oka);
+		for (u32 b = 0; b < batches; b += 2) {
+			if (b + 1 < batches)
+				WVS_ISSUE(vb, okb);
+			WVS_BIN(va, oka);
+			if (b + 1 < batches) {
+				if (b + 2 < batches)
+					WVS_ISSUE(va, oka);
+				WVS_BIN(vb, okb);
+			}
 		}
-		while (r < r1) {
-			r += stride;
-#pragma unroll
-			for (int k = 0; k < U; k++) {
-				const u32 rr = r + (u32)k * nwaves;
-				nxt_ok[k] = rr < r1;
-				if (nxt_ok[k])
-					nxt[k] = scope_load<NT>((const u32 *)(col + (size_t)rr * fs.linesize));
-			}
-#pragma unroll
-			for (int k = 0; k < U; k++) {
-				if (!cur_ok[k])
-					continue;
-				u32 px = cur[k];
-				if (FUSE)
-					px = scope_k0_texel(px, k0, need_uv, need_y);
-				if ((px >> 24) == 0)
-					continue; /* src/waveform.c:247-248 */
-				if (chmask & 1u)
-					atomicAdd(&tab[slot0 * WVS_CH_WORDS + ((px & 0xffu) << 5) + rep], inc);
-				if (chmask & 2u)
-					atomicAdd(&tab[slot1 * WVS_CH_WORDS + (((px >> 8) & 0xffu) << 5) + rep], inc);
-				if (chmask & 4u)
-					atomicAdd(&tab[slot2 * WVS_CH_WORDS + (((px >> 16) & 0xffu) << 5) + rep], inc);
-			}
-#pragma unroll
-			for (int k = 0; k < U; k++) {
-				cur[k] = nxt[k];
-				cur_ok[k] = nxt_ok[k];
-			}
-		}
+#undef WVS_ISSUE
+#undef WVS_BIN
 	}
 	__syncthreads();
 
@@ -807,7 +812,11 @@ template <int U> hipError_t vss_pick_nt(int nt, int merge, int fuse, int hash, c
 }
 hipError_t vss_pick(int unroll, int nt, int merge, int fuse, int hash, const VssArgs *a)
 {
-	return unroll <= 2 ? vss_pick_nt<2>(nt, merge, fuse, hash, a) : vss_pick_nt<4>(nt, merge, fuse, hash, a);
+	if (unroll <= 2)
+		return vss_pick_nt<2>(nt, merge, fuse, hash, a);
+	if (unroll <= 4)
+		return vss_pick_nt<4>(nt, merge, fuse, hash, a);
+	return vss_pick_nt<8>(nt, merge, fuse, hash, a);
 }
 
 struct HisArgs {
@@ -838,7 +847,11 @@ template <int U> hipError_t his_pick_nt(int nt, int fuse, const HisArgs *a)
 }
 hipError_t his_pick(int unroll, int nt, int fuse, const HisArgs *a)
 {
-	return unroll <= 2 ? his_pick_nt<2>(nt, fuse, a) : his_pick_nt<4>(nt, fuse, a);
+	if (unroll <= 2)
+		return his_pick_nt<2>(nt, fuse, a);
+	if (unroll <= 4)
+		return his_pick_nt<4>(nt, fuse, a);
+	return his_pick_nt<8>(nt, fuse, a);
 }
 
 struct WvsArgs {
@@ -870,7 +883,9 @@ hipError_t wvs_pick(int unroll, int nt, int fuse, const WvsArgs *a)
 {
 	if (unroll <= 4)
 		return wvs_pick_nt<4>(nt, fuse, a);
-	return wvs_pick_nt<8>(nt, fuse, a);
+	if (unroll <= 8)
+		return wvs_pick_nt<8>(nt, fuse, a);
+	return wvs_pick_nt<16>(nt, fuse, a);
 }
 
 } // namespace
@@ -878,7 +893,7 @@ hipError_t wvs_pick(int unroll, int nt, int fuse, const WvsArgs *a)
 hipError_t scope_kernels_init(void)
 {
 	hipError_t e = hipSuccess;
-	for (int unroll = 2; unroll <= 4; unroll += 2)
+	for (int unroll = 2; unroll <= 8; unroll *= 2)
 		for (int nt = 0; nt < 2; nt++)
 			for (int fuse = 0; fuse < 2; fuse++) {
 				for (int merge = 0; merge < 3; merge++)

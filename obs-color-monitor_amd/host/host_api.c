@@ -1,0 +1,50 @@
+/*
+ * host_api.c -- what a host (OBS's render thread in the plugin; the tests and bench here) reads back
+ * from the scope sources: the table the worker finished last, i.e. tex_buf[w_tex_buf ^ 1], exactly
+ * what vss_render / wvs_render / his_render upload with gs_texture_set_image
+ * (src/vectorscope.c:410-412, src/waveform.c:399, src/histogram.c:563).
+ */
+#include "scope_sources.h"
+
+struct cm_source *scope_host_cm(void *source)
+{
+	return (struct cm_source *)source; /* every source starts with its struct cm_source */
+}
+
+const uint8_t *scope_host_vss_table(void *data, int *colorspace)
+{
+	struct vss_source *src = data;
+	const int r = src->w_tex_buf ^ 1;
+	if (colorspace)
+		*colorspace = src->tex_cs[r];
+	return src->tex_buf[r];
+}
+
+const uint8_t *scope_host_wvs_table(void *data, uint32_t *width)
+{
+	struct wvs_source *src = data;
+	const int r = src->w_tex_buf ^ 1;
+	if (width)
+		*width = src->tex_buf_width[r];
+	return src->tex_buf[r];
+}
+
+const float *scope_host_his_table(void *data, uint32_t *hi_max)
+{
+	struct his_source *src = data;
+	const int r = src->w_tex_buf ^ 1;
+	if (hi_max)
+		for (int i = 0; i < 3; i++)
+			hi_max[i] = src->hi_max[r][i];
+	return (const float *)src->tex_buf[r];
+}
+
+uint64_t scope_host_frames_processed(void *source)
+{
+	return scope_host_cm(source)->frames_processed;
+}
+
+uint64_t scope_host_frames_dropped(void *source)
+{
+	return scope_host_cm(source)->frames_dropped;
+}

@@ -1,0 +1,224 @@
+/*
+ * scope_common.c -- ring + "color-monitor" consumer thread of the reference
+ * (src/common.c:335-403) for the stand-alone host, and the module's shared GPU context.
+ */
+#include "scope_common.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static scope_ctx *g_gpu;
+static pthread_mutex_t g_gpu_mutex = PTHREAD_MUTEX_INITIALIZER;
+
+int cm_gpu_open(int device)
+{
+	pthread_mutex_lock(&g_gpu_mutex);
+	int st = SCOPE_OK;
+	if (!g_gpu) {
+		st = scope_ctx_create(device, &g_gpu);
+		if (st != SCOPE_OK)
+			blog(LOG_ERROR, "[obs-color-monitor] scope_ctx_create(%d) failed: %s", device, scope_strerror(st));
+	}
+	pthread_mutex_unlock(&g_gpu_mutex);
+	return st;
+}
+
+void cm_gpu_close(void)
+{
+	pthread_mutex_lock(&g_gpu_mutex);
+	scope_ctx_destroy(g_gpu);
+	g_gpu = NULL;
+	pthread_mutex_unlock(&g_gpu_mutex);
+}
+
+scope_ctx *cm_gpu(void)
+{
+	return g_gpu;
+}
+
+/* src/common.c:335-373: build the surface descriptor from the slot's flags and call the scope */
+static void cm_pipeline_thread_loop(struct cm_source *src, struct cm_surface_queue_item *item)
+{
+	if (!(item->flags & (CM_FLAG_CONVERT_RGB | CM_FLAG_CONVERT_YUV)))
+		return;
+	uint8_t *video_data = item->video_data;
+	if (!video_data)
+		return; /* the reference returns when gs_stagesurface_map fails, :349-350 */
+
+	struct cm_surface_data surface_data = {
+		.linesize = item->linesize,
+		.width = item->width,
+		.height = item->height,
+		.colorspace = item->colorspace,
+	};
+	if (item->flags & CM_FLAG_CONVERT_RGB) {
+		surface_data.rgb_data = video_data;
+		video_data += (size_t)item->linesize * item->height; /* :358-359 */
+	}
+	if (item->flags & CM_FLAG_CONVERT_YUV)
+		surface_data.yuv_data = video_data;
+
+	if (item->cb)
+		item->cb(item->cb_data, &surface_data);
+	src->frames_processed++;
+}
+
+/* src/common.c:375-403 */
+static void *cm_pipeline_thread(void *data)
+{
+	struct cm_source *src = data;
+	pthread_mutex_lock(&src->pipeline_mutex);
+	while (!src->request_exit) {
+		const int next = (src->i_read_queue + 1) % CM_SURFACE_QUEUE_SIZE;
+		if (src->i_write_queue == next || src->i_staging_queue == next) {
+			pthread_cond_wait(&src->pipeline_cond, &src->pipeline_mutex);
+			continue;
+		}
+		src->i_read_queue = next;
+		src->busy = true;
+		pthread_mutex_unlock(&src->pipeline_mutex);
+		cm_pipeline_thread_loop(src, &src->queue[next]);
+		pthread_mutex_lock(&src->pipeline_mutex);
+		src->busy = false;
+		pthread_cond_broadcast(&src->pipeline_cond); /* lets cm_drain() observe progress */
+	}
+	pthread_mutex_unlock(&src->pipeline_mutex);
+	return NULL;
+}
+
+static void cm_start_thread(struct cm_source *src)
+{
+	if (src->pipeline_thread_running)
+		return;
+	src->request_exit = false;
+	src->pipeline_thread_running = pthread_create(&src->pipeline_thread, NULL, cm_pipeline_thread, src) == 0;
+}
+
+static void cm_stop_thread(struct cm_source *src)
+{
+	if (!src->pipeline_thread_running)
+		return;
+	pthread_mutex_lock(&src->pipeline_mutex);
+	src->request_exit = true;
+	pthread_cond_broadcast(&src->pipeline_cond);
+	pthread_mutex_unlock(&src->pipeline_mutex);
+	pthread_join(src->pipeline_thread, NULL);
+	src->pipeline_thread_running = false;
+}
+
+void cm_get_defaults(obs_data_t *settings)
+{
+	obs_data_set_default_int(settings, "target_scale", 2); /* src/common.c:124, src/vectorscope.c:157 */
+	obs_data_set_default_int(settings, "colorspace", 0);
+	obs_data_set_default_bool(settings, "bypass", false);
+}
+
+void cm_update(struct cm_source *src, obs_data_t *settings)
+{
+	src->target_scale = (int)obs_data_get_int(settings, "target_scale"); /* src/common.c:88-90 */
+	if (src->target_scale < 1)
+		src->target_scale = 1;
+	/* util.c:25-41: 1 -> 601, 2 -> 709, auto -> the video info's, which defaults to 709 */
+	const int cs = (int)obs_data_get_int(settings, "colorspace");
+	src->colorspace = cs == 1 ? 1 : 2;
+	src->bypass = obs_data_get_bool(settings, "bypass");
+}
+
+void cm_create(struct cm_source *src, obs_data_t *settings, obs_source_t *source)
+{
+	UNUSED_PARAMETER(source);
+	uint32_t flags = src->flags; /* the scope sets flags before or after, as in the reference */
+	memset(src, 0, sizeof *src);
+	src->flags = flags;
+	src->i_write_queue = 0; /* src/common.c:33-35 */
+	src->i_staging_queue = 0;
+	src->i_read_queue = CM_SURFACE_QUEUE_SIZE - 1;
+	pthread_mutex_init(&src->pipeline_mutex, NULL);
+	pthread_cond_init(&src->pipeline_cond, NULL);
+	cm_update(src, settings);
+}
+
+void cm_destroy(struct cm_source *src)
+{
+	cm_stop_thread(src);
+	for (int i = 0; i < CM_SURFACE_QUEUE_SIZE; i++)
+		bfree(src->queue[i].video_data);
+	pthread_mutex_destroy(&src->pipeline_mutex);
+	pthread_cond_destroy(&src->pipeline_cond);
+}
+
+void cm_request(struct cm_source *src, cm_surface_cb_t callback, void *data)
+{
+	src->callback = callback;
+	src->callback_data = data;
+}
+
+void cm_tick(void *data, float unused)
+{
+	UNUSED_PARAMETER(unused);
+	struct cm_source *src = data;
+	/* src/common.c:587-590: a scope attached to an ROI has no thread of its own */
+	if (src->roi || src->bypass)
+		cm_stop_thread(src);
+	else
+		cm_start_thread(src);
+}
+
+bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
+		      uint32_t height)
+{
+	const bool has_rgb = !src->bypass && (src->flags & CM_FLAG_CONVERT_RGB);
+	const bool has_yuv = !src->bypass && (src->flags & CM_FLAG_CONVERT_YUV);
+	if (!has_rgb && !has_yuv)
+		return false;
+
+	pthread_mutex_lock(&src->pipeline_mutex);
+	if (src->i_write_queue == src->i_read_queue) { /* consumer a full ring behind: drop, :260-268 */
+		src->i_staging_queue = -1;
+		src->frames_dropped++;
+		pthread_cond_broadcast(&src->pipeline_cond);
+		pthread_mutex_unlock(&src->pipeline_mutex);
+		return false;
+	}
+	const int w = src->i_write_queue; /* the consumer never takes slot i_write_queue */
+	pthread_mutex_unlock(&src->pipeline_mutex);
+
+	struct cm_surface_queue_item *item = &src->queue[w];
+	const uint32_t sheight = height * ((has_rgb ? 1u : 0u) + (has_yuv ? 1u : 0u)); /* :284-291 */
+	const size_t bytes = (size_t)linesize * sheight;
+	if (item->capacity < bytes) {
+		bfree(item->video_data);
+		item->video_data = bzalloc(bytes);
+		item->capacity = item->video_data ? bytes : 0;
+	}
+	if (item->video_data)
+		memcpy(item->video_data, video_data, bytes); /* gs_stage_texture stand-in */
+	item->linesize = linesize;
+	item->width = width;
+	item->height = height;
+	item->sheight = sheight;
+	item->flags = src->flags & (CM_FLAG_CONVERT_RGB | CM_FLAG_CONVERT_YUV | CM_FLAG_RAW_TEXTURE);
+	item->colorspace = src->colorspace;
+	item->cb = src->callback;
+	item->cb_data = src->callback_data;
+
+	/* :322-329 -- the slot just staged stays off limits until the NEXT frame is staged (in the
+	 * reference its GPU->CPU copy is still in flight); cm_drain() releases it explicitly */
+	pthread_mutex_lock(&src->pipeline_mutex);
+	src->i_staging_queue = w;
+	src->i_write_queue = (w + 1) % CM_SURFACE_QUEUE_SIZE;
+	pthread_cond_broadcast(&src->pipeline_cond);
+	pthread_mutex_unlock(&src->pipeline_mutex);
+	return true;
+}
+
+void cm_drain(struct cm_source *src)
+{
+	pthread_mutex_lock(&src->pipeline_mutex);
+	src->i_staging_queue = -1; /* as the reference does when it drops a frame, :262-264 */
+	pthread_cond_broadcast(&src->pipeline_cond);
+	while (src->pipeline_thread_running &&
+	       (src->busy || (src->i_read_queue + 1) % CM_SURFACE_QUEUE_SIZE != src->i_write_queue))
+		pthread_cond_wait(&src->pipeline_cond, &src->pipeline_mutex);
+	pthread_mutex_unlock(&src->pipeline_mutex);
+}

@@ -1,0 +1,104 @@
+/*
+ * scope_common.h -- host-side mirror of the reference's capture pipeline boundary
+ * (src/common.h, src/common.c), reduced to what the scope accumulation path uses.
+ *
+ * Same names, same argument meaning, same error behaviour as the reference, so that the scope
+ * sources in this directory read like the reference's and a maintainer can move the GPU calls into
+ * the real tree one function at a time.
+ */
+#ifndef SCOPE_COMMON_H
+#define SCOPE_COMMON_H
+
+#include <pthread.h>
+
+#include "../../include/scope_hip.h"
+#include "obs_shim.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/common.h:24-30 -- layout-identical to struct scope_surface_data of the C-ABI */
+struct cm_surface_data {
+	uint8_t *rgb_data, *yuv_data;
+	uint32_t linesize, width, height;
+	int colorspace;
+	void *tex; /* gs_texture_t * in the reference; unused on this path */
+};
+
+/* src/common.h:32 */
+typedef void (*cm_surface_cb_t)(void *data, struct cm_surface_data *surface_data);
+
+/* src/common.h:89-92 */
+#define CM_FLAG_CONVERT_RGB 1
+#define CM_FLAG_CONVERT_YUV 2
+#define CM_FLAG_RAW_TEXTURE 4
+#define CM_FLAG_ROI 8
+
+#define CM_SURFACE_QUEUE_SIZE 3 /* src/common.h:46 */
+
+/* One staged surface of the ring: what gs_stage_texture + gs_stagesurface_map hand to the
+ * pipeline thread in the reference (src/common.h:34-44, src/common.c:343-364). */
+struct cm_surface_queue_item {
+	uint8_t *video_data; /* stacked BGRA8 planes: RGB rows first (if any), then YUV rows */
+	size_t capacity;
+	uint32_t linesize;
+	uint32_t width, height, sheight;
+	uint32_t flags;
+	int colorspace;
+	cm_surface_cb_t cb;
+	void *cb_data;
+};
+
+struct roi_source;
+
+/* src/common.h:48-87, minus everything that only exists to talk to libobs graphics */
+struct cm_source {
+	struct cm_surface_queue_item queue[CM_SURFACE_QUEUE_SIZE];
+	volatile int i_write_queue, i_staging_queue;
+	volatile int i_read_queue;
+
+	pthread_t pipeline_thread;
+	pthread_mutex_t pipeline_mutex;
+	pthread_cond_t pipeline_cond;
+	volatile bool pipeline_thread_running;
+	volatile bool request_exit;
+	volatile bool busy; /* the consumer is inside a callback (cm_drain waits for it) */
+
+	cm_surface_cb_t callback;
+	void *callback_data;
+
+	struct roi_source *roi;
+
+	int target_scale;
+	int colorspace;
+	uint32_t flags;
+	bool bypass;
+
+	uint64_t frames_dropped, frames_processed;
+};
+
+void cm_create(struct cm_source *src, obs_data_t *settings, obs_source_t *source); /* src/common.c:33-52 */
+void cm_destroy(struct cm_source *src);                                            /* src/common.c:54-79 */
+void cm_update(struct cm_source *src, obs_data_t *settings);                       /* src/common.c:81-98 */
+void cm_get_defaults(obs_data_t *settings);
+void cm_request(struct cm_source *src, cm_surface_cb_t callback, void *data);      /* src/common.c:615-620 */
+void cm_tick(void *data, float unused);                                            /* src/common.c:575-595 */
+
+/* Producer half of cm_render_target (src/common.c:223-333) for a host that already holds the
+ * stacked surface: copies it into the next ring slot and wakes the pipeline thread.  Returns false
+ * when the consumer is a full ring behind and the frame was dropped (src/common.c:260-268). */
+bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
+		      uint32_t height);
+/* Blocks until every staged surface has been through the callback (test/bench helper). */
+void cm_drain(struct cm_source *src);
+
+/* The shared GPU context of this module (one scope_ctx per process, like one OBS graphics context). */
+scope_ctx *cm_gpu(void);
+int cm_gpu_open(int device);
+void cm_gpu_close(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

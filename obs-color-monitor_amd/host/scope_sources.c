@@ -1,0 +1,438 @@
+/*
+ * scope_sources.c -- vectorscope / waveform / histogram sources and the ROI fan-out with the
+ * per-pixel loops replaced by calls into libscope_hip.so.
+ *
+ * Everything around the three scope_* calls follows the reference: the NULL-plane guards, the lazy
+ * double buffer, the flip of w_tex_buf by the worker thread, the silent skip on failure (the
+ * callbacks are void; a failed frame leaves the previous table on screen).
+ */
+#include "scope_sources.h"
+
+#include <string.h>
+
+/* -- shared -------------------------------------------------------------------------------------- */
+
+static const struct scope_surface_data *as_scope(const struct cm_surface_data *sd)
+{
+	/* field-for-field the same struct (include/scope_hip.h) */
+	return (const struct scope_surface_data *)sd;
+}
+
+static void log_failure(const char *what, int st)
+{
+	if (st != SCOPE_OK)
+		blog(LOG_ERROR, "[obs-color-monitor] %s failed: %s (%s)", what, scope_strerror(st), scope_last_error(cm_gpu()));
+}
+
+/* -- vectorscope ------------------------------------------------------------------------------------ */
+
+static const char *vss_get_name(void *unused)
+{
+	UNUSED_PARAMETER(unused);
+	return "Vectorscope";
+}
+
+static void vss_update(void *data, obs_data_t *settings)
+{
+	struct vss_source *src = data;
+	cm_update(&src->cm, settings);
+}
+
+static void *vss_create(obs_data_t *settings, obs_source_t *source)
+{
+	struct vss_source *src = bzalloc(sizeof(struct vss_source));
+	src->cm.flags = CM_FLAG_CONVERT_YUV; /* src/vectorscope.c:79 */
+	cm_create(&src->cm, settings, source);
+	cm_request(&src->cm, vss_surface_cb, src);
+	vss_update(src, settings);
+	return src;
+}
+
+static void vss_destroy(void *data)
+{
+	struct vss_source *src = data;
+	cm_destroy(&src->cm);
+	bfree(src->tex_buf[0]); /* src/vectorscope.c:119-120 */
+	bfree(src->tex_buf[1]);
+	bfree(src);
+}
+
+static void vss_get_defaults(obs_data_t *settings)
+{
+	cm_get_defaults(settings);
+}
+
+static uint32_t vss_get_width(void *data)
+{
+	UNUSED_PARAMETER(data);
+	return VS_SIZE; /* src/vectorscope.c:205-215 */
+}
+
+void vss_surface_cb(void *data, struct cm_surface_data *surface_data)
+{
+	struct vss_source *src = data;
+
+	if (!surface_data->yuv_data)
+		return;
+
+	if (!src->tex_buf[src->w_tex_buf])
+		src->tex_buf[src->w_tex_buf] = bzalloc(VS_SIZE * VS_SIZE);
+
+	/* was: vss_draw_vectorscope(src->tex_buf[src->w_tex_buf], surface_data) */
+	const int st = scope_vectorscope(cm_gpu(), as_scope(surface_data), 0, src->tex_buf[src->w_tex_buf]);
+	if (st != SCOPE_OK) {
+		log_failure("scope_vectorscope", st);
+		return; /* keep showing the previous table */
+	}
+
+	src->tex_cs[src->w_tex_buf] = surface_data->colorspace;
+	src->w_tex_buf ^= 1;
+}
+
+static void scope_render_nothing(void *data, gs_effect_t *effect)
+{
+	/* the display shaders (data/vectorscope|waveform|histogram.effect) stay in the plugin;
+	 * the stand-alone host has no graphics context to draw with */
+	UNUSED_PARAMETER(data);
+	UNUSED_PARAMETER(effect);
+}
+
+const struct obs_source_info colormonitor_vectorscope_v2 = {
+	.id = "vectorscope_source",
+	.version = 2,
+	.type = OBS_SOURCE_TYPE_INPUT,
+	.output_flags = OBS_SOURCE_VIDEO | OBS_SOURCE_CUSTOM_DRAW | OBS_SOURCE_INTERACTION,
+	.get_name = vss_get_name,
+	.create = vss_create,
+	.destroy = vss_destroy,
+	.update = vss_update,
+	.get_defaults = vss_get_defaults,
+	.get_width = vss_get_width,
+	.get_height = vss_get_width,
+	.video_render = scope_render_nothing,
+	.video_tick = cm_tick,
+};
+
+/* -- waveform ----------------------------------------------------------------------------------------- */
+
+static const char *wvs_get_name(void *unused)
+{
+	UNUSED_PARAMETER(unused);
+	return "Waveform";
+}
+
+static void wvs_update(void *data, obs_data_t *settings)
+{
+	struct wvs_source *src = data;
+	cm_update(&src->cm, settings);
+	src->components = (uint32_t)obs_data_get_int(settings, "components");
+	/* src/waveform.c:100-102 */
+	src->cm.flags = ((src->components & COMP_RGB) ? CM_FLAG_CONVERT_RGB : 0) |
+			((src->components & COMP_YUV) ? CM_FLAG_CONVERT_YUV : 0);
+}
+
+static void *wvs_create(obs_data_t *settings, obs_source_t *source)
+{
+	struct wvs_source *src = bzalloc(sizeof(struct wvs_source));
+	cm_create(&src->cm, settings, source);
+	cm_request(&src->cm, wvs_surface_cb, src);
+	wvs_update(src, settings);
+	return src;
+}
+
+static void wvs_destroy(void *data)
+{
+	struct wvs_source *src = data;
+	cm_destroy(&src->cm);
+	bfree(src->tex_buf[0]); /* src/waveform.c:87-88 */
+	bfree(src->tex_buf[1]);
+	bfree(src);
+}
+
+static void wvs_get_defaults(obs_data_t *settings)
+{
+	cm_get_defaults(settings);
+	obs_data_set_default_int(settings, "components", COMP_RGB); /* src/waveform.c:115 */
+}
+
+static uint32_t wvs_get_width(void *data)
+{
+	struct wvs_source *src = data;
+	return src->tex_buf_width[src->w_tex_buf ^ 1]; /* overlay display, src/waveform.c:181-189 */
+}
+
+static uint32_t wvs_get_height(void *data)
+{
+	UNUSED_PARAMETER(data);
+	return WV_SIZE;
+}
+
+/* src/waveform.c:207-218 */
+static void ensure_tex_buf_size(struct wvs_source *src, const uint32_t width, int ix)
+{
+	if (src->tex_buf[ix] && src->tex_buf_width[ix] == width)
+		return;
+	if (!width)
+		return;
+	bfree(src->tex_buf[ix]);
+	src->tex_buf[ix] = bzalloc((size_t)width * WV_SIZE * 4);
+	src->tex_buf_width[ix] = width;
+}
+
+void wvs_surface_cb(void *data, struct cm_surface_data *surface_data)
+{
+	struct wvs_source *src = data;
+
+	if ((src->components & COMP_RGB) && !surface_data->rgb_data)
+		return;
+	if ((src->components & COMP_YUV) && !surface_data->yuv_data)
+		return;
+	if (!surface_data->width)
+		return;
+
+	ensure_tex_buf_size(src, surface_data->width, src->w_tex_buf);
+
+	/* was: wvs_draw_waveform(src, src->tex_buf[src->w_tex_buf], surface_data) */
+	const int st = scope_waveform(cm_gpu(), as_scope(surface_data), src->components, 0, src->tex_buf[src->w_tex_buf]);
+	if (st != SCOPE_OK) {
+		log_failure("scope_waveform", st);
+		return;
+	}
+	src->w_tex_buf ^= 1;
+}
+
+const struct obs_source_info colormonitor_waveform = {
+	.id = "waveform_source",
+	.type = OBS_SOURCE_TYPE_INPUT,
+	.output_flags = OBS_SOURCE_VIDEO | OBS_SOURCE_CUSTOM_DRAW,
+	.get_name = wvs_get_name,
+	.create = wvs_create,
+	.destroy = wvs_destroy,
+	.update = wvs_update,
+	.get_defaults = wvs_get_defaults,
+	.get_width = wvs_get_width,
+	.get_height = wvs_get_height,
+	.video_render = scope_render_nothing,
+	.video_tick = cm_tick,
+};
+
+/* -- histogram ---------------------------------------------------------------------------------------- */
+
+static const char *his_get_name(void *unused)
+{
+	UNUSED_PARAMETER(unused);
+	return "Histogram";
+}
+
+static void his_update(void *data, obs_data_t *settings)
+{
+	struct his_source *src = data;
+	cm_update(&src->cm, settings);
+	src->components = (uint32_t)obs_data_get_int(settings, "components");
+	src->cm.flags = ((src->components & COMP_RGB) ? CM_FLAG_CONVERT_RGB : 0) |
+			((src->components & COMP_YUV) ? CM_FLAG_CONVERT_YUV : 0); /* src/histogram.c:119-121 */
+	src->logscale = obs_data_get_bool(settings, "logscale");
+	/* src/histogram.c:125-156: level_mode 0 none, 1 pixel count, 2 per-mille of the frame */
+	const int level_mode = (int)obs_data_get_int(settings, "level_mode");
+	src->level_fixed_value = level_mode == 1 ? (int)obs_data_get_int(settings, "level_fixed_value") : 0;
+	src->level_ratio_value = level_mode == 2 ? (int)obs_data_get_int(settings, "level_ratio_value") : 0;
+}
+
+static void *his_create(obs_data_t *settings, obs_source_t *source)
+{
+	struct his_source *src = bzalloc(sizeof(struct his_source));
+	cm_create(&src->cm, settings, source);
+	cm_request(&src->cm, his_surface_cb, src);
+	his_update(src, settings);
+	return src;
+}
+
+static void his_destroy(void *data)
+{
+	struct his_source *src = data;
+	cm_destroy(&src->cm);
+	bfree(src->tex_buf[0]); /* src/histogram.c:97-98 */
+	bfree(src->tex_buf[1]);
+	bfree(src);
+}
+
+static void his_get_defaults(obs_data_t *settings)
+{
+	cm_get_defaults(settings);
+	obs_data_set_default_int(settings, "components", COMP_RGB); /* src/histogram.c:167 */
+	obs_data_set_default_bool(settings, "logscale", false);
+	obs_data_set_default_int(settings, "level_mode", 0);
+}
+
+static uint32_t his_get_width(void *data)
+{
+	UNUSED_PARAMETER(data);
+	return HI_SIZE;
+}
+
+void his_surface_cb(void *data, struct cm_surface_data *surface_data)
+{
+	struct his_source *src = data;
+
+	if ((src->components & COMP_RGB) && !surface_data->rgb_data)
+		return;
+	if ((src->components & COMP_YUV) && !surface_data->yuv_data)
+		return;
+	if (!surface_data->width)
+		return;
+
+	if (!src->tex_buf[src->w_tex_buf])
+		src->tex_buf[src->w_tex_buf] = bzalloc(sizeof(float) * HI_SIZE * 4);
+
+	/* was: his_draw_histogram(src, tex_buf, hi_max, surface_data) */
+	const int st = scope_histogram(cm_gpu(), as_scope(surface_data), src->components, src->logscale,
+				       src->level_fixed_value, src->level_ratio_value, 0, src->tex_buf[src->w_tex_buf],
+				       src->hi_max[src->w_tex_buf]);
+	if (st != SCOPE_OK) {
+		log_failure("scope_histogram", st);
+		return;
+	}
+	src->w_tex_buf ^= 1;
+}
+
+const struct obs_source_info colormonitor_histogram = {
+	.id = "histogram_source",
+	.type = OBS_SOURCE_TYPE_INPUT,
+	.output_flags = OBS_SOURCE_VIDEO | OBS_SOURCE_CUSTOM_DRAW,
+	.get_name = his_get_name,
+	.create = his_create,
+	.destroy = his_destroy,
+	.update = his_update,
+	.get_defaults = his_get_defaults,
+	.get_width = his_get_width,
+	.get_height = his_get_width,
+	.video_render = scope_render_nothing,
+	.video_tick = cm_tick,
+};
+
+/* -- ROI: one capture shared by several scopes ----------------------------------------------------------- */
+
+static const char *roi_get_name(void *unused)
+{
+	UNUSED_PARAMETER(unused);
+	return "ROI";
+}
+
+static void roi_update(void *data, obs_data_t *settings)
+{
+	struct roi_source *src = data;
+	cm_update(&src->cm, settings);
+}
+
+static void *roi_create(obs_data_t *settings, obs_source_t *source)
+{
+	struct roi_source *src = bzalloc(sizeof(struct roi_source));
+	src->cm.flags = CM_FLAG_ROI | CM_FLAG_RAW_TEXTURE; /* src/roi.c:35 */
+	cm_create(&src->cm, settings, source);
+	pthread_mutex_init(&src->sources_mutex, NULL);
+	cm_request(&src->cm, roi_surface_cb, src);
+	roi_update(src, settings);
+	return src;
+}
+
+static void roi_destroy(void *data)
+{
+	struct roi_source *src = data;
+	cm_destroy(&src->cm);
+	pthread_mutex_destroy(&src->sources_mutex);
+	bfree(src);
+}
+
+void roi_register_source(struct roi_source *src, struct cm_source *cm)
+{
+	pthread_mutex_lock(&src->sources_mutex);
+	if (src->n_sources < ROI_MAX_SOURCES)
+		src->sources[src->n_sources++] = cm;
+	pthread_mutex_unlock(&src->sources_mutex);
+	cm->roi = src;
+}
+
+void roi_unregister_source(struct roi_source *src, struct cm_source *cm)
+{
+	pthread_mutex_lock(&src->sources_mutex);
+	for (size_t i = 0; i < src->n_sources; i++) {
+		if (src->sources[i] == cm) {
+			memmove(&src->sources[i], &src->sources[i + 1], (src->n_sources - i - 1) * sizeof(src->sources[0]));
+			src->n_sources--;
+			break;
+		}
+	}
+	pthread_mutex_unlock(&src->sources_mutex);
+	cm->roi = NULL;
+}
+
+void roi_update_flags(struct roi_source *src)
+{
+	/* src/roi.c:534-540: the ROI captures whatever planes its scopes need */
+	uint32_t flags = CM_FLAG_ROI | CM_FLAG_RAW_TEXTURE;
+	pthread_mutex_lock(&src->sources_mutex);
+	for (size_t i = 0; i < src->n_sources; i++)
+		flags |= src->sources[i]->flags & (CM_FLAG_CONVERT_RGB | CM_FLAG_CONVERT_YUV);
+	pthread_mutex_unlock(&src->sources_mutex);
+	src->cm.flags = flags;
+}
+
+void roi_surface_cb(void *data, struct cm_surface_data *surface_data)
+{
+	struct roi_source *src = data;
+
+	pthread_mutex_lock(&src->sources_mutex);
+	for (size_t i = 0; i < src->n_sources; i++) {
+		struct cm_source *cm = src->sources[i];
+		if (cm->callback)
+			cm->callback(cm->callback_data, surface_data);
+	}
+	pthread_mutex_unlock(&src->sources_mutex);
+}
+
+static void roi_tick(void *data, float unused)
+{
+	struct roi_source *src = data;
+	roi_update_flags(src);
+	cm_tick(&src->cm, unused);
+}
+
+static uint32_t roi_get_size(void *data)
+{
+	UNUSED_PARAMETER(data);
+	return 0;
+}
+
+const struct obs_source_info colormonitor_roi = {
+	.id = "colormonitor_roi",
+	.type = OBS_SOURCE_TYPE_INPUT,
+	.output_flags = OBS_SOURCE_VIDEO | OBS_SOURCE_CUSTOM_DRAW | OBS_SOURCE_INTERACTION,
+	.get_name = roi_get_name,
+	.create = roi_create,
+	.destroy = roi_destroy,
+	.update = roi_update,
+	.get_defaults = cm_get_defaults,
+	.get_width = roi_get_size,
+	.get_height = roi_get_size,
+	.video_render = scope_render_nothing,
+	.video_tick = roi_tick,
+};
+
+/* -- module entry (src/plugin-main.c:58-108, the sources on this path) ------------------------------------ */
+
+bool obs_module_load(void)
+{
+	if (cm_gpu_open(0) != SCOPE_OK)
+		return false; /* no GPU: the module refuses to load rather than fall back to a CPU loop */
+	obs_register_source(&colormonitor_vectorscope_v2);
+	obs_register_source(&colormonitor_waveform);
+	obs_register_source(&colormonitor_histogram);
+	obs_register_source(&colormonitor_roi);
+	blog(LOG_INFO, "[obs-color-monitor] scope accumulation on HIP device 0 (abi %d)", scope_abi_version());
+	return true;
+}
+
+void obs_module_unload(void)
+{
+	cm_gpu_close();
+}

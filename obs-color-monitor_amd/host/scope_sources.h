@@ -1,0 +1,78 @@
+/*
+ * scope_sources.h -- the three scope sources and the ROI fan-out, hot-path members only.
+ * Mirrors struct vss_source (src/vectorscope.c:36-66), struct wvs_source (src/waveform.c:31-49),
+ * struct his_source (src/histogram.c:37-60) and struct roi_source (src/roi.h:10-25).
+ */
+#ifndef SCOPE_SOURCES_H
+#define SCOPE_SOURCES_H
+
+#include "scope_common.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_SIZE 256
+#define WV_SIZE 256
+#define HI_SIZE 256
+#define COMP_RGB 0x07
+#define COMP_Y 0x20
+#define COMP_UV 0x50
+#define COMP_YUV (COMP_Y | COMP_UV)
+
+struct vss_source {
+	struct cm_source cm;
+	uint8_t *tex_buf[2];
+	int tex_cs[2];
+	volatile int w_tex_buf;
+};
+
+struct wvs_source {
+	struct cm_source cm;
+	uint8_t *tex_buf[2];
+	uint32_t tex_buf_width[2];
+	volatile int w_tex_buf;
+	uint32_t components;
+};
+
+struct his_source {
+	struct cm_source cm;
+	uint8_t *tex_buf[2];
+	uint32_t hi_max[2][3];
+	volatile int w_tex_buf;
+	uint32_t components;
+	int level_fixed_value;
+	int level_ratio_value;
+	bool logscale;
+};
+
+#define ROI_MAX_SOURCES 16
+struct roi_source {
+	struct cm_source cm;
+	pthread_mutex_t sources_mutex;
+	struct cm_source *sources[ROI_MAX_SOURCES]; /* DARRAY(struct cm_source *) in the reference */
+	size_t n_sources;
+};
+
+extern const struct obs_source_info colormonitor_vectorscope_v2; /* id "vectorscope_source", version 2 */
+extern const struct obs_source_info colormonitor_waveform;       /* id "waveform_source" */
+extern const struct obs_source_info colormonitor_histogram;      /* id "histogram_source" */
+extern const struct obs_source_info colormonitor_roi;            /* id "colormonitor_roi" */
+
+/* The callbacks the pipeline thread calls (cm_surface_cb_t): same names as the reference's statics. */
+void vss_surface_cb(void *data, struct cm_surface_data *surface_data); /* src/vectorscope.c:248-265 */
+void wvs_surface_cb(void *data, struct cm_surface_data *surface_data); /* src/waveform.c:272-289 */
+void his_surface_cb(void *data, struct cm_surface_data *surface_data); /* src/histogram.c:432-450 */
+void roi_surface_cb(void *data, struct cm_surface_data *surface_data); /* src/roi.c:329-341 */
+
+void roi_register_source(struct roi_source *src, struct cm_source *cm);   /* src/roi.c:315-320 */
+void roi_unregister_source(struct roi_source *src, struct cm_source *cm); /* src/roi.c:322-327 */
+void roi_update_flags(struct roi_source *src);                            /* flag merge of roi_tick, src/roi.c:534-540 */
+
+bool obs_module_load(void); /* src/plugin-main.c:58-108, the four sources of this path */
+void obs_module_unload(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

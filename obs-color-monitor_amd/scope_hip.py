@@ -170,6 +170,8 @@ class ScopeContext:
         self._check(self.L.scope_ctx_set_option(self.h, key.encode(), int(value)))
 
     def set_stream(self, hip_stream: int | None):
+        """Run on the caller's hipStream_t.  A NULL/0 handle selects the context's OWN stream, which does
+        not synchronise with torch's default stream: pass an explicit torch.cuda.Stream().cuda_stream."""
         self._check(self.L.scope_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)))
 
     def get_stream(self) -> int:

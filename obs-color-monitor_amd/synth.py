@@ -4,8 +4,12 @@ Distributions (SURVEY.md 8(d) plus a natural-video stand-in), all BGRA8 with alp
   uniform       every B,G,R byte uniform 0..255
   concentrated  bytes = 120 + U{0..15}: one tight chroma cluster, heavy LDS contention
   flat          the reference UI test's colour (R,G,B) = (0xC6,0xCC,0xD7): one bin for everything
-  gradient      smooth horizontal/vertical/diagonal ramps + 2 LSB of noise: neighbouring pixels share
-                or nearly share their chroma, like real video
+  ramp          horizontal/vertical/diagonal ramps + 2 LSB of noise.  R is a blend of B and G here, so
+                every pixel's (U,V) falls on ONE line of ~200 bins: a stress test (all bins saturate, every
+                wave sees a handful of bins), not a picture
+  natural       stand-in for real video: a smooth random colour field (64x36 random RGB control points,
+                bicubic up-sampling) + 2 LSB of sensor-like noise: neighbouring pixels share or nearly
+                share their chroma, the frame as a whole covers a wide 2-D region of the CbCr plane
 """
 
 
@@ -19,7 +23,16 @@ def make_rgb_frames(torch, n, w, h, dist, seed):
     elif dist == "flat":
         rgb = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
         rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0xD7, 0xCC, 0xC6
-    elif dist == "gradient":
+    elif dist == "natural":
+        import torch.nn.functional as F
+
+        rgb = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
+        for i in range(n):
+            ctrl = torch.rand((1, 3, 36, 64), device="cuda", generator=g) * 255.0
+            img = F.interpolate(ctrl, size=(h, w), mode="bicubic", align_corners=False)
+            img = img + torch.randint(0, 4, (1, 3, h, w), device="cuda", generator=g).float() - 1.5
+            rgb[i, :, :, :3] = img.clamp(0, 255).round().to(torch.uint8)[0].permute(1, 2, 0)
+    elif dist == "ramp":
         xs = torch.arange(w, device="cuda").view(1, 1, w)
         ys = torch.arange(h, device="cuda").view(1, h, 1)
         noise = torch.randint(0, 4, (n, h, w, 3), dtype=torch.int32, device="cuda", generator=g)

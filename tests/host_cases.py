@@ -1,0 +1,155 @@
+"""Drives the C host mirror (obs-color-monitor_amd/host) the way OBS drives the plugin:
+obs_module_load -> obs_source_info.create/update/video_tick -> frames staged into the 3-slot ring ->
+the "color-monitor" thread calls the scope callbacks -> the render side reads tex_buf[w_tex_buf ^ 1]."""
+import ctypes as C
+
+import numpy as np
+
+CB = {
+    "create": C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p),
+    "destroy": C.CFUNCTYPE(None, C.c_void_p),
+    "update": C.CFUNCTYPE(None, C.c_void_p, C.c_void_p),
+    "tick": C.CFUNCTYPE(None, C.c_void_p, C.c_float),
+    "size": C.CFUNCTYPE(C.c_uint32, C.c_void_p),
+    "defaults": C.CFUNCTYPE(None, C.c_void_p),
+    "name": C.CFUNCTYPE(C.c_char_p, C.c_void_p),
+    "render": C.CFUNCTYPE(None, C.c_void_p, C.c_void_p),
+}
+
+
+class SourceInfo(C.Structure):  # obs_shim.h's struct obs_source_info
+    _fields_ = [("id", C.c_char_p), ("version", C.c_uint32), ("type", C.c_int), ("output_flags", C.c_uint32),
+                ("get_name", CB["name"]), ("create", CB["create"]), ("destroy", CB["destroy"]),
+                ("get_width", CB["size"]), ("get_height", CB["size"]), ("get_defaults", CB["defaults"]),
+                ("update", CB["update"]), ("video_tick", CB["tick"]), ("video_render", CB["render"])]
+
+
+class Host:
+    def __init__(self, lib_path):
+        self.L = L = C.CDLL(lib_path)
+        L.obs_module_load.restype = C.c_bool
+        L.fake_obs_find_source.restype = C.POINTER(SourceInfo)
+        L.fake_obs_find_source.argtypes = [C.c_char_p]
+        L.fake_obs_data_create.restype = C.c_void_p
+        L.fake_obs_data_set_int.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+        L.fake_obs_data_release.argtypes = [C.c_void_p]
+        L.scope_host_cm.restype = C.c_void_p
+        L.scope_host_cm.argtypes = [C.c_void_p]
+        L.cm_stage_surface.restype = C.c_bool
+        L.cm_stage_surface.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.cm_drain.argtypes = [C.c_void_p]
+        L.roi_register_source.argtypes = [C.c_void_p, C.c_void_p]
+        L.roi_unregister_source.argtypes = [C.c_void_p, C.c_void_p]
+        L.scope_host_vss_table.restype = C.POINTER(C.c_uint8)
+        L.scope_host_vss_table.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.scope_host_wvs_table.restype = C.POINTER(C.c_uint8)
+        L.scope_host_wvs_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.scope_host_his_table.restype = C.POINTER(C.c_float)
+        L.scope_host_his_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.scope_host_frames_processed.restype = C.c_uint64
+        L.scope_host_frames_processed.argtypes = [C.c_void_p]
+        L.scope_host_frames_dropped.restype = C.c_uint64
+        L.scope_host_frames_dropped.argtypes = [C.c_void_p]
+        L.fake_obs_reset()
+        assert L.obs_module_load(), "module refused to load (no GPU / no HIP library)"
+
+    def close(self):
+        self.L.obs_module_unload()
+
+    def create(self, source_id, **settings):
+        info = self.L.fake_obs_find_source(source_id.encode()).contents
+        d = self.L.fake_obs_data_create()
+        info.get_defaults(d)
+        for k, v in settings.items():
+            self.L.fake_obs_data_set_int(d, k.encode(), int(v))
+        obj = info.create(d, None)
+        self.L.fake_obs_data_release(d)
+        return info, obj
+
+    def stage(self, obj, surface, width, height):
+        """surface: numpy [sheight, linesize] stacked planes."""
+        return bool(self.L.cm_stage_surface(self.L.scope_host_cm(obj), surface.ctypes.data_as(C.c_void_p),
+                                            surface.shape[1], width, height))
+
+    def drain(self, obj):
+        self.L.cm_drain(self.L.scope_host_cm(obj))
+
+    def vss_table(self, obj):
+        cs = C.c_int()
+        p = self.L.scope_host_vss_table(obj, C.byref(cs))
+        return (np.ctypeslib.as_array(p, (256, 256)).copy() if p else None), cs.value
+
+    def wvs_table(self, obj):
+        w = C.c_uint32()
+        p = self.L.scope_host_wvs_table(obj, C.byref(w))
+        return np.ctypeslib.as_array(p, (256, w.value, 4)).copy() if p else None
+
+    def his_table(self, obj):
+        hi = (C.c_uint32 * 3)()
+        p = self.L.scope_host_his_table(obj, hi)
+        return (np.ctypeslib.as_array(p, (256, 4)).copy() if p else None), list(hi)
+
+
+def run_host_checks(host, oracle, w=96, h=40):
+    ids = [b"vectorscope_source", b"waveform_source", b"histogram_source", b"colormonitor_roi"]
+    assert host.L.fake_obs_source_count() == 4
+    for i in ids:
+        assert host.L.fake_obs_find_source(i).contents.id == i
+    assert host.L.fake_obs_find_source(b"vectorscope_source").contents.version == 2
+
+    frames = []
+    for k, dist in enumerate((1, 2, 5)):
+        rgb = oracle.fill_frame(w, h, dist, 40 + k)
+        frames.append((rgb, oracle.rgb_to_yuv(rgb, w, 2)))
+
+    # -- a stand-alone vectorscope source: its own ring + "color-monitor" thread ------------------------
+    info, vss = host.create("vectorscope_source", colorspace=2)
+    assert info.get_width(vss) == 256 and info.get_height(vss) == 256
+    assert host.vss_table(vss)[0] is None  # nothing drawn yet
+    # thread not started yet (no video_tick): two slots fill, the third frame is dropped (common.c:260-268)
+    assert [host.stage(vss, frames[0][1], w, h) for _ in range(3)] == [True, True, False]
+    assert host.L.scope_host_frames_dropped(vss) == 1
+    info.video_tick(vss, 0.0)
+    host.drain(vss)
+    assert host.L.scope_host_frames_processed(vss) == 2
+    for rgb, yuv in frames:
+        assert host.stage(vss, yuv, w, h)
+        host.drain(vss)
+        got, cs = host.vss_table(vss)
+        assert cs == 2 and np.array_equal(got, oracle.vectorscope(yuv, w))
+    info.destroy(vss)
+
+    # -- three scopes behind one ROI capture: one staged surface, three callbacks on one thread ------------
+    roi_info, roi = host.create("colormonitor_roi")
+    vinfo, vss = host.create("vectorscope_source")
+    winfo, wvs = host.create("waveform_source", components=0x07)
+    hinfo, his = host.create("histogram_source", components=0x07, logscale=1)
+    for obj in (vss, wvs, his):
+        host.L.roi_register_source(roi, host.L.scope_host_cm(obj))
+    for info_, obj in ((vinfo, vss), (winfo, wvs), (hinfo, his)):
+        info_.video_tick(obj, 0.0)  # attached to an ROI: no thread of their own (common.c:587-588)
+    roi_info.video_tick(roi, 0.0)   # merges the scopes' plane flags (roi.c:534-540), starts the ROI thread
+    for rgb, yuv in frames:
+        stacked = np.ascontiguousarray(np.concatenate([rgb, yuv]))  # RGB rows then YUV rows (common.c:284-291)
+        assert host.stage(roi, stacked, w, h)
+        host.drain(roi)
+        assert np.array_equal(host.vss_table(vss)[0], oracle.vectorscope(yuv, w))
+        assert np.array_equal(host.wvs_table(wvs), oracle.waveform(rgb, yuv, w, 0x07))
+        want_f, want_hi = oracle.histogram(rgb, yuv, w, 0x07, logscale=1)
+        got_f, got_hi = host.his_table(his)
+        assert np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32)) and got_hi == list(want_hi)
+    assert winfo.get_width(wvs) == w and winfo.get_height(wvs) == 256
+    # a waveform switched to luma gets the YUV plane of the same surface
+    d = host.L.fake_obs_data_create()
+    winfo.get_defaults(d)
+    host.L.fake_obs_data_set_int(d, b"components", 0x20)
+    winfo.update(wvs, d)
+    host.L.fake_obs_data_release(d)
+    rgb, yuv = frames[0]
+    assert host.stage(roi, np.ascontiguousarray(np.concatenate([rgb, yuv])), w, h)
+    host.drain(roi)
+    assert np.array_equal(host.wvs_table(wvs), oracle.waveform(rgb, yuv, w, 0x20))
+    for obj in (vss, wvs, his):
+        host.L.roi_unregister_source(roi, host.L.scope_host_cm(obj))
+    for info_, obj in ((vinfo, vss), (winfo, wvs), (hinfo, his), (roi_info, roi)):
+        info_.destroy(obj)

@@ -20,13 +20,13 @@ for s in $stages; do
     lds)   timeout 300 ./tools/lds_atomic_bench > $out/lds_atomic.txt 2>&1; rc=$? ;;
     sweepq) timeout 900 python tools/sweep.py --quick --out $out/sweep.jsonl > $out/sweep.out 2> $out/sweep.log; rc=$? ;;
     pmc)   # PMC passes on their own (no --stats / sys-trace), per the MI355X guide
-           for d in uniform gradient; do
+           for d in ${PMC_DISTS:-uniform natural}; do
              (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY \
                 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq_$d -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --settle-seconds 0.2 --no-cpu --dist $d $BENCH_EXTRA) > $out/pmc_sq_$d.log 2>&1
              (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE \
                 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq2_$d -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --settle-seconds 0.2 --no-cpu --dist $d $BENCH_EXTRA) > $out/pmc_sq2_$d.log 2>&1
            done; rc=$?
-           python tools/pmc_summary.py $out/pmc_sq_uniform $out/pmc_sq_gradient $out/pmc_sq2_uniform $out/pmc_sq2_gradient > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt ;;
+           python tools/pmc_summary.py $out/pmc_sq_* $out/pmc_sq2_* > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt ;;
     trace) (python tools/lds_trace_gen.py /tmp/lds_traces.bin 2> $out/lds_trace_model.txt && timeout 300 ./tools/lds_trace_bench /tmp/lds_traces.bin > $out/lds_trace.txt 2>&1); rc=$?; paste -d'|' $out/lds_trace_model.txt $out/lds_trace.txt | cut -c1-200 > $out/lds_trace_both.txt ;;
     *) echo "unknown stage $s"; rc=99 ;;
   esac

@@ -5,7 +5,11 @@ import csv
 import glob
 import sys
 
+import os
+
 for d in sys.argv[1:]:
+    if not os.path.isdir(d):
+        continue
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:

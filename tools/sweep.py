@@ -53,7 +53,9 @@ def main():
     out = open(args.out, "w")
 
     ctx = ocm.ScopeContext(0)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    stream = torch.cuda.Stream()  # explicit stream shared by torch and the C-ABI (NULL would mean ctx's own)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
     info = ctx.device_info()
     print(f"# {info}", file=sys.stderr)
     n = args.frames
@@ -93,7 +95,7 @@ def main():
         emit(dict(tag="ref", what=name, ms=round(ms, 4), gbps=round(bytes_moved / (ms * 1e-3) / 1e9, 1)))
     del a, b
 
-    dists = ["uniform", "concentrated", "flat", "gradient"] if not args.quick else ["uniform", "gradient"]
+    dists = ["uniform", "concentrated", "flat", "ramp", "natural"] if not args.quick else ["uniform", "natural"]
     data = {d: make_frames(ctx, n, d) for d in dists}
     tab = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
     # let the clocks leave idle before anything is timed
@@ -120,9 +122,10 @@ def main():
             for groups in (0, 2, 3):
                 for hash_ in (0, 1):
                     vss_run(batch, d, **{"vss.merge": merge, "vss.groups": groups, "vss.hash": hash_})
-        for unroll in (2, 4):
+        for unroll in (2, 4, 8):
             for nt in (0, 1):
                 vss_run(batch, d, **{"vss.unroll": unroll, "nt": nt})
+                vss_run(batch, d, **{"vss.unroll": unroll, "nt": nt, "vss.merge": 0, "vss.groups": 0, "vss.hash": 0})
         vss_run(batch, d, **{"vss.groups": 1})
     for k, v in defaults.items():
         ctx.set_option(k, v)
@@ -160,7 +163,7 @@ def main():
     for d in dists:
         rgb, yuv = data[d]
         batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-        for unroll in (2, 4):
+        for unroll in (2, 4, 8):
             for nt in (0, 1):
                 ctx.set_option("his.unroll", unroll)
                 ctx.set_option("nt", nt)
@@ -177,7 +180,7 @@ def main():
         rgb, yuv = data[d]
         batch_rgb = ctx.make_device_batch(rgb[:nw], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
         batch_yuv = ctx.make_device_batch(yuv[:nw], 4 * W, W, H, planes_are_rgb=False)
-        for unroll in (4, 8):
+        for unroll in (4, 8, 16):
             for nt in (0, 1):
                 ctx.set_option("wvs.unroll", unroll)
                 ctx.set_option("nt", nt)
