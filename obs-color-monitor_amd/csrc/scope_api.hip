@@ -409,13 +409,13 @@ int scope_ctx_create(int device, scope_ctx **out)
 		scope_ctx_destroy(ctx);
 		return SCOPE_EIO;
 	}
-	ctx->tn.vss_merge = 2;
+	ctx->tn.vss_merge = 3;
 	ctx->tn.vss_unroll = 4;
-	ctx->tn.vss_hash = 1;
-	ctx->tn.vss_groups_log2 = 2;
-	ctx->tn.his_unroll = 4;
-	ctx->tn.wvs_unroll = 8;
-	ctx->tn.nt_loads = 0;
+	ctx->tn.vss_hash = 0;
+	ctx->tn.vss_groups_log2 = 3;
+	ctx->tn.his_unroll = 2;
+	ctx->tn.wvs_unroll = 4;
+	ctx->tn.nt_loads = 1;
 	ctx->err[0] = 0;
 	*out = ctx;
 	return SCOPE_OK;

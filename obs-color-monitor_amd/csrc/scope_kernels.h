@@ -40,7 +40,7 @@ struct ScopeK0 {
 
 /* Tunables the host may flip for A/B runs (scope_ctx_set_option). */
 struct ScopeTuning {
-	int vss_merge;       /* 0 none, 1 lane-local run merge, 2 = 1 + wave-uniform shortcut */
+	int vss_merge;       /* 0 none, 1 lane-local run merge, 2 = 1 + wave-uniform shortcut, 3 adaptive */
 	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 2 or 4 */
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3 */

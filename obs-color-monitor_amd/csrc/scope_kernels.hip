@@ -98,7 +98,8 @@ ScopeK0 scope_k0_matrix(int colorspace)
  *
  * Loads are double-buffered: the U loads of batch b+1 are in flight while batch b is binned, and
  * `before_batch` (uniform; may contain barriers) runs between issue and use, so the vectorscope's
- * clamp passes do not drain the memory pipeline.  Row pitch is honoured.
+ * clamp passes do not drain the memory pipeline.  `fn(v, ok)` gets a whole batch: U cells per lane
+ * and which of them are real.  Row pitch is honoured.
  * ---------------------------------------------------------------------------------------- */
 
 typedef u32 scope_v4 __attribute__((vector_size(16)));
@@ -175,19 +176,19 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 #define SCOPE_BIN(v, ok)                                                  \
 	do {                                                              \
 		before_batch((u32)U * blockDim.x * VECW);                 \
-		_Pragma("unroll") for (int k = 0; k < U; k++) if (ok[k]) fn(v[k]); \
+		fn(v, ok);                                                \
 	} while (0)
 
+	/* Every ISSUE is unconditional -- past the end it only re-reads the safe cell with ok = false --
+	 * so on every path exactly U younger loads are outstanding when a batch is binned and the
+	 * compiler can wait with vmcnt(U) instead of draining the queue. */
 	SCOPE_ISSUE(va, oka);
 	for (u32 b = 0; b < batches; b += 2) {
+		SCOPE_ISSUE(vb, okb);
+		SCOPE_BIN(va, oka);
+		SCOPE_ISSUE(va, oka);
 		if (b + 1 < batches)
-			SCOPE_ISSUE(vb, okb);
-		SCOPE_BIN(va, oka); /* upper bound of the pixels a batch adds: U * blockDim * VECW */
-		if (b + 1 < batches) {
-			if (b + 2 < batches)
-				SCOPE_ISSUE(va, oka);
 			SCOPE_BIN(vb, okb);
-		}
 	}
 #undef SCOPE_ISSUE
 #undef SCOPE_BIN
@@ -246,6 +247,15 @@ template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, 
 	return min(w & 0xffffu, 255u);
 }
 
+/* The four pixels of one 16-byte cell.
+ *   MERGE 0  four plain adds.
+ *   MERGE 1  runs of equal neighbours inside the cell are folded into one add.
+ *   MERGE 2  = 1, plus: when every lane of the wave sits on ONE bin, one lane adds for all.
+ *   MERGE 3  adaptive (in vss_region): once per batch the wave votes on whether it is on flat
+ *            content (at least half of its lanes hold only single-colour cells); only then MERGE 2.
+ * Same-address LDS atomics serialise at ~4 clk per lane (profiles/round1/lds_atomic_microbench.txt):
+ * a flat frame costs 127 clk per wave instruction unmerged, 4.5 merged; on noisy video the folding
+ * only costs VALU, hence the vote. */
 template <int MERGE, int HASH> __device__ __forceinline__ void vss_add_run4(u32 *tab, u32 i0, u32 i1, u32 i2, u32 i3)
 {
 	if (MERGE == 0) {
@@ -269,7 +279,7 @@ template <int MERGE, int HASH> __device__ __forceinline__ void vss_add_run4(u32 
 		n0 += n1;
 		n1 = 0;
 	}
-	if (MERGE == 2) {
+	if (MERGE >= 2) {
 		/* whole wave on one bin (flat areas): one lane adds for everybody */
 		const u32 first = __builtin_amdgcn_readfirstlane(i0);
 		const bool same = (n0 == 4) && (i0 == first);
@@ -331,23 +341,61 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		since_clamp += px;
 	};
 	if (VECW == 4) {
-		scope_stream<4, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, [&](const scope_v4 &q) {
-			u32 p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-			if (FUSE) {
-				p0 = scope_k0_texel(p0, k0, true, false);
-				p1 = scope_k0_texel(p1, k0, true, false);
-				p2 = scope_k0_texel(p2, k0, true, false);
-				p3 = scope_k0_texel(p3, k0, true, false);
-			}
-			vss_add_run4<MERGE, HASH>(tab, vss_bin(p0), vss_bin(p1), vss_bin(p2), vss_bin(p3));
-		});
+		scope_stream<4, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch,
+				       [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
+					       u32 idx[U][4];
+#pragma unroll
+					       for (int k = 0; k < U; k++)
+#pragma unroll
+						       for (int j = 0; j < 4; j++) {
+							       u32 p = q[k][j];
+							       if (FUSE)
+								       p = scope_k0_texel(p, k0, true, false);
+							       idx[k][j] = vss_bin(p);
+						       }
+					       /* MERGE 3: ONE vote per batch (16 pixels per lane): does at least half of the wave
+						* hold nothing but single-colour cells?  Then it sits on flat content (screen
+						* capture, letterbox, graphics) where unmerged same-address atomics would cost
+						* ~30x; noisy video never passes the vote and only pays the plain adds.  A
+						* vote per cell costs more in SALU round trips than it saves. */
+					       bool fold = MERGE == 1 || MERGE == 2;
+					       if (MERGE == 3) {
+						       bool flat = true;
+#pragma unroll
+						       for (int k = 0; k < U; k++)
+							       flat &= !ok[k] || ((idx[k][0] == idx[k][1]) & (idx[k][1] == idx[k][2]) &
+										  (idx[k][2] == idx[k][3]));
+						       fold = __popcll(__ballot(flat)) >= 32;
+					       }
+					       if (fold) {
+#pragma unroll
+						       for (int k = 0; k < U; k++)
+							       if (ok[k])
+								       vss_add_run4<(MERGE == 1 ? 1 : 2), HASH>(tab, idx[k][0], idx[k][1],
+													   idx[k][2], idx[k][3]);
+					       } else {
+#pragma unroll
+						       for (int k = 0; k < U; k++)
+							       if (ok[k]) {
+								       vss_add<HASH>(tab, idx[k][0], 1);
+								       vss_add<HASH>(tab, idx[k][1], 1);
+								       vss_add<HASH>(tab, idx[k][2], 1);
+								       vss_add<HASH>(tab, idx[k][3], 1);
+							       }
+					       }
+				       });
 	} else {
-		scope_stream<1, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, [&](const u32 &q) {
-			u32 p0 = q;
-			if (FUSE)
-				p0 = scope_k0_texel(p0, k0, true, false);
-			vss_add<HASH>(tab, vss_bin(p0), 1);
-		});
+		scope_stream<1, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch,
+				       [&](const u32(&q)[U], const bool(&ok)[U]) {
+#pragma unroll
+					       for (int k = 0; k < U; k++) {
+						       u32 p0 = q[k];
+						       if (FUSE)
+							       p0 = scope_k0_texel(p0, k0, true, false);
+						       if (ok[k])
+							       vss_add<HASH>(tab, vss_bin(p0), 1);
+					       }
+				       });
 	}
 }
 
@@ -425,26 +473,31 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 	const bool need_uv = (chmask & 5u) != 0, need_y = (chmask & 2u) != 0;
 	auto nothing = [](u32) {};
 	if (VECW == 4) {
-		scope_stream<4, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing, [&](const scope_v4 &q) {
-			u32 p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-			if (FUSE) {
-				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
-				p1 = scope_k0_texel(p1, k0, need_uv, need_y);
-				p2 = scope_k0_texel(p2, k0, need_uv, need_y);
-				p3 = scope_k0_texel(p3, k0, need_uv, need_y);
-			}
-			his_add(tab, p0, chmask, rep);
-			his_add(tab, p1, chmask, rep);
-			his_add(tab, p2, chmask, rep);
-			his_add(tab, p3, chmask, rep);
-		});
+		scope_stream<4, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing,
+				       [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
+#pragma unroll
+					       for (int k = 0; k < U; k++)
+#pragma unroll
+						       for (int j = 0; j < 4; j++) {
+							       u32 p = q[k][j];
+							       if (FUSE)
+								       p = scope_k0_texel(p, k0, need_uv, need_y);
+							       if (ok[k])
+								       his_add(tab, p, chmask, rep);
+						       }
+				       });
 	} else {
-		scope_stream<1, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing, [&](const u32 &q) {
-			u32 p0 = q;
-			if (FUSE)
-				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
-			his_add(tab, p0, chmask, rep);
-		});
+		scope_stream<1, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing,
+				       [&](const u32(&q)[U], const bool(&ok)[U]) {
+#pragma unroll
+					       for (int k = 0; k < U; k++) {
+						       u32 p0 = q[k];
+						       if (FUSE)
+							       p0 = scope_k0_texel(p0, k0, need_uv, need_y);
+						       if (ok[k])
+							       his_add(tab, p0, chmask, rep);
+					       }
+				       });
 	}
 }
 
@@ -569,17 +622,13 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 
 		const u32 my_rows = (r1 - r0 > wave) ? (r1 - r0 - wave + nwaves - 1) / nwaves : 0;
 		const u32 batches = (my_rows + (u32)U - 1) / (u32)U;
-		if (batches)
-			WVS_ISSUE(va, oka);
+		WVS_ISSUE(va, oka); /* unconditional issues keep the vmcnt bookkeeping exact: see scope_stream */
 		for (u32 b = 0; b < batches; b += 2) {
-			if (b + 1 < batches)
-				WVS_ISSUE(vb, okb);
+			WVS_ISSUE(vb, okb);
 			WVS_BIN(va, oka);
-			if (b + 1 < batches) {
-				if (b + 2 < batches)
-					WVS_ISSUE(va, oka);
+			WVS_ISSUE(va, oka);
+			if (b + 1 < batches)
 				WVS_BIN(vb, okb);
-			}
 		}
 #undef WVS_ISSUE
 #undef WVS_BIN
@@ -804,7 +853,9 @@ template <int U, bool NT> hipError_t vss_pick_merge(int merge, int fuse, int has
 		return vss_pick_fuse<U, NT, 0>(fuse, hash, a);
 	if (merge == 1)
 		return vss_pick_fuse<U, NT, 1>(fuse, hash, a);
-	return vss_pick_fuse<U, NT, 2>(fuse, hash, a);
+	if (merge == 2)
+		return vss_pick_fuse<U, NT, 2>(fuse, hash, a);
+	return vss_pick_fuse<U, NT, 3>(fuse, hash, a);
 }
 template <int U> hipError_t vss_pick_nt(int nt, int merge, int fuse, int hash, const VssArgs *a)
 {
@@ -812,6 +863,8 @@ template <int U> hipError_t vss_pick_nt(int nt, int merge, int fuse, int hash, c
 }
 hipError_t vss_pick(int unroll, int nt, int merge, int fuse, int hash, const VssArgs *a)
 {
+	if (merge >= 3 && unroll > 4)
+		unroll = 4; /* the adaptive variant keeps a whole batch of bin indices live: 8 cells would spill */
 	if (unroll <= 2)
 		return vss_pick_nt<2>(nt, merge, fuse, hash, a);
 	if (unroll <= 4)
@@ -896,7 +949,7 @@ hipError_t scope_kernels_init(void)
 	for (int unroll = 2; unroll <= 8; unroll *= 2)
 		for (int nt = 0; nt < 2; nt++)
 			for (int fuse = 0; fuse < 2; fuse++) {
-				for (int merge = 0; merge < 3; merge++)
+				for (int merge = 0; merge < 4; merge++)
 					for (int hash = 0; hash < 2; hash++)
 						if (e == hipSuccess)
 							e = vss_pick(unroll, nt, merge, fuse, hash, NULL);

@@ -18,7 +18,7 @@ def test_vectorscope_geometry(emul_ctx, oracle, w, h, ls):
     pc.check_vectorscope(emul_ctx, oracle, w, h, 1, ls)
 
 
-@pytest.mark.parametrize("merge", [0, 1, 2])
+@pytest.mark.parametrize("merge", [0, 1, 2, 3])
 @pytest.mark.parametrize("hash_", [0, 1])
 def test_vectorscope_merge_and_hash_variants(emul_ctx, oracle, merge, hash_):
     with pc.options(emul_ctx, **{"vss.merge": merge, "vss.hash": hash_}):

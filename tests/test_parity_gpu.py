@@ -44,7 +44,7 @@ def test_geometry_all_scopes(hip_ctx, oracle, w, h, ls):
     pc.check_k0(hip_ctx, oracle, w, h, 1, 2, ls)
 
 
-@pytest.mark.parametrize("merge", [0, 1, 2])
+@pytest.mark.parametrize("merge", [0, 1, 2, 3])
 @pytest.mark.parametrize("unroll", [2, 4])
 @pytest.mark.parametrize("hash_", [0, 1])
 def test_vectorscope_variants(hip_ctx, oracle, merge, unroll, hash_):

@@ -107,7 +107,7 @@ def main():
         ctx.sync()
 
     # ---- A: vectorscope, batch launch: merge x lane groups x hash x unroll x nt x distribution ---------
-    defaults = {"vss.merge": 2, "vss.unroll": 4, "vss.hash": 1, "vss.groups": 2, "nt": 0}
+    defaults = {"vss.merge": 3, "vss.unroll": 4, "vss.hash": 0, "vss.groups": 3, "nt": 1}
 
     def vss_run(batch, d, **opt):
         for k, v in {**defaults, **opt}.items():
@@ -118,15 +118,15 @@ def main():
     for d in dists:
         rgb, yuv = data[d]
         batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
-        for merge in (0, 1, 2):
+        for merge in (0, 2, 3):
             for groups in (0, 2, 3):
                 for hash_ in (0, 1):
-                    vss_run(batch, d, **{"vss.merge": merge, "vss.groups": groups, "vss.hash": hash_})
-        for unroll in (2, 4, 8):
-            for nt in (0, 1):
-                vss_run(batch, d, **{"vss.unroll": unroll, "nt": nt})
-                vss_run(batch, d, **{"vss.unroll": unroll, "nt": nt, "vss.merge": 0, "vss.groups": 0, "vss.hash": 0})
-        vss_run(batch, d, **{"vss.groups": 1})
+                    for nt in (0, 1):
+                        vss_run(batch, d, **{"vss.merge": merge, "vss.groups": groups, "vss.hash": hash_, "nt": nt})
+        for unroll in (2, 8):
+            vss_run(batch, d, **{"vss.unroll": unroll})
+            vss_run(batch, d, **{"vss.unroll": unroll, "vss.hash": 1, "vss.groups": 2})
+        vss_run(batch, d, **{"vss.merge": 1})
     for k, v in defaults.items():
         ctx.set_option(k, v)
 
@@ -170,8 +170,8 @@ def main():
                 for comp in (0x07, 0x02):
                     k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt, sync=False))
                     report("his_batch", k, wall, l, n, 4096, dist=d, unroll=unroll, nt=nt, comp=hex(comp))
-    ctx.set_option("his.unroll", 4)
-    ctx.set_option("nt", 0)
+    ctx.set_option("his.unroll", 2)
+    ctx.set_option("nt", 1)
 
     # ---- F: waveform ------------------------------------------------------------------------------------
     nw = min(n, 16)
@@ -187,8 +187,8 @@ def main():
                 for comp, bt in ((0x07, batch_rgb), (0x04, batch_rgb), (0x20, batch_yuv)):
                     k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(bt, comp, wtab, sync=False), reps=10)
                     report("wvs_batch", k, wall, l, nw, 256 * W * 4, dist=d, unroll=unroll, nt=nt, comp=hex(comp))
-    ctx.set_option("wvs.unroll", 8)
-    ctx.set_option("nt", 0)
+    ctx.set_option("wvs.unroll", 4)
+    ctx.set_option("nt", 1)
     # single-frame waveform (row bands + saturating reduce)
     rgb, yuv = data["uniform"]
     one = ctx.make_device_batch(rgb[:1], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
