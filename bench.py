@@ -186,6 +186,15 @@ def main():
     pix_per_step = world * n * w * h
     value = pix_per_step * args.steps / elapsed / 1e9
     algo_bytes = n * (4 * w * h + (table_bytes if wl != "histogram" else 4096))  # SURVEY.md 8(d), per launch
+    # HBM bytes per launch from the PMC counters: measured once with rocprofv3 on this exact workload and
+    # committed (bench.py cannot run under a counter pass itself); null for any other configuration
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")))
+        if world == 1 and (pmc["workload"], pmc["frames_per_step"], pmc["width"], pmc["height"]) == (wl, n, w, h) and not args.option:
+            traffic = pmc["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     kern_avg_ms = kernel_ms / launches if launches else float("nan")
     achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches else float("nan")
     result = {
@@ -226,7 +235,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": round(kern_avg_ms, 5),
             "launches_timed": launches,
