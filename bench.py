@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "ramp", "natural"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-reduce", action="store_true",
+                    help="run the RCCL table reduction even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
     args = ap.parse_args()
 
@@ -62,8 +64,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_reduce
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = ocm.ScopeContext(local_rank)  # raises without libscope_hip.so / a GPU: no fallback
@@ -99,7 +105,7 @@ def main():
         table_bytes = 4096
     tables = [torch.empty((n, table_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)]
     reducer = None
-    if world > 1:
+    if use_dist:
         assert wl != "waveform", "multi-GPU waveform shards by column strip without a reduction; bench covers K1/K3"
         from obs_color_monitor_amd.row_tiles import TableAllReduce
 
@@ -133,7 +139,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.profile(True)
@@ -142,12 +148,12 @@ def main():
         step(i)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     launches, kernel_ms = ctx.kernel_ms()
     ctx.profile(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -173,7 +179,7 @@ def main():
             mine = o.histogram_counts(host_planes[f], o.rgb_to_yuv(host_planes[f], w, 2), w, args.components)
             mine = mine.astype(np.int64)
         want = torch.from_numpy(mine.reshape(-1).astype(np.int64)).cuda()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(want)
         if wl != "histogram":
             want = want.clamp(max=255)
@@ -272,7 +278,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if not parity:
         sys.exit(3)

@@ -39,6 +39,7 @@ extern "C" {
 #define SCOPE_ENODEV (-19)  /* no usable HIP device */
 #define SCOPE_EIO (-5)      /* a HIP runtime call failed; see scope_last_error() */
 #define SCOPE_ENODATA (-61) /* the plane the scope needs is NULL: nothing was done */
+#define SCOPE_EAGAIN (-11)  /* pipeline: every ring slot is in flight (collect first) / nothing to collect */
 
 /* ---- flags -------------------------------------------------------------------------------- */
 #define SCOPE_IN_DEVICE 0x1u  /* plane pointers are device (HBM) pointers; default: host */
@@ -148,6 +149,36 @@ int scope_waveform_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t c
 			 uint8_t *out);
 int scope_histogram_counts_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
 				 uint32_t *counts);
+
+/* ---- frame pipeline: the staging ring moved into HBM ----------------------------------------
+ * Replaces the reference's 3-slot staging ring + pipeline thread (CM_SURFACE_QUEUE_SIZE,
+ * src/common.h:46; cm_render_target / cm_pipeline_thread, src/common.c:223-403) for a host that
+ * produces RGB frames at video rate: per frame one host->HBM copy of the RGB plane on an upload
+ * stream, then K0-fused vectorscope + waveform + histogram on the compute stream, then the three
+ * small tables back on a download stream -- three hipStreams overlapped across `depth` frames in
+ * flight.  Source planes in pinned memory (hipHostMalloc / hipHostRegister) make the upload truly
+ * asynchronous; they must stay valid until the frame is collected. */
+typedef struct scope_pipe scope_pipe;
+
+struct scope_pipe_config {
+	uint32_t width, height;
+	uint32_t depth;          /* frames in flight, 1..16; the reference uses 3 */
+	int colorspace;          /* for the fused K0 */
+	uint32_t wvs_components; /* 0 = no waveform */
+	uint32_t his_components; /* 0 = no histogram */
+	int want_vectorscope;
+};
+
+int scope_pipe_create(scope_ctx *ctx, const struct scope_pipe_config *cfg, scope_pipe **out);
+void scope_pipe_destroy(scope_pipe *pipe);
+/* Enqueue one RGB frame (bytes B,G,R,A).  SCOPE_EAGAIN when `depth` frames are already in flight. */
+int scope_pipe_submit(scope_pipe *pipe, const uint8_t *rgb_host, uint32_t linesize);
+/* Wait for the OLDEST frame in flight and hand out its tables (pinned host memory owned by the
+ * pipe, valid until `depth` more frames have been submitted).  Pointers for scopes that were not
+ * configured come back NULL.  his_counts is uint32[256][4] (apply scope_histogram_level for K3b).
+ * SCOPE_EAGAIN when nothing is in flight. */
+int scope_pipe_collect(scope_pipe *pipe, const uint8_t **vectorscope, const uint8_t **waveform,
+		       const uint32_t **his_counts);
 
 /* ---- multi-GPU glue ------------------------------------------------------------------------
  * A row-tiled frame gives each GPU a clamped u8 partial table; saturating add of clamped

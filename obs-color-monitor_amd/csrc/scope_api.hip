@@ -367,6 +367,8 @@ const char *scope_strerror(int status)
 		return "HIP runtime error";
 	case SCOPE_ENODATA:
 		return "required plane is NULL";
+	case SCOPE_EAGAIN:
+		return "pipeline full / empty";
 	default:
 		return "unknown status";
 	}
@@ -804,6 +806,188 @@ int scope_ctx_kernel_ms(scope_ctx *ctx, uint32_t *launches, float *total_ms)
 	}
 	*launches = n;
 	*total_ms = sum;
+	return SCOPE_OK;
+}
+
+/* ---- frame pipeline ---------------------------------------------------------------------------- */
+
+#define SCOPE_PIPE_MAX_DEPTH 16
+
+struct scope_pipe_slot {
+	uint8_t *dev_rgb;
+	uint8_t *dev_vss, *dev_wvs;
+	uint32_t *dev_his;
+	uint8_t *host_tables; /* pinned: vss | wvs | his back to back */
+	hipEvent_t uploaded, computed, downloaded;
+};
+
+struct scope_pipe {
+	scope_ctx *ctx;
+	struct scope_pipe_config cfg;
+	size_t pitch, vss_bytes, wvs_bytes, his_bytes;
+	hipStream_t up, down;
+	scope_pipe_slot slot[SCOPE_PIPE_MAX_DEPTH];
+	uint64_t submitted, collected;
+};
+
+void scope_pipe_destroy(scope_pipe *p)
+{
+	if (!p)
+		return;
+	(void)hipSetDevice(p->ctx->device);
+	(void)hipStreamSynchronize(p->ctx->stream);
+	if (p->up)
+		(void)hipStreamSynchronize(p->up);
+	if (p->down)
+		(void)hipStreamSynchronize(p->down);
+	for (uint32_t i = 0; i < p->cfg.depth; i++) {
+		scope_pipe_slot *s = &p->slot[i];
+		if (s->dev_rgb)
+			(void)hipFree(s->dev_rgb);
+		if (s->dev_vss)
+			(void)hipFree(s->dev_vss);
+		if (s->dev_wvs)
+			(void)hipFree(s->dev_wvs);
+		if (s->dev_his)
+			(void)hipFree(s->dev_his);
+		if (s->host_tables)
+			(void)hipHostFree(s->host_tables);
+		if (s->uploaded)
+			(void)hipEventDestroy(s->uploaded);
+		if (s->computed)
+			(void)hipEventDestroy(s->computed);
+		if (s->downloaded)
+			(void)hipEventDestroy(s->downloaded);
+	}
+	if (p->up)
+		(void)hipStreamDestroy(p->up);
+	if (p->down)
+		(void)hipStreamDestroy(p->down);
+	free(p);
+}
+
+int scope_pipe_create(scope_ctx *ctx, const struct scope_pipe_config *cfg, scope_pipe **out)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!cfg || !out || cfg->width == 0 || cfg->height == 0 || cfg->depth == 0 || cfg->depth > SCOPE_PIPE_MAX_DEPTH)
+		return fail(ctx, SCOPE_EINVAL, "bad pipeline configuration", hipSuccess);
+	st = check_geometry(ctx, cfg->width * 4, cfg->width, cfg->height);
+	if (st)
+		return st;
+	scope_pipe *p = (scope_pipe *)calloc(1, sizeof *p);
+	if (!p)
+		return SCOPE_ENOMEM;
+	p->ctx = ctx;
+	p->cfg = *cfg;
+	p->pitch = round_up((size_t)cfg->width * 4, 16);
+	p->vss_bytes = cfg->want_vectorscope ? SCOPE_VSS_BINS : 0;
+	p->wvs_bytes = (cfg->wvs_components & 0x77u) ? (size_t)SCOPE_WV_SIZE * cfg->width * 4 : 0;
+	p->his_bytes = (cfg->his_components & 0x77u) ? SCOPE_HIS_WORDS * sizeof(uint32_t) : 0;
+	bool ok = hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking) == hipSuccess &&
+		  hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking) == hipSuccess;
+	for (uint32_t i = 0; ok && i < cfg->depth; i++) {
+		scope_pipe_slot *s = &p->slot[i];
+		ok = hipMalloc((void **)&s->dev_rgb, round_up(p->pitch * cfg->height, 256)) == hipSuccess;
+		if (ok && p->vss_bytes)
+			ok = hipMalloc((void **)&s->dev_vss, p->vss_bytes) == hipSuccess;
+		if (ok && p->wvs_bytes)
+			ok = hipMalloc((void **)&s->dev_wvs, p->wvs_bytes) == hipSuccess;
+		if (ok && p->his_bytes)
+			ok = hipMalloc((void **)&s->dev_his, p->his_bytes) == hipSuccess;
+		if (ok)
+			ok = hipHostMalloc((void **)&s->host_tables, p->vss_bytes + p->wvs_bytes + p->his_bytes + 64, 0) ==
+			     hipSuccess;
+		ok = ok && hipEventCreate(&s->uploaded) == hipSuccess && hipEventCreate(&s->computed) == hipSuccess &&
+		     hipEventCreate(&s->downloaded) == hipSuccess;
+	}
+	if (!ok) {
+		scope_pipe_destroy(p);
+		return fail(ctx, SCOPE_ENOMEM, "pipeline allocation", hipSuccess);
+	}
+	*out = p;
+	return SCOPE_OK;
+}
+
+int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
+{
+	if (!p || !rgb_host)
+		return SCOPE_EINVAL;
+	scope_ctx *ctx = p->ctx;
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if ((uint64_t)p->cfg.width * 4 > linesize)
+		return fail(ctx, SCOPE_EINVAL, "linesize < 4*width", hipSuccess);
+	if (p->submitted - p->collected >= p->cfg.depth)
+		return SCOPE_EAGAIN;
+	scope_pipe_slot *s = &p->slot[p->submitted % p->cfg.depth];
+	const uint32_t w = p->cfg.width, h = p->cfg.height;
+	const uint32_t dev_flags = SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE | SCOPE_ASYNC;
+
+	/* upload stream: the RGB plane only -- half the bytes of the reference's RGB+YUV staging surface */
+	HIP_TRY(ctx, hipMemcpy2DAsync(s->dev_rgb, p->pitch, rgb_host, linesize, (size_t)w * 4, h, hipMemcpyHostToDevice, p->up));
+	HIP_TRY(ctx, hipEventRecord(s->uploaded, p->up));
+
+	/* compute stream: three reductions of the same HBM-resident plane, K0 fused where YUV is needed */
+	HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->uploaded, 0));
+	const uint8_t *plane[1] = {s->dev_rgb};
+	if (p->vss_bytes) {
+		st = run_vectorscope(ctx, plane, 1, (uint32_t)p->pitch, w, h, 1, p->cfg.colorspace, dev_flags, s->dev_vss);
+		if (st)
+			return st;
+	}
+	if (p->wvs_bytes) {
+		const uint32_t c = p->cfg.wvs_components;
+		st = run_waveform(ctx, plane, 1, (uint32_t)p->pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace,
+				  dev_flags, s->dev_wvs);
+		if (st)
+			return st;
+	}
+	if (p->his_bytes) {
+		const uint32_t c = p->cfg.his_components;
+		st = run_histogram(ctx, plane, 1, (uint32_t)p->pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace,
+				   dev_flags, s->dev_his);
+		if (st)
+			return st;
+	}
+	HIP_TRY(ctx, hipEventRecord(s->computed, ctx->stream));
+
+	/* download stream: the small tables into pinned memory */
+	HIP_TRY(ctx, hipStreamWaitEvent(p->down, s->computed, 0));
+	uint8_t *dst = s->host_tables;
+	if (p->vss_bytes)
+		HIP_TRY(ctx, hipMemcpyAsync(dst, s->dev_vss, p->vss_bytes, hipMemcpyDeviceToHost, p->down));
+	if (p->wvs_bytes)
+		HIP_TRY(ctx, hipMemcpyAsync(dst + p->vss_bytes, s->dev_wvs, p->wvs_bytes, hipMemcpyDeviceToHost, p->down));
+	if (p->his_bytes)
+		HIP_TRY(ctx, hipMemcpyAsync(dst + p->vss_bytes + p->wvs_bytes, s->dev_his, p->his_bytes, hipMemcpyDeviceToHost,
+					    p->down));
+	HIP_TRY(ctx, hipEventRecord(s->downloaded, p->down));
+	p->submitted++;
+	return SCOPE_OK;
+}
+
+int scope_pipe_collect(scope_pipe *p, const uint8_t **vectorscope, const uint8_t **waveform, const uint32_t **his_counts)
+{
+	if (!p)
+		return SCOPE_EINVAL;
+	scope_ctx *ctx = p->ctx;
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (p->submitted == p->collected)
+		return SCOPE_EAGAIN;
+	scope_pipe_slot *s = &p->slot[p->collected % p->cfg.depth];
+	HIP_TRY(ctx, hipEventSynchronize(s->downloaded));
+	if (vectorscope)
+		*vectorscope = p->vss_bytes ? s->host_tables : NULL;
+	if (waveform)
+		*waveform = p->wvs_bytes ? s->host_tables + p->vss_bytes : NULL;
+	if (his_counts)
+		*his_counts = p->his_bytes ? (const uint32_t *)(s->host_tables + p->vss_bytes + p->wvs_bytes) : NULL;
+	p->collected++;
 	return SCOPE_OK;
 }
 

@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libscope_hip.so")
 
-OK, EINVAL, ENOMEM, ENODEV, EIO, ENODATA = 0, -22, -12, -19, -5, -61
+OK, EINVAL, ENOMEM, ENODEV, EIO, ENODATA, EAGAIN = 0, -22, -12, -19, -5, -61, -11
 IN_DEVICE, OUT_DEVICE, ASYNC, FUSE_K0 = 0x1, 0x2, 0x4, 0x8
 COMP_RGB, COMP_Y, COMP_UV, COMP_YUV = 0x07, 0x20, 0x50, 0x70
 
@@ -33,6 +33,7 @@ ABI_SYMBOLS = (
     "scope_table_widen_u8_u32", "scope_table_clamp_u32_u8",
     "scope_table_pack_u8_u16x2", "scope_table_unpack_clamp_u16x2_u8",
     "scope_ctx_profile", "scope_ctx_kernel_ms",
+    "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect",
 )
 
 
@@ -60,6 +61,11 @@ class Batch(C.Structure):
         ("planes_are_rgb", C.c_int),
         ("colorspace", C.c_int),
     ]
+
+
+class PipeConfig(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_uint32), ("colorspace", C.c_int),
+                ("wvs_components", C.c_uint32), ("his_components", C.c_uint32), ("want_vectorscope", C.c_int)]
 
 
 class DeviceInfo(C.Structure):
@@ -113,6 +119,10 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_table_unpack_clamp_u16x2_u8": (i32, [vp, vp, vp, u64]),
         "scope_ctx_profile": (i32, [vp, i32]),
         "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
+        "scope_pipe_create": (i32, [vp, C.POINTER(PipeConfig), C.POINTER(vp)]),
+        "scope_pipe_destroy": (None, [vp]),
+        "scope_pipe_submit": (i32, [vp, vp, u32]),
+        "scope_pipe_collect": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
@@ -307,3 +317,40 @@ class ScopeContext:
         n, ms = C.c_uint32(), C.c_float()
         self._check(self.L.scope_ctx_kernel_ms(self.h, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
+
+
+class ScopePipe:
+    """scope_pipe: `depth` frames in flight over upload / compute / download streams."""
+
+    def __init__(self, ctx: ScopeContext, width, height, depth=3, colorspace=2, wvs_components=COMP_RGB,
+                 his_components=COMP_RGB, want_vectorscope=True):
+        self.ctx, self.w, self.h = ctx, width, height
+        self.cfg = PipeConfig(width, height, depth, colorspace, wvs_components, his_components, int(want_vectorscope))
+        h = C.c_void_p()
+        ctx._check(ctx.L.scope_pipe_create(ctx.h, C.byref(self.cfg), C.byref(h)))
+        self.h_pipe = h
+
+    def close(self):
+        if getattr(self, "h_pipe", None):
+            self.ctx.L.scope_pipe_destroy(self.h_pipe)
+            self.h_pipe = None
+
+    def submit(self, rgb_ptr: int, linesize: int) -> bool:
+        """False when the ring is full (collect first)."""
+        st = self.ctx._check(self.ctx.L.scope_pipe_submit(self.h_pipe, C.c_void_p(rgb_ptr), linesize), allow=(EAGAIN,))
+        return st == OK
+
+    def collect(self):
+        """(vectorscope, waveform, histogram counts) numpy views of the oldest frame, or None when empty."""
+        v, w, hh = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        st = self.ctx._check(self.ctx.L.scope_pipe_collect(self.h_pipe, C.byref(v), C.byref(w), C.byref(hh)), allow=(EAGAIN,))
+        if st != OK:
+            return None
+
+        def view(p, shape, dtype):
+            if not p.value:
+                return None
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_uint8 * n).from_address(p.value), dtype=dtype).reshape(shape)
+
+        return view(v, (256, 256), np.uint8), view(w, (256, self.w, 4), np.uint8), view(hh, (256, 4), np.uint32)

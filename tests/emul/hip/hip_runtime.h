@@ -89,6 +89,9 @@ hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
+hipError_t hipHostFree(void *p);
 hipError_t hipGetLastError(void);
 const char *hipGetErrorString(hipError_t e);
 

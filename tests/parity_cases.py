@@ -201,3 +201,32 @@ def check_device_path(ctx, oracle, to_dev, to_host, w, h, linesize, n=2, offset=
     for i in range(n):
         assert_same(got[i], oracle.histogram_counts(rgbs[i], None, w, 0x07), f"device histogram frame {i}")
     return hy, hr
+
+
+def check_pipeline(ctx, oracle, w, h, n_frames=7, depth=3, linesize=None):
+    """scope_pipe: frames in flight over three streams; every frame's three tables bit-exact, in order."""
+    import obs_color_monitor_amd as ocm
+
+    linesize = linesize or 4 * w
+    frames_ = [oracle.fill_frame(w, h, 1 + i % 5, 900 + i, linesize) for i in range(n_frames)]
+    pipe = ocm.ScopePipe(ctx, w, h, depth=depth, colorspace=2, wvs_components=0x07, his_components=0x70)
+    try:
+        assert pipe.collect() is None
+        done = 0
+
+        def check(i, got):
+            yuv = oracle.rgb_to_yuv(frames_[i], w, 2)
+            assert_same(got[0], oracle.vectorscope(yuv, w), f"pipe frame {i} vectorscope")
+            assert_same(got[1], oracle.waveform(frames_[i], yuv, w, 0x07), f"pipe frame {i} waveform")
+            assert_same(got[2], oracle.histogram_counts(frames_[i], yuv, w, 0x70), f"pipe frame {i} histogram")
+
+        for i, f in enumerate(frames_):
+            while not pipe.submit(f.ctypes.data, f.shape[1]):
+                check(done, pipe.collect())
+                done += 1
+        while done < n_frames:
+            check(done, pipe.collect())
+            done += 1
+        assert pipe.collect() is None
+    finally:
+        pipe.close()

@@ -122,3 +122,7 @@ def _np_dev(a):
 @pytest.mark.parametrize("w,h,ls,off", [(64, 12, 256, 0), (35, 7, 140, 0), (64, 12, 256, 4), (35, 7, 148, 8)])
 def test_device_path_and_unaligned_rows(emul_ctx, oracle, w, h, ls, off):
     pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, w, h, ls, n=2, offset=off)
+
+
+def test_frame_pipeline(emul_ctx, oracle):
+    pc.check_pipeline(emul_ctx, oracle, 70, 20, n_frames=5, depth=2, linesize=4 * 70 + 24)

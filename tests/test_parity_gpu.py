@@ -261,3 +261,9 @@ def test_properties_full_size(hip_ctx, oracle):
     wv, _ = hip_ctx.waveform(rgb=flat_rgb, yuv=flat_yuv, width=w, components=0x20)
     rows = np.nonzero(wv[..., 1].any(axis=1))[0]
     assert list(rows) == [255 - 204] and (wv[255 - 204, :, 1] == 255).all() and not wv[..., (0, 2, 3)].any()
+
+
+def test_frame_pipeline_streams(hip_ctx, oracle):
+    """BASELINE config 5 in miniature and at full size: frames in flight over upload/compute/download streams."""
+    pc.check_pipeline(hip_ctx, oracle, 640, 360, n_frames=9, depth=3)
+    pc.check_pipeline(hip_ctx, oracle, 3840, 2160, n_frames=5, depth=3)

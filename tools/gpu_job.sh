@@ -33,6 +33,7 @@ for s in $stages; do
                 python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --settle-seconds 0.2 --no-cpu $BENCH_EXTRA) > $out/pmc_$c.log 2>&1
            done; rc=$?
            python tools/pmc_summary.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_traffic.txt 2>&1; cat $out/pmc_traffic.txt ;;
+    stream) (timeout 600 python tools/stream_bench.py > $out/stream_max.json 2> $out/stream.err; timeout 600 python tools/stream_bench.py --target-fps 240 --frames 720 > $out/stream_240.json 2>> $out/stream.err); rc=$?; cat $out/stream_max.json $out/stream_240.json; tail -3 $out/stream.err ;;
     trace) (python tools/lds_trace_gen.py /tmp/lds_traces.bin 2> $out/lds_trace_model.txt && timeout 300 ./tools/lds_trace_bench /tmp/lds_traces.bin > $out/lds_trace.txt 2>&1); rc=$?; paste -d'|' $out/lds_trace_model.txt $out/lds_trace.txt | cut -c1-200 > $out/lds_trace_both.txt ;;
     *) echo "unknown stage $s"; rc=99 ;;
   esac
