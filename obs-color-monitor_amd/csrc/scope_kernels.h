@@ -41,11 +41,11 @@ struct ScopeK0 {
 /* Tunables the host may flip for A/B runs (scope_ctx_set_option). */
 struct ScopeTuning {
 	int vss_merge;       /* 0 none, 1 lane-local run merge, 2 = 1 + wave-uniform shortcut, 3 adaptive */
-	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 2 or 4 */
+	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 4 or 8 */
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3 */
 	int his_unroll;      /* 2 or 4 */
-	int wvs_unroll;      /* rows per lane per batch: 4 or 8 */
+	int wvs_unroll;      /* rows per lane per batch (two batches in flight): 4 or 8 */
 	int nt_loads;        /* 1: non-temporal pixel loads */
 };
 

@@ -851,9 +851,7 @@ template <int U, bool NT> hipError_t vss_pick_merge(int merge, int fuse, int has
 {
 	if (merge <= 0)
 		return vss_pick_fuse<U, NT, 0>(fuse, hash, a);
-	if (merge == 1)
-		return vss_pick_fuse<U, NT, 1>(fuse, hash, a);
-	if (merge == 2)
+	if (merge <= 2) /* MERGE 1 (fold without the one-bin shortcut) is not built: 2 covers it */
 		return vss_pick_fuse<U, NT, 2>(fuse, hash, a);
 	return vss_pick_fuse<U, NT, 3>(fuse, hash, a);
 }
@@ -865,8 +863,6 @@ hipError_t vss_pick(int unroll, int nt, int merge, int fuse, int hash, const Vss
 {
 	if (merge >= 3 && unroll > 4)
 		unroll = 4; /* the adaptive variant keeps a whole batch of bin indices live: 8 cells would spill */
-	if (unroll <= 2)
-		return vss_pick_nt<2>(nt, merge, fuse, hash, a);
 	if (unroll <= 4)
 		return vss_pick_nt<4>(nt, merge, fuse, hash, a);
 	return vss_pick_nt<8>(nt, merge, fuse, hash, a);
@@ -902,9 +898,7 @@ hipError_t his_pick(int unroll, int nt, int fuse, const HisArgs *a)
 {
 	if (unroll <= 2)
 		return his_pick_nt<2>(nt, fuse, a);
-	if (unroll <= 4)
-		return his_pick_nt<4>(nt, fuse, a);
-	return his_pick_nt<8>(nt, fuse, a);
+	return his_pick_nt<4>(nt, fuse, a);
 }
 
 struct WvsArgs {
@@ -936,9 +930,7 @@ hipError_t wvs_pick(int unroll, int nt, int fuse, const WvsArgs *a)
 {
 	if (unroll <= 4)
 		return wvs_pick_nt<4>(nt, fuse, a);
-	if (unroll <= 8)
-		return wvs_pick_nt<8>(nt, fuse, a);
-	return wvs_pick_nt<16>(nt, fuse, a);
+	return wvs_pick_nt<8>(nt, fuse, a);
 }
 
 } // namespace

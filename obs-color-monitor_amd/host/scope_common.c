@@ -183,16 +183,34 @@ bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t
 	const int w = src->i_write_queue; /* the consumer never takes slot i_write_queue */
 	pthread_mutex_unlock(&src->pipeline_mutex);
 
+	/* src/common.c:272-282: the ROI rectangle, when valid, selects the sub-rectangle that is staged */
+	uint32_t x = 0, y = 0, cx = width, cy = height;
+	if ((src->flags & CM_FLAG_ROI) && 0 <= src->x0 && src->x0 < src->x1 && 0 <= src->y0 && src->y0 < src->y1 &&
+	    (uint32_t)src->x1 <= width && (uint32_t)src->y1 <= height) {
+		x = (uint32_t)src->x0;
+		y = (uint32_t)src->y0;
+		cx = (uint32_t)src->x1 - x;
+		cy = (uint32_t)src->y1 - y;
+	}
 	struct cm_surface_queue_item *item = &src->queue[w];
-	const uint32_t sheight = height * ((has_rgb ? 1u : 0u) + (has_yuv ? 1u : 0u)); /* :284-291 */
-	const size_t bytes = (size_t)linesize * sheight;
+	const uint32_t planes = (has_rgb ? 1u : 0u) + (has_yuv ? 1u : 0u);
+	const uint32_t sheight = cy * planes; /* :284-291 */
+	const uint32_t out_linesize = cx * 4;
+	const size_t bytes = (size_t)out_linesize * sheight;
 	if (item->capacity < bytes) {
 		bfree(item->video_data);
 		item->video_data = bzalloc(bytes);
 		item->capacity = item->video_data ? bytes : 0;
 	}
-	if (item->video_data)
-		memcpy(item->video_data, video_data, bytes); /* gs_stage_texture stand-in */
+	if (item->video_data) { /* gs_draw_sprite_subregion + gs_stage_texture stand-in */
+		for (uint32_t p = 0; p < planes; p++)
+			for (uint32_t r = 0; r < cy; r++)
+				memcpy(item->video_data + ((size_t)p * cy + r) * out_linesize,
+				       video_data + ((size_t)p * height + y + r) * linesize + (size_t)x * 4, out_linesize);
+	}
+	linesize = out_linesize;
+	width = cx;
+	height = cy;
 	item->linesize = linesize;
 	item->width = width;
 	item->height = height;

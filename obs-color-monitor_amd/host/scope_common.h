@@ -69,6 +69,7 @@ struct cm_source {
 	void *callback_data;
 
 	struct roi_source *roi;
+	int x0, x1, y0, y1; /* ROI rectangle in capture pixels (src/common.h:62); used when CM_FLAG_ROI */
 
 	int target_scale;
 	int colorspace;
@@ -86,8 +87,10 @@ void cm_request(struct cm_source *src, cm_surface_cb_t callback, void *data);   
 void cm_tick(void *data, float unused);                                            /* src/common.c:575-595 */
 
 /* Producer half of cm_render_target (src/common.c:223-333) for a host that already holds the
- * stacked surface: copies it into the next ring slot and wakes the pipeline thread.  Returns false
- * when the consumer is a full ring behind and the frame was dropped (src/common.c:260-268). */
+ * captured planes stacked vertically (RGB rows, then YUV rows, `height` rows each): stages them
+ * into the next ring slot -- cropped to the ROI rectangle when CM_FLAG_ROI is set and the rectangle
+ * is valid (src/common.c:272-282) -- and wakes the pipeline thread.  Returns false when the
+ * consumer is a full ring behind and the frame was dropped (src/common.c:260-268). */
 bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
 		      uint32_t height);
 /* Blocks until every staged surface has been through the callback (test/bench helper). */

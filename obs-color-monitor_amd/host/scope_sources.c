@@ -322,6 +322,36 @@ static void roi_update(void *data, obs_data_t *settings)
 {
 	struct roi_source *src = data;
 	cm_update(&src->cm, settings);
+	src->n_interleave = (int)obs_data_get_int(settings, "interleave"); /* src/roi.c:108 */
+	/* the rectangle arrives through mouse interaction in the plugin (src/roi.c:343-521); a host sets it here */
+	src->cm.x0 = (int)obs_data_get_int(settings, "roi_x0");
+	src->cm.y0 = (int)obs_data_get_int(settings, "roi_y0");
+	src->cm.x1 = (int)obs_data_get_int(settings, "roi_x1");
+	src->cm.y1 = (int)obs_data_get_int(settings, "roi_y1");
+}
+
+static void roi_get_defaults(obs_data_t *settings)
+{
+	cm_get_defaults(settings);
+	obs_data_set_default_int(settings, "interleave", 1); /* src/roi.c:99 */
+	obs_data_set_default_int(settings, "roi_x0", -1);    /* no rectangle: the whole capture */
+	obs_data_set_default_int(settings, "roi_y0", -1);
+	obs_data_set_default_int(settings, "roi_x1", -1);
+	obs_data_set_default_int(settings, "roi_y1", -1);
+}
+
+bool roi_target_render(struct roi_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
+		       uint32_t height)
+{
+	src->interleave_rendered = true;
+	if (src->i_interleave != 0 && src->n_interleave > 0)
+		return true; /* this frame is skipped */
+
+	cm_stage_surface(&src->cm, video_data, linesize, width, height);
+
+	if (src->n_interleave <= 0)
+		return true;
+	return false;
 }
 
 static void *roi_create(obs_data_t *settings, obs_source_t *source)
@@ -393,8 +423,16 @@ void roi_surface_cb(void *data, struct cm_surface_data *surface_data)
 static void roi_tick(void *data, float unused)
 {
 	struct roi_source *src = data;
+
+	/* src/roi.c:523-532 */
+	if (src->interleave_rendered && src->i_interleave++ >= src->n_interleave)
+		src->i_interleave = 0;
+	src->interleave_rendered = false;
+
+	if (src->i_interleave == 0 || src->n_interleave <= 0)
+		cm_tick(&src->cm, unused);
+
 	roi_update_flags(src);
-	cm_tick(&src->cm, unused);
 }
 
 static uint32_t roi_get_size(void *data)
@@ -411,7 +449,7 @@ const struct obs_source_info colormonitor_roi = {
 	.create = roi_create,
 	.destroy = roi_destroy,
 	.update = roi_update,
-	.get_defaults = cm_get_defaults,
+	.get_defaults = roi_get_defaults,
 	.get_width = roi_get_size,
 	.get_height = roi_get_size,
 	.video_render = scope_render_nothing,

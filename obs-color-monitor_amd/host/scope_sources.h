@@ -49,6 +49,8 @@ struct his_source {
 #define ROI_MAX_SOURCES 16
 struct roi_source {
 	struct cm_source cm;
+	int n_interleave, i_interleave; /* src/roi.h:13-14: process one frame in n_interleave + 1 */
+	bool interleave_rendered;
 	pthread_mutex_t sources_mutex;
 	struct cm_source *sources[ROI_MAX_SOURCES]; /* DARRAY(struct cm_source *) in the reference */
 	size_t n_sources;
@@ -68,6 +70,10 @@ void roi_surface_cb(void *data, struct cm_surface_data *surface_data); /* src/ro
 void roi_register_source(struct roi_source *src, struct cm_source *cm);   /* src/roi.c:315-320 */
 void roi_unregister_source(struct roi_source *src, struct cm_source *cm); /* src/roi.c:322-327 */
 void roi_update_flags(struct roi_source *src);                            /* flag merge of roi_tick, src/roi.c:534-540 */
+/* src/roi.c:266-277 with the host's captured planes in place of the OBS render: stages the frame
+ * unless this tick is skipped by interleaving.  Returns what the reference returns. */
+bool roi_target_render(struct roi_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
+		       uint32_t height);
 
 bool obs_module_load(void); /* src/plugin-main.c:58-108, the four sources of this path */
 void obs_module_unload(void);

@@ -40,6 +40,8 @@ class Host:
         L.cm_drain.argtypes = [C.c_void_p]
         L.roi_register_source.argtypes = [C.c_void_p, C.c_void_p]
         L.roi_unregister_source.argtypes = [C.c_void_p, C.c_void_p]
+        L.roi_target_render.restype = C.c_bool
+        L.roi_target_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.scope_host_vss_table.restype = C.POINTER(C.c_uint8)
         L.scope_host_vss_table.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.scope_host_wvs_table.restype = C.POINTER(C.c_uint8)
@@ -152,4 +154,32 @@ def run_host_checks(host, oracle, w=96, h=40):
     for obj in (vss, wvs, his):
         host.L.roi_unregister_source(roi, host.L.scope_host_cm(obj))
     for info_, obj in ((vinfo, vss), (winfo, wvs), (hinfo, his), (roi_info, roi)):
+        info_.destroy(obj)
+
+    # -- ROI rectangle (crop, common.c:272-282) and interleave (roi.c:266-277,523-532) --------------------
+    x0, y0, x1, y1 = 8, 4, 8 + 50, 4 + 23  # an odd-sized sub-rectangle: ragged width, arbitrary pitch
+    roi_info, roi = host.create("colormonitor_roi", interleave=1, roi_x0=x0, roi_y0=y0, roi_x1=x1, roi_y1=y1)
+    vinfo, vss = host.create("vectorscope_source")
+    winfo, wvs = host.create("waveform_source", components=0x07)
+    for obj in (vss, wvs):
+        host.L.roi_register_source(roi, host.L.scope_host_cm(obj))
+        (vinfo if obj == vss else winfo).video_tick(obj, 0.0)
+    staged = []
+    for t in range(6):  # interleave = 1: every second frame is captured (doc/dock.md:58-65)
+        rgb, yuv = frames[t % 3]
+        roi_info.video_tick(roi, 0.0)
+        stacked = np.ascontiguousarray(np.concatenate([rgb, yuv]))
+        skipped = host.L.roi_target_render(roi, stacked.ctypes.data_as(C.c_void_p), stacked.shape[1], w, h)
+        staged.append(not skipped)
+        if not skipped:
+            host.drain(roi)
+            crop_rgb = np.ascontiguousarray(rgb[y0:y1, 4 * x0:4 * x1])
+            crop_yuv = np.ascontiguousarray(yuv[y0:y1, 4 * x0:4 * x1])
+            assert np.array_equal(host.vss_table(vss)[0], oracle.vectorscope(crop_yuv, x1 - x0))
+            assert np.array_equal(host.wvs_table(wvs), oracle.waveform(crop_rgb, crop_yuv, x1 - x0, 0x07))
+    assert staged == [True, False, True, False, True, False]
+    assert host.L.scope_host_frames_processed(roi) == 3
+    for obj in (vss, wvs):
+        host.L.roi_unregister_source(roi, host.L.scope_host_cm(obj))
+    for info_, obj in ((vinfo, vss), (winfo, wvs), (roi_info, roi)):
         info_.destroy(obj)
