@@ -150,6 +150,30 @@ int scope_waveform_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t c
 int scope_histogram_counts_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
 				 uint32_t *counts);
 
+/* ---- D1-D3: display post-passes (tables -> scope picture) -------------------------------------
+ * The reference's display pixel shaders as output-sized GPU passes; out = RGBA8 bytes R,G,B,A,
+ * row-major.  `display`: 0 overlay, 1 stack, 2 parade (DISP_*, src/waveform.c:22-24).  Tables and
+ * pictures are both host or both device (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE together).
+ * The reference leaves the final FLOAT->UNORM8 rounding to the GPU OBS runs on; here it is pinned
+ * to floor(clamp01(x)*255+0.5), like K0. */
+
+/* data/vectorscope.effect:27-33 + src/vectorscope.c:414-439 (zoom 1).  color_type: 0 white, 1 UV
+ * colouring (BT.601 constants when colorspace == 1).  rgba = 256*256*4 bytes. */
+int scope_display_vectorscope(scope_ctx *ctx, const uint8_t *table, int intensity, int color_type, int colorspace,
+			      uint32_t flags, uint8_t *rgba);
+/* data/waveform.effect:30-83 + src/waveform.c:334-360.  table = uint8[256][width][4];
+ * rgba = out_w*out_h*4 bytes with the sizes scope_display_size(width, 256, ...) returns. */
+int scope_display_waveform(scope_ctx *ctx, const uint8_t *table, uint32_t width, uint32_t components, int display,
+			   int intensity, uint32_t flags, uint8_t *rgba);
+/* data/histogram.effect:30-85 + src/histogram.c:522-548.  tex = float[256][4] (after K3b), hi_max = uint32[3];
+ * sizes: scope_display_size(256, level_height, ...). */
+int scope_display_histogram(scope_ctx *ctx, const float *tex, const uint32_t *hi_max, uint32_t components, int display,
+			    uint32_t level_height, uint32_t flags, uint8_t *rgba);
+/* get_width/get_height of the sources: width x n for parade, height x n for stack
+ * (src/waveform.c:181-199, src/histogram.c:304-322). */
+void scope_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, int display, uint32_t *out_w,
+			uint32_t *out_h);
+
 /* ---- frame pipeline: the staging ring moved into HBM ----------------------------------------
  * Replaces the reference's 3-slot staging ring + pipeline thread (CM_SURFACE_QUEUE_SIZE,
  * src/common.h:46; cm_render_target / cm_pipeline_thread, src/common.c:223-403) for a host that

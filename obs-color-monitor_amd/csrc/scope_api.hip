@@ -343,6 +343,48 @@ int enter(scope_ctx *ctx)
 	return SCOPE_OK;
 }
 
+uint32_t display_n_components(uint32_t components)
+{
+	/* n_components(), src/waveform.c:172-179 */
+	uint32_t n = 0;
+	for (uint32_t c = components & 0x77u; c; c >>= 1)
+		n += c & 1u;
+	return n;
+}
+
+/* shared plumbing: table in (host or device) -> kernel -> picture out (host or device) */
+template <typename Launch>
+int display_run(scope_ctx *ctx, const void *table, size_t table_bytes, uint8_t *rgba, size_t out_bytes,
+		       uint32_t flags, Launch launch)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!table || !rgba)
+		return fail(ctx, SCOPE_EINVAL, "NULL argument", hipSuccess);
+	const uint32_t dev = flags & (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE);
+	if (dev != 0 && dev != (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE))
+		return fail(ctx, SCOPE_EINVAL, "display passes take host or device buffers, not a mix", hipSuccess);
+	if (out_bytes == 0)
+		return SCOPE_OK;
+	if (dev) {
+		HIP_TRY(ctx, launch((const uint8_t *)table, rgba));
+		if (!(flags & SCOPE_ASYNC))
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return SCOPE_OK;
+	}
+	st = grow(ctx, &ctx->stage_in, &ctx->stage_in_bytes, round_up(table_bytes, 256));
+	if (!st)
+		st = grow(ctx, &ctx->stage_out, &ctx->stage_out_bytes, round_up(out_bytes, 256));
+	if (st)
+		return st;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in, table, table_bytes, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, launch(ctx->stage_in, ctx->stage_out));
+	HIP_TRY(ctx, hipMemcpyAsync(rgba, ctx->stage_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SCOPE_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -807,6 +849,64 @@ int scope_ctx_kernel_ms(scope_ctx *ctx, uint32_t *launches, float *total_ms)
 	*launches = n;
 	*total_ms = sum;
 	return SCOPE_OK;
+}
+
+/* ---- D1-D3 display post-passes ------------------------------------------------------------------ */
+
+void scope_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, int display, uint32_t *out_w,
+			uint32_t *out_h)
+{
+	const uint32_t n = display_n_components(components);
+	if (out_w)
+		*out_w = display == 2 ? base_w * n : base_w;
+	if (out_h)
+		*out_h = display == 1 ? base_h * n : base_h;
+}
+
+int scope_display_vectorscope(scope_ctx *ctx, const uint8_t *table, int intensity, int color_type, int colorspace,
+			      uint32_t flags, uint8_t *rgba)
+{
+	if (!ctx)
+		return SCOPE_EINVAL;
+	if (intensity < 1)
+		intensity = 1; /* src/vectorscope.c:129-131 */
+	return display_run(ctx, table, SCOPE_VSS_BINS, rgba, SCOPE_VSS_BINS * 4, flags, [&](const uint8_t *t, uint8_t *o) {
+		return scope_launch_display_vss(t, o, intensity, color_type, colorspace, ctx->stream);
+	});
+}
+
+int scope_display_waveform(scope_ctx *ctx, const uint8_t *table, uint32_t width, uint32_t components, int display,
+			   int intensity, uint32_t flags, uint8_t *rgba)
+{
+	if (!ctx)
+		return SCOPE_EINVAL;
+	if (width == 0 || (uint64_t)width * 256 * 3 >= (1ull << 30))
+		return fail(ctx, SCOPE_EINVAL, "bad waveform width", hipSuccess);
+	uint32_t ow, oh;
+	scope_display_size(width, SCOPE_WV_SIZE, components, display, &ow, &oh);
+	const uint32_t n = display_n_components(components);
+	return display_run(ctx, table, (size_t)SCOPE_WV_SIZE * width * 4, rgba, (size_t)ow * oh * 4, flags,
+			   [&](const uint8_t *t, uint8_t *o) {
+				   return scope_launch_display_wvs(t, o, width, n, display, intensity, ow, oh, ctx->stream);
+			   });
+}
+
+int scope_display_histogram(scope_ctx *ctx, const float *tex, const uint32_t *hi_max, uint32_t components, int display,
+			    uint32_t level_height, uint32_t flags, uint8_t *rgba)
+{
+	if (!ctx)
+		return SCOPE_EINVAL;
+	if (!hi_max || level_height == 0 || level_height > 65536)
+		return fail(ctx, SCOPE_EINVAL, "bad histogram display arguments", hipSuccess);
+	uint32_t ow, oh;
+	scope_display_size(SCOPE_HI_SIZE, level_height, components, display, &ow, &oh);
+	const uint32_t n = display_n_components(components);
+	/* his_set_image: the maxima travel as floats (src/histogram.c:428-429) */
+	const float hm0 = (float)hi_max[0], hm1 = (float)hi_max[1], hm2 = (float)hi_max[2];
+	return display_run(ctx, tex, SCOPE_HIS_WORDS * sizeof(float), rgba, (size_t)ow * oh * 4, flags,
+			   [&](const uint8_t *t, uint8_t *o) {
+				   return scope_launch_display_his((const float *)t, o, hm0, hm1, hm2, n, display, ow, oh, ctx->stream);
+			   });
 }
 
 /* ---- frame pipeline ---------------------------------------------------------------------------- */

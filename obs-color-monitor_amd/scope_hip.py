@@ -34,6 +34,7 @@ ABI_SYMBOLS = (
     "scope_table_pack_u8_u16x2", "scope_table_unpack_clamp_u16x2_u8",
     "scope_ctx_profile", "scope_ctx_kernel_ms",
     "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect",
+    "scope_display_vectorscope", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
 )
 
 
@@ -119,6 +120,10 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_table_unpack_clamp_u16x2_u8": (i32, [vp, vp, vp, u64]),
         "scope_ctx_profile": (i32, [vp, i32]),
         "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
+        "scope_display_vectorscope": (i32, [vp, vp, i32, i32, i32, u32, vp]),
+        "scope_display_waveform": (i32, [vp, vp, u32, u32, i32, i32, u32, vp]),
+        "scope_display_histogram": (i32, [vp, vp, vp, u32, i32, u32, u32, vp]),
+        "scope_display_size": (None, [u32, u32, u32, i32, C.POINTER(u32), C.POINTER(u32)]),
         "scope_pipe_create": (i32, [vp, C.POINTER(PipeConfig), C.POINTER(vp)]),
         "scope_pipe_destroy": (None, [vp]),
         "scope_pipe_submit": (i32, [vp, vp, u32]),
@@ -302,6 +307,35 @@ class ScopeContext:
 
     def clamp_dev(self, in_dev, out_dev, n):
         self._check(self.L.scope_table_clamp_u32_u8(self.h, _dptr(in_dev), _dptr(out_dev), n))
+
+    # -- display post-passes (host tables in, host RGBA pictures out) --------------------------------
+    def display_size(self, base_w, base_h, components, display):
+        ow, oh = C.c_uint32(), C.c_uint32()
+        self.L.scope_display_size(base_w, base_h, components, display, C.byref(ow), C.byref(oh))
+        return int(ow.value), int(oh.value)
+
+    def display_vectorscope(self, table, intensity=25, color_type=1, colorspace=2):
+        out = np.full((256, 256, 4), 0xEE, dtype=np.uint8)
+        t = np.ascontiguousarray(table, dtype=np.uint8)
+        self._check(self.L.scope_display_vectorscope(self.h, _hptr(t), intensity, color_type, colorspace, 0, _hptr(out)))
+        return out
+
+    def display_waveform(self, table, components, display, intensity=25):
+        t = np.ascontiguousarray(table, dtype=np.uint8)
+        w = t.shape[1]
+        ow, oh = self.display_size(w, 256, components, display)
+        out = np.full((oh, ow, 4), 0xEE, dtype=np.uint8)
+        self._check(self.L.scope_display_waveform(self.h, _hptr(t), w, components, display, intensity, 0, _hptr(out)))
+        return out
+
+    def display_histogram(self, tex, hi_max, components, display, level_height=200):
+        t = np.ascontiguousarray(tex, dtype=np.float32)
+        hi = np.ascontiguousarray(hi_max, dtype=np.uint32)
+        ow, oh = self.display_size(256, level_height, components, display)
+        out = np.full((oh, ow, 4), 0xEE, dtype=np.uint8)
+        self._check(self.L.scope_display_histogram(self.h, t.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
+                                                   components, display, level_height, 0, _hptr(out)))
+        return out
 
     def pack16_dev(self, in_dev, out_dev, n_pairs):
         self._check(self.L.scope_table_pack_u8_u16x2(self.h, _dptr(in_dev), _dptr(out_dev), n_pairs))

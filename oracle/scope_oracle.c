@@ -241,6 +241,164 @@ void oracle_histogram(uint8_t *tex_buf, uint32_t *hi_max, const struct oracle_su
 			       level_ratio_value);
 }
 
+/* ------------------------------------------------------------ D1-D3 ---- */
+
+static const float disp_color[3][3] = {
+	/* rows of the effects' `color` matrix: data/waveform.effect:4-9, data/histogram.effect:4-9 */
+	{1.00f, 0.41f, 0.41f},
+	{0.00f, 1.00f, 0.00f},
+	{0.53f, 0.53f, 1.00f},
+};
+
+/* n_components(): population count of the plane bits, src/waveform.c:172-179, src/histogram.c:295-302 */
+static uint32_t disp_n_components(uint32_t components)
+{
+	uint32_t n = 0;
+	for (uint32_t c = components & 0x77u; c; c >>= 1)
+		n += c & 1u;
+	return n;
+}
+
+void oracle_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, int display, uint32_t *out_w,
+			 uint32_t *out_h)
+{
+	const uint32_t n = disp_n_components(components);
+	*out_w = display == 2 ? base_w * n : base_w; /* src/waveform.c:349-351, histogram.c:537-539 */
+	*out_h = display == 1 ? base_h * n : base_h; /* src/waveform.c:345-347, histogram.c:533-535 */
+}
+
+/* Which pixel shader runs and where it samples: the technique names of waveform.c:343-356. */
+struct disp_pick {
+	int overlay; /* DrawOverlay: all three channels at once */
+	int chan;    /* otherwise: channel index i into the sampled texel / colour row */
+	float u, v;  /* texture coordinate the shader samples at */
+	float level; /* histogram only: the coordinate the threshold uses (uv.y or its per-band fraction) */
+};
+
+static struct disp_pick disp_select(float uvx, float uvy, uint32_t n, int display)
+{
+	struct disp_pick p = {1, 0, uvx, uvy, uvy};
+	if (display == 1 && n == 3) { /* PSDrawStack */
+		p.overlay = 0;
+		p.chan = (int)(uvy * 3);
+		p.v = uvy * 3 - (float)p.chan;
+		p.level = p.v;
+	} else if (display == 1 && n == 2) { /* PSDrawStackUV */
+		p.overlay = 0;
+		p.chan = uvy < 0.5f ? 0 : 2;
+		p.v = uvy * 2;
+		p.level = uvy < 0.5f ? uvy * 2 : uvy * 2 - 1;
+	} else if (display == 2 && n == 3) { /* PSDrawParade */
+		p.overlay = 0;
+		p.chan = (int)(uvx * 3);
+		p.u = uvx * 3 - (float)p.chan;
+	} else if (display == 2 && n == 2) { /* PSDrawParadeUV */
+		p.overlay = 0;
+		p.chan = uvx < 0.5f ? 0 : 2;
+		p.u = uvx * 2;
+	}
+	return p;
+}
+
+/* Point sampling with Repeat addressing: texel index of coordinate t on an axis of `size` texels. */
+static uint32_t disp_texel(float t, uint32_t size)
+{
+	const float w = t - floorf(t);
+	uint32_t i = (uint32_t)floorf(w * (float)size);
+	return i >= size ? size - 1 : i;
+}
+
+void oracle_display_vectorscope(uint8_t *out, const uint8_t *table, int intensity, int color_type, int colorspace)
+{
+	/* src/vectorscope.c:418-439 */
+	float color[4] = {1.0f, 1.0f, 1.0f, 1.0f}, cu[3] = {0, 0, 0}, cv[3] = {0, 0, 0};
+	if (color_type == 1) {
+		color[0] = color[1] = color[2] = 0.5f;
+		if (colorspace == 1) {
+			cu[1] = -0.3441f, cu[2] = +1.772f;
+			cv[0] = +1.402f, cv[1] = -0.7141f;
+		} else {
+			cu[1] = -0.1873f, cu[2] = +1.8556f;
+			cv[0] = +1.5748f, cv[1] = -0.4681f;
+		}
+	}
+	for (uint32_t py = 0; py < 256; py++) {
+		for (uint32_t px = 0; px < 256; px++) {
+			const float uvx = ((float)px + 0.5f) / 256.0f, uvy = ((float)py + 0.5f) / 256.0f;
+			const float s = uvx * 2.0f - 1.0f, t = 1.0f - uvy * 2.0f;
+			float r = ((float)table[py * 256 + px] / 255.0f) * (float)intensity;
+			if (r > 1.0f)
+				r = 1.0f;
+			uint8_t *o = out + ((size_t)py * 256 + px) * 4;
+			for (int c = 0; c < 3; c++) {
+				float rgb = color[c] + cu[c] * s;
+				rgb = rgb + cv[c] * t;
+				o[c] = k0_quantise(rgb * r);
+			}
+			o[3] = k0_quantise(color[3]);
+		}
+	}
+}
+
+void oracle_display_waveform(uint8_t *out, const uint8_t *table, uint32_t width, uint32_t components, int display,
+			     int intensity)
+{
+	uint32_t ow, oh;
+	oracle_display_size(width, 256, components, display, &ow, &oh);
+	const uint32_t n = disp_n_components(components);
+	for (uint32_t py = 0; py < oh; py++) {
+		for (uint32_t px = 0; px < ow; px++) {
+			const float uvx = ((float)px + 0.5f) / (float)ow, uvy = ((float)py + 0.5f) / (float)oh;
+			const struct disp_pick p = disp_select(uvx, uvy, n, display);
+			const uint8_t *texel = table + ((size_t)disp_texel(p.v, 256) * width + disp_texel(p.u, width)) * 4;
+			uint8_t *o = out + ((size_t)py * ow + px) * 4;
+			/* a GS_BGRX texel samples as x = R = byte 2, y = G = byte 1, z = B = byte 0 */
+			if (p.overlay) {
+				for (int c = 0; c < 3; c++) {
+					float r = ((float)texel[2 - c] / 255.0f) * (float)intensity;
+					if (r > 1.0f)
+						r = 1.0f;
+					o[c] = k0_quantise(r);
+				}
+			} else {
+				float r = ((float)texel[2 - p.chan] / 255.0f) * (float)intensity;
+				if (r > 1.0f)
+					r = 1.0f;
+				for (int c = 0; c < 3; c++)
+					o[c] = k0_quantise(disp_color[p.chan][c] * r);
+			}
+			o[3] = 255;
+		}
+	}
+}
+
+void oracle_display_histogram(uint8_t *out, const float *tex, const uint32_t *hi_max, uint32_t components, int display,
+			      uint32_t level_height)
+{
+	uint32_t ow, oh;
+	oracle_display_size(256, level_height, components, display, &ow, &oh);
+	const uint32_t n = disp_n_components(components);
+	const float hm[3] = {(float)hi_max[0], (float)hi_max[1], (float)hi_max[2]}; /* his_set_image, histogram.c:428-429 */
+	for (uint32_t py = 0; py < oh; py++) {
+		for (uint32_t px = 0; px < ow; px++) {
+			const float uvx = ((float)px + 0.5f) / (float)ow, uvy = ((float)py + 0.5f) / (float)oh;
+			const struct disp_pick p = disp_select(uvx, uvy, n, display);
+			/* the histogram parade samples at uv.x*3 (uv.x*2) without subtracting i: Repeat wraps it */
+			const float *texel = tex + (size_t)disp_texel(p.u, 256) * 4;
+			uint8_t *o = out + ((size_t)py * ow + px) * 4;
+			if (p.overlay) {
+				for (int c = 0; c < 3; c++)
+					o[c] = texel[c] >= (1 - uvy) * hm[c] ? 255 : 0;
+			} else {
+				const float r = texel[p.chan] >= (1 - p.level) * hm[p.chan] ? 1.0f : 0.0f;
+				for (int c = 0; c < 3; c++)
+					o[c] = k0_quantise(disp_color[p.chan][c] * r);
+			}
+			o[3] = 255;
+		}
+	}
+}
+
 /* ------------------------------------------------------- test inputs ---- */
 
 static inline uint64_t xorshift64(uint64_t *s)

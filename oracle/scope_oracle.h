@@ -65,6 +65,28 @@ void oracle_histogram(uint8_t *tex_buf, uint32_t *hi_max, const struct oracle_su
 void oracle_histogram_level(uint8_t *tex_buf, uint32_t *hi_max, uint32_t width, uint32_t height, uint32_t components,
 			    int logscale, int level_fixed_value, int level_ratio_value);
 
+/* D1-D3: the display pixel shaders that turn the tables into the scope picture.
+ * fp32, operations in the shaders' order, texel centres at (x+0.5)/size, point sampling, and the
+ * FLOAT->UNORM8 store pinned like K0 (the reference leaves it to the GPU: parity unpinned).
+ * Output: RGBA8 bytes R,G,B,A, row-major.  display: 0 overlay, 1 stack, 2 parade. */
+
+/* data/vectorscope.effect:27-33 with the uniforms of src/vectorscope.c:414-439.
+ * color_type 0 = white, 1 = UV colouring (601 constants when colorspace == 1).  out = 256*256*4 bytes. */
+void oracle_display_vectorscope(uint8_t *out, const uint8_t *table, int intensity, int color_type, int colorspace);
+
+/* data/waveform.effect:30-83 with the technique choice of src/waveform.c:334-360.
+ * table = uint8[256][width][4].  Output size via oracle_display_size(). */
+void oracle_display_waveform(uint8_t *out, const uint8_t *table, uint32_t width, uint32_t components, int display,
+			     int intensity);
+
+/* data/histogram.effect:30-85 with src/histogram.c:522-548.  tex = float[256][4], hi_max = uint32[3]. */
+void oracle_display_histogram(uint8_t *out, const float *tex, const uint32_t *hi_max, uint32_t components, int display,
+			      uint32_t level_height);
+
+/* Output width/height of D2 (base_w = frame width, base_h = 256) and D3 (base_w = 256, base_h = level_height). */
+void oracle_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, int display, uint32_t *out_w,
+			 uint32_t *out_h);
+
 /* Deterministic frame generator shared by tests and bench (xorshift64).
  * dist: 1 uniform, 2 concentrated (128 + U{-8..7}), 3 flat (R,G,B)=(0xC6,0xCC,0xD7),
  *       4 eight vertical colour bars, 5 uniform with alpha==0 on a 16x16 checker.

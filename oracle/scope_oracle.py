@@ -60,6 +60,10 @@ class COracle:
         L.oracle_histogram_counts.restype = C.c_int
         L.oracle_histogram.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Surface), C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.oracle_histogram_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]
+        L.oracle_display_vectorscope.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oracle_display_waveform.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+        L.oracle_display_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
+        L.oracle_display_size.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.oracle_fill_frame.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64]
         L.oracle_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         L.oracle_fnv1a64.restype = C.c_uint64
@@ -120,6 +124,35 @@ class COracle:
         hi = np.zeros(3, dtype=np.uint32)
         self.lib.oracle_histogram_level(_ptr(tex), _ptr(hi), width, height, components, logscale, level_fixed, level_ratio)
         return tex.view(np.float32).reshape(256, 4), hi
+
+
+    # -- display shaders D1-D3 -----------------------------------------------------------------
+    def display_size(self, base_w, base_h, components, display):
+        ow, oh = C.c_uint32(), C.c_uint32()
+        self.lib.oracle_display_size(base_w, base_h, components, display, C.byref(ow), C.byref(oh))
+        return int(ow.value), int(oh.value)
+
+    def display_vectorscope(self, table, intensity=25, color_type=1, colorspace=2):
+        out = np.empty((256, 256, 4), dtype=np.uint8)
+        t = np.ascontiguousarray(table, dtype=np.uint8)
+        self.lib.oracle_display_vectorscope(_ptr(out), _ptr(t), intensity, color_type, colorspace)
+        return out
+
+    def display_waveform(self, table, components, display, intensity=25):
+        t = np.ascontiguousarray(table, dtype=np.uint8)
+        ow, oh = self.display_size(t.shape[1], 256, components, display)
+        out = np.empty((oh, ow, 4), dtype=np.uint8)
+        self.lib.oracle_display_waveform(_ptr(out), _ptr(t), t.shape[1], components, display, intensity)
+        return out
+
+    def display_histogram(self, tex, hi_max, components, display, level_height=200):
+        t = np.ascontiguousarray(tex, dtype=np.float32)
+        hi = np.ascontiguousarray(hi_max, dtype=np.uint32)
+        ow, oh = self.display_size(256, level_height, components, display)
+        out = np.empty((oh, ow, 4), dtype=np.uint8)
+        self.lib.oracle_display_histogram(_ptr(out), t.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
+                                          components, display, level_height)
+        return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -126,3 +126,7 @@ def test_device_path_and_unaligned_rows(emul_ctx, oracle, w, h, ls, off):
 
 def test_frame_pipeline(emul_ctx, oracle):
     pc.check_pipeline(emul_ctx, oracle, 70, 20, n_frames=5, depth=2, linesize=4 * 70 + 24)
+
+
+def test_display_post_passes(emul_ctx, oracle):
+    pc.check_display(emul_ctx, oracle, 35, 20)

@@ -267,3 +267,9 @@ def test_frame_pipeline_streams(hip_ctx, oracle):
     """BASELINE config 5 in miniature and at full size: frames in flight over upload/compute/download streams."""
     pc.check_pipeline(hip_ctx, oracle, 640, 360, n_frames=9, depth=3)
     pc.check_pipeline(hip_ctx, oracle, 3840, 2160, n_frames=5, depth=3)
+
+
+def test_display_post_passes(hip_ctx, oracle):
+    """tables -> scope pictures on the GPU, every display technique."""
+    pc.check_display(hip_ctx, oracle, 70, 40)
+    pc.check_display(hip_ctx, oracle, 1280, 72)
