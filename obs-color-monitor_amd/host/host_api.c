@@ -48,3 +48,16 @@ uint64_t scope_host_frames_dropped(void *source)
 {
 	return scope_host_cm(source)->frames_dropped;
 }
+
+/* The picture the source's video_render produced (RGBA8, row-major); NULL before the first render. */
+const uint8_t *scope_host_picture(void *source, int kind, uint32_t *width, uint32_t *height)
+{
+	const struct scope_picture *pic = kind == 0   ? &((struct vss_source *)source)->pic
+					  : kind == 1 ? &((struct wvs_source *)source)->pic
+						      : &((struct his_source *)source)->pic;
+	if (width)
+		*width = pic->width;
+	if (height)
+		*height = pic->height;
+	return pic->rgba;
+}

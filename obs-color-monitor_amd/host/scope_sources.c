@@ -24,6 +24,21 @@ static void log_failure(const char *what, int st)
 		blog(LOG_ERROR, "[obs-color-monitor] %s failed: %s (%s)", what, scope_strerror(st), scope_last_error(cm_gpu()));
 }
 
+/* The display shaders (D1-D3) run as GPU post-passes; the picture lands where the plugin would have
+ * drawn it.  Silent skip on failure, like every render path of the reference. */
+static uint8_t *picture_reserve(struct scope_picture *pic, uint32_t w, uint32_t h)
+{
+	const size_t need = (size_t)w * h * 4;
+	if (pic->capacity < need) {
+		bfree(pic->rgba);
+		pic->rgba = bzalloc(need);
+		pic->capacity = pic->rgba ? need : 0;
+	}
+	pic->width = w;
+	pic->height = h;
+	return pic->rgba;
+}
+
 /* -- vectorscope ------------------------------------------------------------------------------------ */
 
 static const char *vss_get_name(void *unused)
@@ -36,6 +51,10 @@ static void vss_update(void *data, obs_data_t *settings)
 {
 	struct vss_source *src = data;
 	cm_update(&src->cm, settings);
+	src->intensity = (int)obs_data_get_int(settings, "intensity"); /* src/vectorscope.c:129-133 */
+	if (src->intensity < 1)
+		src->intensity = 1;
+	src->color_type = (int)obs_data_get_int(settings, "color_type");
 }
 
 static void *vss_create(obs_data_t *settings, obs_source_t *source)
@@ -54,12 +73,31 @@ static void vss_destroy(void *data)
 	cm_destroy(&src->cm);
 	bfree(src->tex_buf[0]); /* src/vectorscope.c:119-120 */
 	bfree(src->tex_buf[1]);
+	bfree(src->pic.rgba);
 	bfree(src);
 }
 
 static void vss_get_defaults(obs_data_t *settings)
 {
 	cm_get_defaults(settings);
+	obs_data_set_default_int(settings, "intensity", 25); /* src/vectorscope.c:158 */
+	obs_data_set_default_int(settings, "color_type", 1); /* color_type_uv, :166 */
+}
+
+/* src/vectorscope.c:382-471 minus graticule and zoom: upload + PSDrawBare become one GPU pass */
+static void vss_render(void *data, gs_effect_t *effect)
+{
+	UNUSED_PARAMETER(effect);
+	struct vss_source *src = data;
+	const int r_tex_buf = src->w_tex_buf ^ 1;
+	if (!src->tex_buf[r_tex_buf])
+		return; /* :411 */
+	uint8_t *rgba = picture_reserve(&src->pic, VS_SIZE, VS_SIZE);
+	if (!rgba)
+		return;
+	log_failure("scope_display_vectorscope",
+		    scope_display_vectorscope(cm_gpu(), src->tex_buf[r_tex_buf], src->intensity, src->color_type,
+					      src->tex_cs[r_tex_buf], 0, rgba));
 }
 
 static uint32_t vss_get_width(void *data)
@@ -109,7 +147,7 @@ const struct obs_source_info colormonitor_vectorscope_v2 = {
 	.get_defaults = vss_get_defaults,
 	.get_width = vss_get_width,
 	.get_height = vss_get_width,
-	.video_render = scope_render_nothing,
+	.video_render = vss_render,
 	.video_tick = cm_tick,
 };
 
@@ -129,6 +167,10 @@ static void wvs_update(void *data, obs_data_t *settings)
 	/* src/waveform.c:100-102 */
 	src->cm.flags = ((src->components & COMP_RGB) ? CM_FLAG_CONVERT_RGB : 0) |
 			((src->components & COMP_YUV) ? CM_FLAG_CONVERT_YUV : 0);
+	src->display = (int)obs_data_get_int(settings, "display");
+	src->intensity = (int)obs_data_get_int(settings, "intensity");
+	if (src->intensity < 1)
+		src->intensity = 1;
 }
 
 static void *wvs_create(obs_data_t *settings, obs_source_t *source)
@@ -146,6 +188,7 @@ static void wvs_destroy(void *data)
 	cm_destroy(&src->cm);
 	bfree(src->tex_buf[0]); /* src/waveform.c:87-88 */
 	bfree(src->tex_buf[1]);
+	bfree(src->pic.rgba);
 	bfree(src);
 }
 
@@ -153,18 +196,41 @@ static void wvs_get_defaults(obs_data_t *settings)
 {
 	cm_get_defaults(settings);
 	obs_data_set_default_int(settings, "components", COMP_RGB); /* src/waveform.c:115 */
+	obs_data_set_default_int(settings, "display", 0);
+	obs_data_set_default_int(settings, "intensity", 51); /* src/waveform.c:114 */
+}
+
+/* src/waveform.c:334-392 minus graticule: upload + DrawOverlay/Stack/Parade become one GPU pass */
+static void wvs_render(void *data, gs_effect_t *effect)
+{
+	UNUSED_PARAMETER(effect);
+	struct wvs_source *src = data;
+	const int r = src->w_tex_buf ^ 1;
+	if (!src->tex_buf[r] || !src->tex_buf_width[r])
+		return;
+	uint32_t w, h;
+	scope_display_size(src->tex_buf_width[r], WV_SIZE, src->components, src->display, &w, &h);
+	uint8_t *rgba = picture_reserve(&src->pic, w, h);
+	if (!rgba || !w || !h)
+		return;
+	log_failure("scope_display_waveform", scope_display_waveform(cm_gpu(), src->tex_buf[r], src->tex_buf_width[r],
+								      src->components, src->display, src->intensity, 0, rgba));
 }
 
 static uint32_t wvs_get_width(void *data)
 {
-	struct wvs_source *src = data;
-	return src->tex_buf_width[src->w_tex_buf ^ 1]; /* overlay display, src/waveform.c:181-189 */
+	struct wvs_source *src = data; /* src/waveform.c:181-189 */
+	uint32_t w, h;
+	scope_display_size(src->tex_buf_width[src->w_tex_buf ^ 1], WV_SIZE, src->components, src->display, &w, &h);
+	return w;
 }
 
 static uint32_t wvs_get_height(void *data)
 {
-	UNUSED_PARAMETER(data);
-	return WV_SIZE;
+	struct wvs_source *src = data; /* src/waveform.c:191-199 */
+	uint32_t w, h;
+	scope_display_size(src->tex_buf_width[src->w_tex_buf ^ 1], WV_SIZE, src->components, src->display, &w, &h);
+	return h;
 }
 
 /* src/waveform.c:207-218 */
@@ -212,7 +278,7 @@ const struct obs_source_info colormonitor_waveform = {
 	.get_defaults = wvs_get_defaults,
 	.get_width = wvs_get_width,
 	.get_height = wvs_get_height,
-	.video_render = scope_render_nothing,
+	.video_render = wvs_render,
 	.video_tick = cm_tick,
 };
 
@@ -236,6 +302,10 @@ static void his_update(void *data, obs_data_t *settings)
 	const int level_mode = (int)obs_data_get_int(settings, "level_mode");
 	src->level_fixed_value = level_mode == 1 ? (int)obs_data_get_int(settings, "level_fixed_value") : 0;
 	src->level_ratio_value = level_mode == 2 ? (int)obs_data_get_int(settings, "level_ratio_value") : 0;
+	src->display = (int)obs_data_get_int(settings, "display");
+	src->level_height = (int)obs_data_get_int(settings, "level_height"); /* src/histogram.c:123 */
+	if (src->level_height < 1)
+		src->level_height = 1;
 }
 
 static void *his_create(obs_data_t *settings, obs_source_t *source)
@@ -253,6 +323,7 @@ static void his_destroy(void *data)
 	cm_destroy(&src->cm);
 	bfree(src->tex_buf[0]); /* src/histogram.c:97-98 */
 	bfree(src->tex_buf[1]);
+	bfree(src->pic.rgba);
 	bfree(src);
 }
 
@@ -262,12 +333,42 @@ static void his_get_defaults(obs_data_t *settings)
 	obs_data_set_default_int(settings, "components", COMP_RGB); /* src/histogram.c:167 */
 	obs_data_set_default_bool(settings, "logscale", false);
 	obs_data_set_default_int(settings, "level_mode", 0);
+	obs_data_set_default_int(settings, "display", 0);
+	obs_data_set_default_int(settings, "level_height", 200); /* src/histogram.c:168 */
 }
 
 static uint32_t his_get_width(void *data)
 {
-	UNUSED_PARAMETER(data);
-	return HI_SIZE;
+	struct his_source *src = data; /* src/histogram.c:304-312 */
+	uint32_t w, h;
+	scope_display_size(HI_SIZE, (uint32_t)src->level_height, src->components, src->display, &w, &h);
+	return w;
+}
+
+static uint32_t his_get_height(void *data)
+{
+	struct his_source *src = data; /* src/histogram.c:314-322 */
+	uint32_t w, h;
+	scope_display_size(HI_SIZE, (uint32_t)src->level_height, src->components, src->display, &w, &h);
+	return h;
+}
+
+/* src/histogram.c:522-578 minus graticule */
+static void his_render(void *data, gs_effect_t *effect)
+{
+	UNUSED_PARAMETER(effect);
+	struct his_source *src = data;
+	const int r = src->w_tex_buf ^ 1;
+	if (!src->tex_buf[r])
+		return;
+	uint32_t w, h;
+	scope_display_size(HI_SIZE, (uint32_t)src->level_height, src->components, src->display, &w, &h);
+	uint8_t *rgba = picture_reserve(&src->pic, w, h);
+	if (!rgba || !w || !h)
+		return;
+	log_failure("scope_display_histogram",
+		    scope_display_histogram(cm_gpu(), (const float *)src->tex_buf[r], src->hi_max[r], src->components,
+					    src->display, (uint32_t)src->level_height, 0, rgba));
 }
 
 void his_surface_cb(void *data, struct cm_surface_data *surface_data)
@@ -305,8 +406,8 @@ const struct obs_source_info colormonitor_histogram = {
 	.update = his_update,
 	.get_defaults = his_get_defaults,
 	.get_width = his_get_width,
-	.get_height = his_get_width,
-	.video_render = scope_render_nothing,
+	.get_height = his_get_height,
+	.video_render = his_render,
 	.video_tick = cm_tick,
 };
 

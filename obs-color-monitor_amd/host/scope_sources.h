@@ -20,11 +20,21 @@ extern "C" {
 #define COMP_UV 0x50
 #define COMP_YUV (COMP_Y | COMP_UV)
 
+/* What video_render produced last: the scope picture (RGBA8) the display shader would have drawn. */
+struct scope_picture {
+	uint8_t *rgba;
+	size_t capacity;
+	uint32_t width, height;
+};
+
 struct vss_source {
 	struct cm_source cm;
 	uint8_t *tex_buf[2];
 	int tex_cs[2];
 	volatile int w_tex_buf;
+	int intensity;  /* src/vectorscope.c:55,129-131 */
+	int color_type; /* 0 white, 1 UV (src/vectorscope.c:36-39) */
+	struct scope_picture pic;
 };
 
 struct wvs_source {
@@ -33,6 +43,9 @@ struct wvs_source {
 	uint32_t tex_buf_width[2];
 	volatile int w_tex_buf;
 	uint32_t components;
+	int display;   /* DISP_OVERLAY / DISP_STACK / DISP_PARADE, src/waveform.c:22-24 */
+	int intensity; /* src/waveform.c:104-106 */
+	struct scope_picture pic;
 };
 
 struct his_source {
@@ -44,6 +57,9 @@ struct his_source {
 	int level_fixed_value;
 	int level_ratio_value;
 	bool logscale;
+	int display;
+	int level_height; /* src/histogram.c:53,123 */
+	struct scope_picture pic;
 };
 
 #define ROI_MAX_SOURCES 16

@@ -48,6 +48,8 @@ class Host:
         L.scope_host_wvs_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.scope_host_his_table.restype = C.POINTER(C.c_float)
         L.scope_host_his_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.scope_host_picture.restype = C.POINTER(C.c_uint8)
+        L.scope_host_picture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.scope_host_frames_processed.restype = C.c_uint64
         L.scope_host_frames_processed.argtypes = [C.c_void_p]
         L.scope_host_frames_dropped.restype = C.c_uint64
@@ -85,6 +87,11 @@ class Host:
         w = C.c_uint32()
         p = self.L.scope_host_wvs_table(obj, C.byref(w))
         return np.ctypeslib.as_array(p, (256, w.value, 4)).copy() if p else None
+
+    def picture(self, obj, kind):
+        w, h = C.c_uint32(), C.c_uint32()
+        p = self.L.scope_host_picture(obj, kind, C.byref(w), C.byref(h))
+        return np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy() if p else None
 
     def his_table(self, obj):
         hi = (C.c_uint32 * 3)()
@@ -141,6 +148,16 @@ def run_host_checks(host, oracle, w=96, h=40):
         got_f, got_hi = host.his_table(his)
         assert np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32)) and got_hi == list(want_hi)
     assert winfo.get_width(wvs) == w and winfo.get_height(wvs) == 256
+    # video_render: the display shaders as GPU post-passes, the picture the plugin would have drawn
+    rgb, yuv = frames[-1]
+    vinfo.video_render(vss, None)
+    assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2))
+    winfo.video_render(wvs, None)
+    assert np.array_equal(host.picture(wvs, 1), oracle.display_waveform(oracle.waveform(rgb, yuv, w, 0x07), 0x07, 0, 51))
+    hinfo.video_render(his, None)
+    flt, hi = oracle.histogram(rgb, yuv, w, 0x07, logscale=1)
+    assert np.array_equal(host.picture(his, 2), oracle.display_histogram(flt, hi, 0x07, 0, 200))
+    assert hinfo.get_width(his) == 256 and hinfo.get_height(his) == 200
     # a waveform switched to luma gets the YUV plane of the same surface
     d = host.L.fake_obs_data_create()
     winfo.get_defaults(d)
