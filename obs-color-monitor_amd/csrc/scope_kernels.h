@@ -31,11 +31,13 @@ struct ScopeFrameSet {
 	uint32_t width, height;
 };
 
-/* K0 matrix, rows U,Y,V; columns r,g,b (signed, so every term is an add). */
+/* K0 matrix, rows U,Y,V; columns r,g,b (signed, so every term is an add).  U and V coefficients
+ * of one column sit next to each other: the kernels use them as packed pairs (v_pk_mul_f32). */
 struct ScopeK0 {
-	float ur, ug, ub;
+	float ur, vr;
+	float ug, vg;
+	float ub, vb;
 	float yr, yg, yb;
-	float vr, vg, vb;
 };
 
 /* Tunables the host may flip for A/B runs (scope_ctx_set_option). */

@@ -20,6 +20,7 @@
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (K0 must not be FMA-contracted).
  */
 #include "scope_kernels.h"
+#include <scope_vec.h>
 
 typedef uint32_t u32;
 typedef uint64_t u64;
@@ -55,16 +56,14 @@ __device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool nee
 	const float r = scope_unorm8((px >> 16) & 0xffu);
 	u32 out = 0xff000000u;
 	if (need_uv) {
-		float u = __fmul_rn(k.ur, r);
-		u = __fadd_rn(u, __fmul_rn(k.ug, g));
-		u = __fadd_rn(u, __fmul_rn(k.ub, b));
-		u = __fadd_rn(u, 0.5f);
-		u = __fsub_rn(u, 0.00390625f);
-		float v = __fmul_rn(k.vr, r);
-		v = __fadd_rn(v, __fmul_rn(k.vg, g));
-		v = __fadd_rn(v, __fmul_rn(k.vb, b));
-		v = __fadd_rn(v, 0.5f);
-		out |= scope_k0_quantise(u) | (scope_k0_quantise(v) << 16);
+		/* U and V side by side in one 2-vector: the same operations in the same order on both halves,
+		 * so they issue as v_pk_mul_f32 / v_pk_add_f32 (no FMA: -ffp-contract=off).  V's "- 0" is exact. */
+		scope_f2 uv = scope_f2_make(k.ur, k.vr) * scope_f2_make(r, r);
+		uv = uv + scope_f2_make(k.ug, k.vg) * scope_f2_make(g, g);
+		uv = uv + scope_f2_make(k.ub, k.vb) * scope_f2_make(b, b);
+		uv = uv + scope_f2_make(0.5f, 0.5f);
+		uv = uv - scope_f2_make(0.00390625f, 0.0f);
+		out |= scope_k0_quantise(scope_f2_lo(uv)) | (scope_k0_quantise(scope_f2_hi(uv)) << 16);
 	}
 	if (need_y) {
 		float y = __fmul_rn(k.yr, r);
@@ -78,11 +77,17 @@ __device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool nee
 ScopeK0 scope_k0_matrix(int colorspace)
 {
 	/* src/common.c:207-208: colorspace == 1 -> 601, anything else -> 709 */
-	if (colorspace == 1)
-		return ScopeK0{-0.147643f, -0.289855f, +0.437500f, +0.299000f, +0.587000f,
-			       +0.114000f, +0.437500f, -0.366351f, -0.071147f};
-	return ScopeK0{-0.100643f, -0.338571f, +0.439216f, +0.212600f, +0.715200f,
-		       +0.072200f, +0.439216f, -0.398941f, -0.040273f};
+	ScopeK0 k;
+	if (colorspace == 1) {
+		k.ur = -0.147643f, k.ug = -0.289855f, k.ub = +0.437500f;
+		k.yr = +0.299000f, k.yg = +0.587000f, k.yb = +0.114000f;
+		k.vr = +0.437500f, k.vg = -0.366351f, k.vb = -0.071147f;
+	} else {
+		k.ur = -0.100643f, k.ug = -0.338571f, k.ub = +0.439216f;
+		k.yr = +0.212600f, k.yg = +0.715200f, k.yb = +0.072200f;
+		k.vr = +0.439216f, k.vg = -0.398941f, k.vb = -0.040273f;
+	}
+	return k;
 }
 
 /* ------------------------------------------------------------------------------------------

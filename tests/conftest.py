@@ -53,6 +53,9 @@ def hip_ctx():
     import torch  # first: the library then shares torch's HIP runtime (same libamdhip64 soname)
 
     assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    # normally a no-op (build() ran and the .so travelled with the tree); hipcc exists on the GPU box too
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "obs-color-monitor_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "obs-color-monitor_amd", "host")])
     import obs_color_monitor_amd as ocm
 
     ctx = ocm.ScopeContext(0)  # raises if libscope_hip.so is missing: no fallback

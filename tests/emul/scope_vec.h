@@ -1,0 +1,29 @@
+/* tests/emul/scope_vec.h -- CPU stand-in of csrc/scope_vec.h (TEST INFRASTRUCTURE ONLY). */
+#pragma once
+struct scope_f2 {
+	float x, y;
+};
+static inline scope_f2 scope_f2_make(float a, float b)
+{
+	return scope_f2{a, b};
+}
+static inline float scope_f2_lo(scope_f2 v)
+{
+	return v.x;
+}
+static inline float scope_f2_hi(scope_f2 v)
+{
+	return v.y;
+}
+static inline scope_f2 operator+(scope_f2 a, scope_f2 b)
+{
+	return scope_f2{a.x + b.x, a.y + b.y};
+}
+static inline scope_f2 operator-(scope_f2 a, scope_f2 b)
+{
+	return scope_f2{a.x - b.x, a.y - b.y};
+}
+static inline scope_f2 operator*(scope_f2 a, scope_f2 b)
+{
+	return scope_f2{a.x * b.x, a.y * b.y};
+}

@@ -20,7 +20,7 @@ def test_host_mirror_on_emulated_kernels(emul_lib, oracle):
 
 
 @pytest.mark.gpu
-def test_host_mirror_on_gpu(oracle):
+def test_host_mirror_on_gpu(hip_ctx, oracle):
     import torch  # noqa: F401
 
     path = os.path.join(ROOT, "obs-color-monitor_amd", "libscope_host.so")

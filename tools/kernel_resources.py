@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Prints VGPR/SGPR/scratch/LDS/occupancy for every kernel of a .hip file compiled for gfx950."""
+import os
 import re
 import subprocess
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "obs-color-monitor_amd/csrc/scope_kernels.hip"
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", src, "-o", "/dev/null",
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.dirname(os.path.abspath(src)), "-c", src, "-o", "/dev/null",
        "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 keys = {"VGPRs": "vgpr", "TotalSGPRs": "sgpr", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occ",
