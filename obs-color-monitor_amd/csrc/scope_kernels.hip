@@ -217,10 +217,12 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 #define VSS_WORDS 32768u
 #define VSS_EPOCH_PIXELS 65280u
 
+/* A pixel's bin as a key: byte0 = U, byte2 = V (src/vectorscope.c:228-232).  Equal keys <=> equal bins;
+ * the bin index u + 256*(255 - v) is never materialised: the LDS byte address comes straight from the
+ * key's bits (each VALU instruction occupies a SIMD for a quad-cycle here, so instructions are what counts). */
 __device__ __forceinline__ u32 vss_bin(u32 px)
 {
-	/* byte0 = U, byte2 = V: idx = u + 256*(255 - v)   (src/vectorscope.c:228-232) */
-	return (px & 0xffu) | ((~px >> 8) & 0xff00u);
+	return px & 0x00ff00ffu;
 }
 
 __device__ __forceinline__ u32 vss_rev5(u32 row)
@@ -228,16 +230,20 @@ __device__ __forceinline__ u32 vss_rev5(u32 row)
 	return __brev(row) >> 27;
 }
 
-template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 idx, u32 n)
+template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u32 n)
 {
-	const u32 row = idx >> 8;
+	const u32 t = ~key; /* bits 16..23 = row = 255 - v */
+	u32 byte, shift;
 	if (HASH == 1) {
-		const u32 word = (row << 7) + ((idx & 127u) ^ vss_rev5(row));
-		atomicAdd(&tab[word], n << ((idx >> 3) & 16u));
+		/* word row*128 + ((u & 127) ^ rev5(row)), half u >> 7 */
+		byte = ((t >> 7) & 0x1fe00u) ^ ((key & 127u) << 2) ^ ((__brev(t >> 16) >> 27) << 2);
+		shift = (key >> 3) & 16u;
 	} else {
-		const u32 word = (row << 7) + (((idx & 0xffu) >> 1) ^ ((row & 3u) << 3));
-		atomicAdd(&tab[word], n << ((idx & 1u) << 4));
+		/* word row*128 + ((u >> 1) ^ ((row & 3) << 3)), half u & 1; the three terms use disjoint bits */
+		byte = ((t >> 7) & 0x1fe00u) ^ ((t >> 11) & 0x60u) ^ ((key << 1) & 0x1fcu);
+		shift = (key & 1u) << 4;
 	}
+	atomicAdd((u32 *)((uint8_t *)tab + byte), n << shift);
 }
 
 /* one clamped bin out of the table */
