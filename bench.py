@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32, help="distinct HBM-resident frames per step")
     ap.add_argument("--workload", default="vectorscope", choices=["vectorscope", "vectorscope_rgb", "waveform", "histogram"])
     ap.add_argument("--components", type=lambda s: int(s, 0), default=0x07)
-    ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "ramp", "natural"])
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "ramp", "natural", "screen"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-reduce", action="store_true",

@@ -261,7 +261,7 @@ template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, 
 /* The four pixels of one 16-byte cell.
  *   MERGE 0  four plain adds.
  *   MERGE 1  runs of equal neighbours inside the cell are folded into one add.
- *   MERGE 2  = 1, plus: when every lane of the wave sits on ONE bin, one lane adds for all.
+ *   MERGE 2  = 1, plus: lanes whose cell is one colour are aggregated across the wave (3 colours).
  *   MERGE 3  adaptive (in vss_region): once per batch the wave votes on whether it is on flat
  *            content (at least half of its lanes hold only single-colour cells); only then MERGE 2.
  * Same-address LDS atomics serialise at ~4 clk per lane (profiles/round1/lds_atomic_microbench.txt):
@@ -291,18 +291,34 @@ template <int MERGE, int HASH> __device__ __forceinline__ void vss_add_run4(u32 
 		n1 = 0;
 	}
 	if (MERGE >= 2) {
-		/* whole wave on one bin (flat areas): one lane adds for everybody */
-		const u32 first = __builtin_amdgcn_readfirstlane(i0);
-		const bool same = (n0 == 4) && (i0 == first);
-		if (__all(same)) {
-			const u64 active = __ballot(1);
-			const u32 lane = threadIdx.x & 63u;
-			if (lane == (u32)(__ffsll((long long)active) - 1))
-				vss_add<HASH>(tab, first, 4u * (u32)__popcll(active));
-			return;
+		/* Flat areas: lanes whose whole cell is one colour are aggregated across the wave, one
+		 * colour per round -- one lane adds 4 * (lanes on that colour).  Three rounds take care of a
+		 * background and two more flat colours (screen capture, graphics, letterbox); whatever is
+		 * left adds for itself below.  (A general colour-by-colour aggregation that also collects
+		 * partial cells was tried: its four ballots per round cost more than the conflicts it
+		 * removes -- profiles/round1/sweep_r1v.jsonl vs sweep_r1u.jsonl.) */
+		const u32 lane = threadIdx.x & 63u;
+		bool mine = n0 == 4; /* my cell is still to be added and is one colour */
+		u64 todo = __ballot(mine);
+#pragma unroll
+		for (int round = 0; round < 3; round++) {
+			if (todo == 0)
+				break;
+			const u32 leader = (u32)(__ffsll((long long)todo) - 1);
+			const u32 colour = __builtin_amdgcn_readlane(i0, leader);
+			const bool hit = mine && i0 == colour;
+			const u64 m = __ballot(hit);
+			if (lane == leader)
+				vss_add<HASH>(tab, colour, 4u * (u32)__popcll(m));
+			if (hit) {
+				mine = false;
+				n0 = 0;
+			}
+			todo &= ~m;
 		}
 	}
-	vss_add<HASH>(tab, i0, n0);
+	if (n0)
+		vss_add<HASH>(tab, i0, n0);
 	if (n1)
 		vss_add<HASH>(tab, i1, n1);
 	if (n2)

@@ -7,6 +7,8 @@ Distributions (SURVEY.md 8(d) plus a natural-video stand-in), all BGRA8 with alp
   ramp          horizontal/vertical/diagonal ramps + 2 LSB of noise.  R is a blend of B and G here, so
                 every pixel's (U,V) falls on ONE line of ~200 bins: a stress test (all bins saturate, every
                 wave sees a handful of bins), not a picture
+  screen        stand-in for screen capture / graphics: a flat background, 300 flat rectangles in random
+                colours and a sprinkle of single-pixel detail (~3 %): most waves see one or two colours
   natural       stand-in for real video: a smooth random colour field (64x36 random RGB control points,
                 bicubic up-sampling) + 2 LSB of sensor-like noise: neighbouring pixels share or nearly
                 share their chroma, the frame as a whole covers a wide 2-D region of the CbCr plane
@@ -23,6 +25,20 @@ def make_rgb_frames(torch, n, w, h, dist, seed):
     elif dist == "flat":
         rgb = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
         rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0xD7, 0xCC, 0xC6
+    elif dist == "screen":
+        rgb = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
+        for i in range(n):
+            img = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+            img[...] = torch.randint(0, 256, (3,), dtype=torch.uint8, device="cuda", generator=g)
+            cpu = torch.Generator()
+            cpu.manual_seed(seed * 1000 + i)
+            for _ in range(300):
+                x0, y0 = int(torch.randint(0, w - 8, (1,), generator=cpu)), int(torch.randint(0, h - 8, (1,), generator=cpu))
+                ww, hh = int(torch.randint(8, 600, (1,), generator=cpu)), int(torch.randint(8, 300, (1,), generator=cpu))
+                img[y0:y0 + hh, x0:x0 + ww] = torch.randint(0, 256, (3,), dtype=torch.uint8, device="cuda", generator=g)
+            detail = torch.rand((h, w), device="cuda", generator=g) < 0.03
+            img[detail] = torch.randint(0, 256, (int(detail.sum()), 3), dtype=torch.uint8, device="cuda", generator=g)
+            rgb[i, :, :, :3] = img
     elif dist == "natural":
         import torch.nn.functional as F
 

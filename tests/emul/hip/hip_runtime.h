@@ -140,6 +140,10 @@ static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t x)
 {
 	return x;
 }
+static inline uint32_t __builtin_amdgcn_readlane(uint32_t x, uint32_t)
+{
+	return x; /* the only active lane is the caller */
+}
 static inline int __all(int p)
 {
 	return p != 0;

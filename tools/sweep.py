@@ -95,7 +95,7 @@ def main():
         emit(dict(tag="ref", what=name, ms=round(ms, 4), gbps=round(bytes_moved / (ms * 1e-3) / 1e9, 1)))
     del a, b
 
-    dists = ["uniform", "concentrated", "flat", "ramp", "natural"] if not args.quick else ["uniform", "natural"]
+    dists = ["uniform", "concentrated", "flat", "ramp", "natural", "screen"] if not args.quick else ["uniform", "natural", "screen"]
     data = {d: make_frames(ctx, n, d) for d in dists}
     tab = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
     # let the clocks leave idle before anything is timed
