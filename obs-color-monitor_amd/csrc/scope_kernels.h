@@ -42,7 +42,7 @@ struct ScopeK0 {
 
 /* Tunables the host may flip for A/B runs (scope_ctx_set_option). */
 struct ScopeTuning {
-	int vss_merge;       /* 0 none, 1 lane-local run merge, 2 = 1 + wave-uniform shortcut, 3 adaptive */
+	int vss_merge;       /* 0 plain adds, 1|2 absorb mode always, 3 absorb mode by wave vote (default) */
 	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 4 or 8 */
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3 */

@@ -258,73 +258,55 @@ template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, 
 	return min(w & 0xffffu, 255u);
 }
 
-/* The four pixels of one 16-byte cell.
- *   MERGE 0  four plain adds.
- *   MERGE 1  runs of equal neighbours inside the cell are folded into one add.
- *   MERGE 2  = 1, plus: lanes whose cell is one colour are aggregated across the wave (3 colours).
- *   MERGE 3  adaptive (in vss_region): once per batch the wave votes on whether it is on flat
- *            content (at least half of its lanes hold only single-colour cells); only then MERGE 2.
- * Same-address LDS atomics serialise at ~4 clk per lane (profiles/round1/lds_atomic_microbench.txt):
- * a flat frame costs 127 clk per wave instruction unmerged, 4.5 merged; on noisy video the folding
- * only costs VALU, hence the vote. */
-template <int MERGE, int HASH> __device__ __forceinline__ void vss_add_run4(u32 *tab, u32 i0, u32 i1, u32 i2, u32 i3)
+/* Flat content (screen capture, graphics, letterbox, a paused scene): almost every pixel of a lane's
+ * stream has the colour the lane saw last.  Same-address LDS atomics serialise at ~4 clk per lane
+ * (profiles/round1/lds_atomic_microbench.txt) -- a flat frame costs 127 clk per wave instruction --
+ * so in *absorb mode* a lane keeps (colour, count) in two registers, counts matching pixels there and
+ * only sends the others to LDS; the pair is added when the colour changes, before every clamp pass and
+ * at the end of the slice.  Whether a batch runs in absorb mode is one wave vote (vss_region). */
+struct VssLane {
+	u32 colour; /* key of the pending pixels; 0xffffffff = none (no key has bits in bytes 1 and 3) */
+	u32 count;
+};
+
+template <int HASH> __device__ __forceinline__ void vss_absorb4(u32 *tab, VssLane &st, u32 k0, u32 k1, u32 k2, u32 k3)
 {
-	if (MERGE == 0) {
-		vss_add<HASH>(tab, i0, 1);
-		vss_add<HASH>(tab, i1, 1);
-		vss_add<HASH>(tab, i2, 1);
-		vss_add<HASH>(tab, i3, 1);
+	const bool any = (k0 == st.colour) | (k1 == st.colour) | (k2 == st.colour) | (k3 == st.colour);
+	if (!any && st.count)
+		vss_add<HASH>(tab, st.colour, st.count); /* the colour changed: hand in the old one (rare) */
+	const u32 colour = any ? st.colour : k0;        /* ... and start counting the new one */
+	const bool e0 = k0 == colour, e1 = k1 == colour, e2 = k2 == colour, e3 = k3 == colour;
+	st.colour = colour;
+	st.count = (any ? st.count : 0u) + (u32)e0 + (u32)e1 + (u32)e2 + (u32)e3;
+	if (!(e0 & e1 & e2 & e3)) { /* one exec test skips all four when the whole wave was absorbed */
+		if (!e0)
+			vss_add<HASH>(tab, k0, 1);
+		if (!e1)
+			vss_add<HASH>(tab, k1, 1);
+		if (!e2)
+			vss_add<HASH>(tab, k2, 1);
+		if (!e3)
+			vss_add<HASH>(tab, k3, 1);
+	}
+}
+
+/* Add what the lanes still hold.  Called by whole waves (uniform control flow).  When every pending
+ * lane of the wave holds the same colour -- the flat-frame case -- one lane adds the wave's total. */
+template <int HASH> __device__ __forceinline__ void vss_flush_lane(u32 *tab, VssLane &st)
+{
+	const u64 pending = __ballot(st.count != 0);
+	if (pending == 0)
 		return;
+	const u32 leader = (u32)(__ffsll((long long)pending) - 1);
+	const u32 colour = __builtin_amdgcn_readlane(st.colour, leader);
+	if (__all(st.count == 0 || st.colour == colour)) {
+		const u32 total = scope_wave_sum(st.count);
+		if ((threadIdx.x & 63u) == leader)
+			vss_add<HASH>(tab, colour, total);
+	} else if (st.count) {
+		vss_add<HASH>(tab, st.colour, st.count);
 	}
-	/* fold runs of equal neighbours onto their first element */
-	u32 n0 = 1, n1 = 1, n2 = 1, n3 = 1;
-	if (i3 == i2) {
-		n2 += n3;
-		n3 = 0;
-	}
-	if (i2 == i1) {
-		n1 += n2;
-		n2 = 0;
-	}
-	if (i1 == i0) {
-		n0 += n1;
-		n1 = 0;
-	}
-	if (MERGE >= 2) {
-		/* Flat areas: lanes whose whole cell is one colour are aggregated across the wave, one
-		 * colour per round -- one lane adds 4 * (lanes on that colour).  Three rounds take care of a
-		 * background and two more flat colours (screen capture, graphics, letterbox); whatever is
-		 * left adds for itself below.  (A general colour-by-colour aggregation that also collects
-		 * partial cells was tried: its four ballots per round cost more than the conflicts it
-		 * removes -- profiles/round1/sweep_r1v.jsonl vs sweep_r1u.jsonl.) */
-		const u32 lane = threadIdx.x & 63u;
-		bool mine = n0 == 4; /* my cell is still to be added and is one colour */
-		u64 todo = __ballot(mine);
-#pragma unroll
-		for (int round = 0; round < 3; round++) {
-			if (todo == 0)
-				break;
-			const u32 leader = (u32)(__ffsll((long long)todo) - 1);
-			const u32 colour = __builtin_amdgcn_readlane(i0, leader);
-			const bool hit = mine && i0 == colour;
-			const u64 m = __ballot(hit);
-			if (lane == leader)
-				vss_add<HASH>(tab, colour, 4u * (u32)__popcll(m));
-			if (hit) {
-				mine = false;
-				n0 = 0;
-			}
-			todo &= ~m;
-		}
-	}
-	if (n0)
-		vss_add<HASH>(tab, i0, n0);
-	if (n1)
-		vss_add<HASH>(tab, i1, n1);
-	if (n2)
-		vss_add<HASH>(tab, i2, n2);
-	if (n3)
-		vss_add<HASH>(tab, i3, n3);
+	st.count = 0;
 }
 
 __device__ __forceinline__ u32 vss_clamp_word(u32 w)
@@ -350,7 +332,7 @@ __device__ __forceinline__ void vss_clamp_pass(u32 *tab)
 
 template <int VECW, int U, bool NT, int MERGE, bool FUSE, int HASH>
 __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
-					   u32 slice, u32 slices, u32 glog2, const ScopeK0 &k0, u32 &since_clamp)
+					   u32 slice, u32 slices, u32 glog2, const ScopeK0 &k0, u32 &since_clamp, VssLane &st)
 {
 	if (ncols == 0)
 		return;
@@ -360,6 +342,7 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 	auto epoch = [&](u32 px) {
 		/* uniform across the workgroup: everybody takes the same branch */
 		if (since_clamp + px > VSS_EPOCH_PIXELS) {
+			vss_flush_lane<HASH>(tab, st); /* pending pixels belong to the epoch that ends here */
 			__syncthreads();
 			vss_clamp_pass(tab);
 			__syncthreads();
@@ -380,26 +363,24 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 								       p = scope_k0_texel(p, k0, true, false);
 							       idx[k][j] = vss_bin(p);
 						       }
-					       /* MERGE 3: ONE vote per batch (16 pixels per lane): does at least half of the wave
-						* hold nothing but single-colour cells?  Then it sits on flat content (screen
-						* capture, letterbox, graphics) where unmerged same-address atomics would cost
-						* ~30x; noisy video never passes the vote and only pays the plain adds.  A
-						* vote per cell costs more in SALU round trips than it saves. */
-					       bool fold = MERGE == 1 || MERGE == 2;
+					       /* MERGE 3: ONE vote per batch (16 pixels per lane): does at least a quarter of the wave
+						* hold nothing but single-colour cells?  Then it sits on flat content and runs
+						* this batch in absorb mode; noisy video never passes the vote and only pays the
+						* plain adds.  (A vote per cell costs more in SALU round trips than it saves.) */
+					       bool absorb = MERGE == 1 || MERGE == 2;
 					       if (MERGE == 3) {
 						       bool flat = true;
 #pragma unroll
 						       for (int k = 0; k < U; k++)
 							       flat &= !ok[k] || ((idx[k][0] == idx[k][1]) & (idx[k][1] == idx[k][2]) &
 										  (idx[k][2] == idx[k][3]));
-						       fold = __popcll(__ballot(flat)) >= 32;
+						       absorb = __popcll(__ballot(flat)) >= 16;
 					       }
-					       if (fold) {
+					       if (absorb) {
 #pragma unroll
 						       for (int k = 0; k < U; k++)
 							       if (ok[k])
-								       vss_add_run4<(MERGE == 1 ? 1 : 2), HASH>(tab, idx[k][0], idx[k][1],
-													   idx[k][2], idx[k][3]);
+								       vss_absorb4<HASH>(tab, st, idx[k][0], idx[k][1], idx[k][2], idx[k][3]);
 					       } else {
 #pragma unroll
 						       for (int k = 0; k < U; k++)
@@ -445,10 +426,12 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	__syncthreads();
 
 	u32 since_clamp = 0;
+	VssLane st = {0xffffffffu, 0};
 	vss_region<4, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, glog2, k0,
-						 since_clamp);
+						 since_clamp, st);
 	vss_region<1, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, glog2,
-						 k0, since_clamp);
+						 k0, since_clamp, st);
+	vss_flush_lane<HASH>(tab, st);
 	__syncthreads();
 
 	/* flush: 16 consecutive bins of one row per lane per step, one coalesced 16-byte store */
@@ -878,7 +861,7 @@ template <int U, bool NT> hipError_t vss_pick_merge(int merge, int fuse, int has
 {
 	if (merge <= 0)
 		return vss_pick_fuse<U, NT, 0>(fuse, hash, a);
-	if (merge <= 2) /* MERGE 1 (fold without the one-bin shortcut) is not built: 2 covers it */
+	if (merge <= 2) /* 1 and 2: always absorb mode */
 		return vss_pick_fuse<U, NT, 2>(fuse, hash, a);
 	return vss_pick_fuse<U, NT, 3>(fuse, hash, a);
 }
