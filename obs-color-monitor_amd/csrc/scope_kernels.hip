@@ -557,11 +557,20 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
  * ---------------------------------------------------------------------------------------- */
 
 #define WVS_CH_WORDS 8192u
+#define WVS_U 4 /* rows per lane per batch; two batches in flight */
 
-template <int U, bool NT, bool FUSE>
-__global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, u32 chmask,
-							       ScopeK0 k0, uint8_t *dst)
+/* CH = which bytes of the texel are counted (bit c -> byte c), a compile-time constant so that the
+ * per-pixel code has no channel branches.  Everything about a row is wave-uniform (a wave reads one
+ * row segment at a time), so row pointers and the row-validity tests live in SGPRs / scalar branches;
+ * per lane there is only the column offset, the alpha test and the atomics. */
+template <int CH, bool FUSE>
+__global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, ScopeK0 k0,
+							       uint8_t *dst)
 {
+	constexpr int U = WVS_U;
+	constexpr u32 slot0 = 0, slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1), nch = slot2 + ((CH >> 2) & 1);
+	constexpr bool need_uv = (CH & 5) != 0, need_y = (CH & 2) != 0;
+
 	u32 *tab = scope_lds;
 	const u32 unit = blockIdx.x;
 	const u32 per_frame = strips * bands;
@@ -572,67 +581,66 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 	const uint8_t *plane = fs.plane[frame];
 	const u32 W = fs.width;
 
-	/* compact LDS slot of each enabled channel */
-	const u32 slot0 = 0;
-	const u32 slot1 = (chmask & 1u);
-	const u32 slot2 = slot1 + ((chmask >> 1) & 1u);
-	const u32 nch = slot2 + ((chmask >> 2) & 1u);
-
 	const uint4 zero = make_uint4(0, 0, 0, 0);
 	for (u32 i = threadIdx.x * 4; i < nch * WVS_CH_WORDS; i += blockDim.x * 4)
 		*(uint4 *)&tab[i] = zero;
 	__syncthreads();
 
 	const u32 lane = threadIdx.x & 63u;
-	const u32 wave = threadIdx.x >> 6;
+	const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const u32 nwaves = blockDim.x >> 6;
 	const u32 x = strip * SCOPE_WVS_STRIP + lane;
+	const bool live = x < W; /* lanes past the right edge read the strip's first column and bin nothing */
 	const u32 r0 = scope_slice_begin(fs.height, band, bands);
 	const u32 r1 = scope_slice_begin(fs.height, band + 1, bands);
 	const u32 rep = lane & 31u;
 	const u32 inc = (lane < 32u) ? 1u : 65536u;
-	const bool need_uv = (chmask & 5u) != 0, need_y = (chmask & 2u) != 0;
 
-	if (x < W && r0 < r1) {
-		/* wave w takes rows r0+w, r0+w+nwaves, ...; two register sets of U rows are used ping-pong,
-		 * loads unconditional (clamped to r0) so the waits are counted: see scope_stream */
-		const uint8_t *col = plane + (size_t)x * 4;
-		const u32 stride = nwaves * (u32)U;
+	/* wave w takes rows r0+w, r0+w+nwaves, ...: `mine` rows, numbered 0.. in that order */
+	const u32 mine = (r1 - r0 > wave) ? (r1 - r0 - wave + nwaves - 1) / nwaves : 0;
+	if (mine) {
+		const uint8_t *row = plane + (size_t)(r0 + wave) * fs.linesize; /* wave-uniform */
+		const size_t row_step = (size_t)nwaves * fs.linesize;
+		const u32 lane_off = (live ? x : strip * SCOPE_WVS_STRIP) * 4u;
 		u32 va[U], vb[U];
 		bool oka[U], okb[U];
-		u32 r = r0 + wave;
+		u32 next = 0;
+		const uint8_t *cur = row;
 
-#define WVS_ISSUE(v, ok)                                                                                     \
-	do {                                                                                                 \
-		_Pragma("unroll") for (int k = 0; k < U; k++)                                                \
-		{                                                                                            \
-			const u32 rr = r + (u32)k * nwaves;                                                  \
-			ok[k] = rr < r1;                                                                     \
-			v[k] = scope_load<NT>((const u32 *)(col + (size_t)(ok[k] ? rr : r0) * fs.linesize)); \
-		}                                                                                            \
-		r += stride;                                                                                 \
+		/* unconditional loads (rows past the end re-read row 0) keep the vmcnt bookkeeping exact and the
+		 * two register sets are used ping-pong: see scope_stream */
+#define WVS_ISSUE(v, ok)                                                                                      \
+	do {                                                                                                  \
+		_Pragma("unroll") for (int k = 0; k < U; k++)                                                 \
+		{                                                                                             \
+			ok[k] = next + (u32)k < mine;                                                         \
+			v[k] = scope_load_row_nt(ok[k] ? cur : row, lane_off);                                \
+			cur += row_step;                                                                      \
+		}                                                                                             \
+		next += (u32)U;                                                                               \
 	} while (0)
-#define WVS_BIN(v, ok)                                                                                       \
-	do {                                                                                                 \
-		_Pragma("unroll") for (int k = 0; k < U; k++)                                                \
-		{                                                                                            \
-			u32 px = v[k];                                                                       \
-			if (FUSE)                                                                            \
-				px = scope_k0_texel(px, k0, need_uv, need_y);                                \
-			if (ok[k] && (px >> 24) != 0) { /* src/waveform.c:247-248 */                         \
-				if (chmask & 1u)                                                             \
+#define WVS_BIN(v, ok)                                                                                        \
+	do {                                                                                                  \
+		_Pragma("unroll") for (int k = 0; k < U; k++)                                                 \
+		{                                                                                             \
+			if (!ok[k])                                                                           \
+				continue;                                                                     \
+			u32 px = v[k];                                                                        \
+			if (FUSE)                                                                             \
+				px = scope_k0_texel(px, k0, need_uv, need_y);                                 \
+			if (live && (px >> 24) != 0) { /* src/waveform.c:247-248 */                           \
+				if (CH & 1)                                                                   \
 					atomicAdd(&tab[slot0 * WVS_CH_WORDS + ((px & 0xffu) << 5) + rep], inc); \
-				if (chmask & 2u)                                                             \
+				if (CH & 2)                                                                   \
 					atomicAdd(&tab[slot1 * WVS_CH_WORDS + (((px >> 8) & 0xffu) << 5) + rep], inc); \
-				if (chmask & 4u)                                                             \
+				if (CH & 4)                                                                   \
 					atomicAdd(&tab[slot2 * WVS_CH_WORDS + (((px >> 16) & 0xffu) << 5) + rep], inc); \
-			}                                                                                    \
-		}                                                                                            \
+			}                                                                                     \
+		}                                                                                             \
 	} while (0)
 
-		const u32 my_rows = (r1 - r0 > wave) ? (r1 - r0 - wave + nwaves - 1) / nwaves : 0;
-		const u32 batches = (my_rows + (u32)U - 1) / (u32)U;
-		WVS_ISSUE(va, oka); /* unconditional issues keep the vmcnt bookkeeping exact: see scope_stream */
+		const u32 batches = (mine + (u32)U - 1) / (u32)U;
+		WVS_ISSUE(va, oka);
 		for (u32 b = 0; b < batches; b += 2) {
 			WVS_ISSUE(vb, okb);
 			WVS_BIN(va, oka);
@@ -655,21 +663,21 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 	const bool vec_ok = ((W & 3u) == 0) && ((((size_t)table) & 15u) == 0);
 	for (u32 value = threadIdx.x >> 4; value < 256u; value += blockDim.x >> 4) {
 		u32 o[4] = {0, 0, 0, 0};
-		if (chmask & 1u) {
+		if (CH & 1) {
 			const uint4 c = *(const uint4 *)&tab[slot0 * WVS_CH_WORDS + (value << 5) + woff];
 			o[0] |= min((c.x >> shift) & 0xffffu, 255u);
 			o[1] |= min((c.y >> shift) & 0xffffu, 255u);
 			o[2] |= min((c.z >> shift) & 0xffffu, 255u);
 			o[3] |= min((c.w >> shift) & 0xffffu, 255u);
 		}
-		if (chmask & 2u) {
+		if (CH & 2) {
 			const uint4 c = *(const uint4 *)&tab[slot1 * WVS_CH_WORDS + (value << 5) + woff];
 			o[0] |= min((c.x >> shift) & 0xffffu, 255u) << 8;
 			o[1] |= min((c.y >> shift) & 0xffffu, 255u) << 8;
 			o[2] |= min((c.z >> shift) & 0xffffu, 255u) << 8;
 			o[3] |= min((c.w >> shift) & 0xffffu, 255u) << 8;
 		}
-		if (chmask & 4u) {
+		if (CH & 4) {
 			const uint4 c = *(const uint4 *)&tab[slot2 * WVS_CH_WORDS + (value << 5) + woff];
 			o[0] |= min((c.x >> shift) & 0xffffu, 255u) << 16;
 			o[1] |= min((c.y >> shift) & 0xffffu, 255u) << 16;
@@ -913,34 +921,43 @@ hipError_t his_pick(int unroll, int nt, int fuse, const HisArgs *a)
 
 struct WvsArgs {
 	const ScopeFrameSet *fs;
-	u32 strips, bands, chmask, lds;
+	u32 strips, bands, lds;
 	ScopeK0 k0;
 	uint8_t *dst;
 	hipStream_t st;
 };
 
-template <int U, bool NT, bool FUSE> hipError_t wvs_variant(const WvsArgs *a)
+template <int CH, bool FUSE> hipError_t wvs_variant(const WvsArgs *a)
 {
 	if (!a)
-		return hipFuncSetAttribute((const void *)scope_wvs_kernel<U, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
 					   (int)WVS_LDS_BYTES);
-	hipLaunchKernelGGL((scope_wvs_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->strips * a->bands), dim3(SCOPE_BLOCK),
-			   a->lds, a->st, *a->fs, a->strips, a->bands, a->chmask, a->k0, a->dst);
+	hipLaunchKernelGGL((scope_wvs_kernel<CH, FUSE>), dim3(a->fs->n_frames * a->strips * a->bands), dim3(SCOPE_BLOCK),
+			   a->lds, a->st, *a->fs, a->strips, a->bands, a->k0, a->dst);
 	return hipGetLastError();
 }
-template <int U, bool NT> hipError_t wvs_pick_fuse(int fuse, const WvsArgs *a)
+template <int CH> hipError_t wvs_pick_fuse(int fuse, const WvsArgs *a)
 {
-	return fuse ? wvs_variant<U, NT, true>(a) : wvs_variant<U, NT, false>(a);
+	return fuse ? wvs_variant<CH, true>(a) : wvs_variant<CH, false>(a);
 }
-template <int U> hipError_t wvs_pick_nt(int nt, int fuse, const WvsArgs *a)
+hipError_t wvs_pick(u32 chmask, int fuse, const WvsArgs *a)
 {
-	return nt ? wvs_pick_fuse<U, true>(fuse, a) : wvs_pick_fuse<U, false>(fuse, a);
-}
-hipError_t wvs_pick(int unroll, int nt, int fuse, const WvsArgs *a)
-{
-	if (unroll <= 4)
-		return wvs_pick_nt<4>(nt, fuse, a);
-	return wvs_pick_nt<8>(nt, fuse, a);
+	switch (chmask & 7u) {
+	case 1:
+		return wvs_pick_fuse<1>(fuse, a);
+	case 2:
+		return wvs_pick_fuse<2>(fuse, a);
+	case 3:
+		return wvs_pick_fuse<3>(fuse, a);
+	case 4:
+		return wvs_pick_fuse<4>(fuse, a);
+	case 5:
+		return wvs_pick_fuse<5>(fuse, a);
+	case 6:
+		return wvs_pick_fuse<6>(fuse, a);
+	default:
+		return wvs_pick_fuse<7>(fuse, a);
+	}
 }
 
 } // namespace
@@ -957,9 +974,11 @@ hipError_t scope_kernels_init(void)
 							e = vss_pick(unroll, nt, merge, fuse, hash, NULL);
 				if (e == hipSuccess)
 					e = his_pick(unroll, nt, fuse, NULL);
-				if (e == hipSuccess)
-					e = wvs_pick(unroll * 2, nt, fuse, NULL);
 			}
+	for (u32 chmask = 1; chmask <= 7; chmask++)
+		for (int fuse = 0; fuse < 2; fuse++)
+			if (e == hipSuccess)
+				e = wvs_pick(chmask, fuse, NULL);
 	return e;
 }
 
@@ -1004,8 +1023,11 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 {
 	const u32 strips = (fs.width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
 	const u32 nch = (chmask & 1u) + ((chmask >> 1) & 1u) + ((chmask >> 2) & 1u);
-	const WvsArgs a = {&fs, strips, bands, chmask, (nch ? nch : 1u) * WVS_CH_WORDS * 4u, scope_k0_matrix(colorspace), dst, st};
-	return wvs_pick(tn.wvs_unroll, tn.nt_loads, fuse_k0, &a);
+	if (nch == 0)
+		return hipErrorInvalidValue; /* the C-ABI zero-fills such tables itself */
+	(void)tn;
+	const WvsArgs a = {&fs, strips, bands, nch * WVS_CH_WORDS * 4u, scope_k0_matrix(colorspace), dst, st};
+	return wvs_pick(chmask, fuse_k0, &a);
 }
 
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,

@@ -25,6 +25,19 @@ __device__ __forceinline__ float scope_f2_hi(scope_f2 v)
 }
 
 /* Sum over the 64 lanes of a wave; every lane must be active (uniform control flow). */
+/* Streaming (non-temporal) load of one dword at `row + lane_off`, where `row` is wave-uniform.  The row
+ * pointer is pinned into SGPRs and the access is typed as global memory so that the load uses the
+ * scalar-base + 32-bit lane-offset addressing form: no 64-bit per-lane address arithmetic. */
+__device__ __forceinline__ unsigned scope_load_row_nt(const unsigned char *row, unsigned lane_off)
+{
+	typedef const __attribute__((address_space(1))) unsigned char *gptr;
+	const unsigned long long a = (unsigned long long)row;
+	const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+	const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+	gptr base = (gptr)(((unsigned long long)hi << 32) | lo);
+	return __builtin_nontemporal_load((const __attribute__((address_space(1))) unsigned *)(base + lane_off));
+}
+
 __device__ __forceinline__ unsigned scope_wave_sum(unsigned x)
 {
 #pragma unroll

@@ -28,6 +28,11 @@ static inline scope_f2 operator*(scope_f2 a, scope_f2 b)
 	return scope_f2{a.x * b.x, a.y * b.y};
 }
 /* the emulated wave has one active lane */
+static inline unsigned scope_load_row_nt(const unsigned char *row, unsigned lane_off)
+{
+	return *(const unsigned *)(row + lane_off);
+}
+
 static inline unsigned scope_wave_sum(unsigned x)
 {
 	return x;

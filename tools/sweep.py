@@ -195,6 +195,24 @@ def main():
     k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(one, 0x07, wtab[0], sync=False))
     report("wvs_single", k, wall, l, 1, 256 * W * 4, dist="uniform")
 
+    # ---- G: the plugin's situation: ONE pageable host plane per synchronous call (PCIe-inclusive) -----------
+    import numpy as np
+
+    host_yuv = data["uniform"][1][0].cpu().numpy()
+    host_rgb = data["uniform"][0][0].cpu().numpy()
+    for name, fn in (("vectorscope", lambda: ctx.vectorscope(yuv=host_yuv, width=W)),
+                     ("waveform_rgb", lambda: ctx.waveform(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07)),
+                     ("histogram_rgb", lambda: ctx.histogram(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07))):
+        for _ in range(3):
+            fn()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            fn()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        emit(dict(tag="host_call", scope=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1),
+                  gpix=round(W * H / (ms * 1e-3) / 1e9, 2), note="pageable host plane in, table out, synchronous"))
+
     out.close()
     ctx.close()
 
