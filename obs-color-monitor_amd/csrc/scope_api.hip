@@ -270,12 +270,12 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 		if (bands > 1 && ((table & 15u) || (((uintptr_t)dst) & 15u)))
 			bands = 1;
 		if (bands == 1) {
-			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->num_cu, ctx->tn, ctx->stream));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * bands * table);
 			if (st)
 				return st;
-			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, bands, chmask, fuse, colorspace, ctx->partial, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, bands, chmask, fuse, colorspace, ctx->partial, ctx->num_cu, ctx->tn, ctx->stream));
 			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, bands, table, ctx->stream));
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
@@ -458,7 +458,8 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.vss_hash = 0;
 	ctx->tn.vss_groups_log2 = 3;
 	ctx->tn.his_unroll = 2;
-	ctx->tn.wvs_unroll = 4;
+	ctx->tn.wvs_wide = 1;
+	ctx->tn.wvs_persist = 1;
 	ctx->tn.nt_loads = 1;
 	ctx->err[0] = 0;
 	*out = ctx;
@@ -544,8 +545,10 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.nt_loads = value;
 	else if (!strcmp(key, "his.unroll"))
 		ctx->tn.his_unroll = value;
-	else if (!strcmp(key, "wvs.unroll"))
-		ctx->tn.wvs_unroll = value;
+	else if (!strcmp(key, "wvs.persist"))
+		ctx->tn.wvs_persist = value != 0;
+	else if (!strcmp(key, "wvs.wide"))
+		ctx->tn.wvs_wide = value != 0;
 	else if (!strcmp(key, "slices"))
 		ctx->slices_override = value;
 	else

@@ -21,6 +21,7 @@
 #define SCOPE_HIS_WORDS 1024u    /* HI_SIZE * 4, src/histogram.c:20 */
 #define SCOPE_WVS_ROWS 256u       /* WV_SIZE, src/waveform.c:20 */
 #define SCOPE_BLOCK 1024         /* threads per workgroup of every accumulation kernel */
+#define SCOPE_CU_LDS_BYTES 163840u /* gfx950: 160 KiB per CU */
 #define SCOPE_WVS_STRIP 64u      /* columns owned by one waveform workgroup (= one wave wide) */
 
 /* A batch of same-geometry BGRA8 planes resident in HBM. */
@@ -47,7 +48,8 @@ struct ScopeTuning {
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3 */
 	int his_unroll;      /* 2 or 4 */
-	int wvs_unroll;      /* rows per lane per batch (two batches in flight): 4 or 8 */
+	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
+	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */
 	int nt_loads;        /* 1: non-temporal pixel loads */
 };
 
@@ -74,7 +76,7 @@ hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t c
 /* K2.  dst = uint8[n_frames][bands][256][width][4]; combine with scope_launch_sat_reduce when
  * bands > 1.  chmask as above (bit c -> byte c of the output texel). */
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint8_t *dst, const ScopeTuning &tn, hipStream_t st);
+			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256). */
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,

@@ -20,6 +20,7 @@
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (K0 must not be FMA-contracted).
  */
 #include "scope_kernels.h"
+#include <type_traits>
 #include <scope_vec.h>
 
 typedef uint32_t u32;
@@ -557,13 +558,71 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
  * ---------------------------------------------------------------------------------------- */
 
 #define WVS_CH_WORDS 8192u
-#define WVS_U 4 /* rows per lane per batch; two batches in flight */
+#define WVS_U 4 /* row pairs per wave per batch; two batches in flight */
 
-/* CH = which bytes of the texel are counted (bit c -> byte c), a compile-time constant so that the
- * per-pixel code has no channel branches.  Everything about a row is wave-uniform (a wave reads one
- * row segment at a time), so row pointers and the row-validity tests live in SGPRs / scalar branches;
- * per lane there is only the column offset, the alpha test and the atomics. */
-template <int CH, bool FUSE>
+/* Counter of (value, column c of the strip): 16-bit half (c & 1) of word value*32 + (c >> 1).
+ *
+ * A wave reads TWO rows at a time: lanes 0-31 the first, lanes 32-63 the second, each lane two adjacent
+ * texels (one 8-byte load when WIDE).  One atomic instruction therefore touches, per 32-lane half, 32
+ * different words of one 32-word group = 32 different banks whatever the pixel values are; the two
+ * halves go through the LDS in separate passes.  Conflict-free by construction.
+ *
+ * CH = which bytes of the texel are counted (bit c -> byte c), a compile-time constant so that the
+ * per-pixel code has no channel branches.  Row-pair pointers and validity are wave-uniform (SGPRs,
+ * scalar branches); per lane there is one constant 32-bit offset, the alpha tests and the atomics.
+ * WIDE needs width % 4 == 0, 8-byte aligned rows and a 16-byte aligned table; otherwise texels are
+ * loaded and stored one by one. */
+template <int CH> __device__ __forceinline__ void wvs_count(u32 *tab, u32 px, u32 wbyte, u32 inc)
+{
+	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1);
+	uint8_t *t = (uint8_t *)tab + wbyte;
+	if (CH & 1)
+		atomicAdd((u32 *)(t + ((px & 0xffu) << 7)), inc);
+	if (CH & 2)
+		atomicAdd((u32 *)(t + slot1 * WVS_CH_WORDS * 4u + (((px >> 8) & 0xffu) << 7)), inc);
+	if (CH & 4)
+		atomicAdd((u32 *)(t + slot2 * WVS_CH_WORDS * 4u + (((px >> 16) & 0xffu) << 7)), inc);
+}
+
+/* One (frame, band, strip) unit as a wave sees it; everything here is wave-uniform. */
+struct WvsUnit {
+	const uint8_t *rows; /* first row of the band (always a readable address) */
+	u32 frame, band, strip;
+	u32 nrows;  /* rows in the band */
+	u32 npairs; /* row pairs = nrows / 2; an odd last row is handled apart */
+	u32 slots;  /* batches per wave, rounded up to an even number >= 2 (slots past the data load nothing useful) */
+};
+
+__device__ __forceinline__ WvsUnit wvs_unit(const ScopeFrameSet &fs, u32 unit, u32 total, u32 strips, u32 bands,
+					    u32 nwaves)
+{
+	WvsUnit u;
+	if (unit >= total) { /* past the end: two empty slots */
+		u.rows = fs.plane[0];
+		u.frame = u.band = u.strip = u.nrows = u.npairs = 0;
+		u.slots = 2;
+		return u;
+	}
+	const u32 per_frame = strips * bands;
+	u.frame = unit / per_frame;
+	const u32 rem = unit - u.frame * per_frame;
+	u.band = rem / strips;
+	u.strip = rem - u.band * strips;
+	const u32 r0 = scope_slice_begin(fs.height, u.band, bands);
+	u.nrows = scope_slice_begin(fs.height, u.band + 1, bands) - r0;
+	u.rows = fs.plane[u.frame] + (size_t)r0 * fs.linesize;
+	u.npairs = u.nrows >> 1;
+	const u32 nbatch = (u.npairs + WVS_U - 1) / WVS_U;
+	u.slots = max(2u, ((nbatch + nwaves - 1) / nwaves + 1u) & ~1u);
+	return u;
+}
+
+/* Persistent workgroups: workgroup g takes units g, g + gridDim.x, ...  The loads of a wave form ONE
+ * stream over all its units -- the first batches of the next unit are issued before the current unit's
+ * table is flushed and stay in flight across the flush and the zero-fill -- so the memory pipeline does
+ * not drain at every unit boundary (a unit is only ~0.5 MB).  Batch n of a unit = row pairs 4n..4n+3;
+ * wave w takes batches w, w + nwaves, ... */
+template <int CH, bool FUSE, bool WIDE>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, ScopeK0 k0,
 							       uint8_t *dst)
 {
@@ -572,52 +631,57 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 	constexpr bool need_uv = (CH & 5) != 0, need_y = (CH & 2) != 0;
 
 	u32 *tab = scope_lds;
-	const u32 unit = blockIdx.x;
-	const u32 per_frame = strips * bands;
-	const u32 frame = unit / per_frame;
-	const u32 rem = unit - frame * per_frame;
-	const u32 band = rem / strips;
-	const u32 strip = rem - band * strips;
-	const uint8_t *plane = fs.plane[frame];
 	const u32 W = fs.width;
-
-	const uint4 zero = make_uint4(0, 0, 0, 0);
-	for (u32 i = threadIdx.x * 4; i < nch * WVS_CH_WORDS; i += blockDim.x * 4)
-		*(uint4 *)&tab[i] = zero;
-	__syncthreads();
-
+	const u32 total = fs.n_frames * strips * bands;
 	const u32 lane = threadIdx.x & 63u;
+	const u32 pair = lane & 31u;  /* columns 2*pair, 2*pair+1 of the strip */
+	const u32 second = lane >> 5; /* which row of the row pair */
 	const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const u32 nwaves = blockDim.x >> 6;
-	const u32 x = strip * SCOPE_WVS_STRIP + lane;
-	const bool live = x < W; /* lanes past the right edge read the strip's first column and bin nothing */
-	const u32 r0 = scope_slice_begin(fs.height, band, bands);
-	const u32 r1 = scope_slice_begin(fs.height, band + 1, bands);
-	const u32 rep = lane & 31u;
-	const u32 inc = (lane < 32u) ? 1u : 65536u;
+	const u32 wbyte = pair << 2;
+	const u32 second_off = second * fs.linesize;
+	const size_t pair_bytes = (size_t)2u * fs.linesize;
 
-	/* wave w takes rows r0+w, r0+w+nwaves, ...: `mine` rows, numbered 0.. in that order */
-	const u32 mine = (r1 - r0 > wave) ? (r1 - r0 - wave + nwaves - 1) / nwaves : 0;
-	if (mine) {
-		const uint8_t *row = plane + (size_t)(r0 + wave) * fs.linesize; /* wave-uniform */
-		const size_t row_step = (size_t)nwaves * fs.linesize;
-		const u32 lane_off = (live ? x : strip * SCOPE_WVS_STRIP) * 4u;
-		u32 va[U], vb[U];
-		bool oka[U], okb[U];
-		u32 next = 0;
-		const uint8_t *cur = row;
+	/* ---- issue side: where the wave's load stream is ------------------------------------------ */
+	u32 unit_i = blockIdx.x, slot_i = 0;
+	WvsUnit ui = wvs_unit(fs, unit_i, total, strips, bands, nwaves);
+	u32 lo0 = 0, lo1 = 0; /* per-lane byte offsets inside a row pair of the issue-side unit */
+#define WVS_LANE_OFFSETS()                                                                                    \
+	do {                                                                                                  \
+		const u32 xs_ = ui.strip * SCOPE_WVS_STRIP, x0_ = xs_ + 2u * pair;                            \
+		lo0 = ((x0_ < W) ? x0_ : xs_) * 4u + second_off;                                              \
+		lo1 = ((x0_ + 1u < W) ? x0_ + 1u : xs_) * 4u + second_off;                                    \
+	} while (0)
+	WVS_LANE_OFFSETS();
 
-		/* unconditional loads (rows past the end re-read row 0) keep the vmcnt bookkeeping exact and the
-		 * two register sets are used ping-pong: see scope_stream */
+	u32 va[U][2], vb[U][2];
+	bool oka[U], okb[U];
+
+	/* Unconditional loads keep the vmcnt bookkeeping exact (see scope_stream); a slot past the data reads
+	 * the 8 bytes at the band's first texel with every lane, i.e. one cache line. */
 #define WVS_ISSUE(v, ok)                                                                                      \
 	do {                                                                                                  \
+		if (slot_i == ui.slots) {                                                                     \
+			unit_i += gridDim.x;                                                                  \
+			slot_i = 0;                                                                           \
+			ui = wvs_unit(fs, unit_i, total, strips, bands, nwaves);                              \
+			WVS_LANE_OFFSETS();                                                                   \
+		}                                                                                             \
+		const u32 first_ = (wave + slot_i * nwaves) * (u32)U;                                         \
 		_Pragma("unroll") for (int k = 0; k < U; k++)                                                 \
 		{                                                                                             \
-			ok[k] = next + (u32)k < mine;                                                         \
-			v[k] = scope_load_row_nt(ok[k] ? cur : row, lane_off);                                \
-			cur += row_step;                                                                      \
+			ok[k] = first_ + (u32)k < ui.npairs;                                                  \
+			const uint8_t *p_ = ui.rows + (ok[k] ? (size_t)(first_ + (u32)k) * pair_bytes : (size_t)0); \
+			if (WIDE) {                                                                           \
+				const scope_u2 t_ = scope_load_row2_nt(p_, ok[k] ? lo0 : 0u);                 \
+				v[k][0] = t_.x;                                                               \
+				v[k][1] = t_.y;                                                               \
+			} else {                                                                              \
+				v[k][0] = scope_load_row_nt(p_, ok[k] ? lo0 : 0u);                            \
+				v[k][1] = scope_load_row_nt(p_, ok[k] ? lo1 : 0u);                            \
+			}                                                                                     \
 		}                                                                                             \
-		next += (u32)U;                                                                               \
+		slot_i++;                                                                                     \
 	} while (0)
 #define WVS_BIN(v, ok)                                                                                        \
 	do {                                                                                                  \
@@ -625,74 +689,129 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 		{                                                                                             \
 			if (!ok[k])                                                                           \
 				continue;                                                                     \
-			u32 px = v[k];                                                                        \
-			if (FUSE)                                                                             \
-				px = scope_k0_texel(px, k0, need_uv, need_y);                                 \
-			if (live && (px >> 24) != 0) { /* src/waveform.c:247-248 */                           \
-				if (CH & 1)                                                                   \
-					atomicAdd(&tab[slot0 * WVS_CH_WORDS + ((px & 0xffu) << 5) + rep], inc); \
-				if (CH & 2)                                                                   \
-					atomicAdd(&tab[slot1 * WVS_CH_WORDS + (((px >> 8) & 0xffu) << 5) + rep], inc); \
-				if (CH & 4)                                                                   \
-					atomicAdd(&tab[slot2 * WVS_CH_WORDS + (((px >> 16) & 0xffu) << 5) + rep], inc); \
+			u32 p0 = v[k][0], p1 = v[k][1];                                                       \
+			if (FUSE) {                                                                           \
+				p0 = scope_k0_texel(p0, k0, need_uv, need_y);                                 \
+				p1 = scope_k0_texel(p1, k0, need_uv, need_y);                                 \
 			}                                                                                     \
+			if (live0 && (p0 >> 24) != 0) /* src/waveform.c:247-248 */                            \
+				wvs_count<CH>(tab, p0, wbyte, 1u);                                            \
+			if (live1 && (p1 >> 24) != 0)                                                         \
+				wvs_count<CH>(tab, p1, wbyte, 65536u);                                        \
 		}                                                                                             \
 	} while (0)
 
-		const u32 batches = (mine + (u32)U - 1) / (u32)U;
-		WVS_ISSUE(va, oka);
-		for (u32 b = 0; b < batches; b += 2) {
-			WVS_ISSUE(vb, okb);
+	WVS_ISSUE(va, oka);
+	WVS_ISSUE(vb, okb);
+
+	/* ---- bin side: one unit at a time, two slots behind the load stream ------------------------
+	 * `steady` = a flush precedes this unit.  Its stores were issued AFTER the two batches now in flight, so
+	 * with the first slot pair peeled the compiler can count them (vmcnt(11..8) instead of (7..4)) and the
+	 * wave does not wait for the table write-out before it goes on binning. */
+	auto run_unit = [&](const u32 unit_b, auto steady) {
+		const WvsUnit ub = wvs_unit(fs, unit_b, total, strips, bands, nwaves);
+		const u32 xs = ub.strip * SCOPE_WVS_STRIP; /* always < W */
+		const u32 x0 = xs + 2u * pair;
+		const bool live0 = x0 < W, live1 = x0 + 1u < W;
+
+		const uint4 zero = make_uint4(0, 0, 0, 0);
+		for (u32 i = threadIdx.x * 4; i < nch * WVS_CH_WORDS; i += blockDim.x * 4)
+			*(uint4 *)&tab[i] = zero;
+		__syncthreads();
+
+		u32 sl = 0;
+		if (decltype(steady)::value) {
 			WVS_BIN(va, oka);
 			WVS_ISSUE(va, oka);
-			if (b + 1 < batches)
-				WVS_BIN(vb, okb);
+			WVS_BIN(vb, okb);
+			WVS_ISSUE(vb, okb);
+			sl = 2;
 		}
+		for (; sl < ub.slots; sl += 2) {
+			WVS_BIN(va, oka);
+			WVS_ISSUE(va, oka);
+			WVS_BIN(vb, okb);
+			WVS_ISSUE(vb, okb);
+		}
+		/* an odd last row of the band: first half of wave 0 */
+		if ((ub.nrows & 1u) && wave == 0 && second == 0) {
+			const uint8_t *p = ub.rows + (size_t)(ub.nrows - 1u) * fs.linesize;
+			u32 p0 = *(const u32 *)(p + (live0 ? x0 : xs) * 4u), p1 = *(const u32 *)(p + (live1 ? x0 + 1u : xs) * 4u);
+			if (FUSE) {
+				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
+				p1 = scope_k0_texel(p1, k0, need_uv, need_y);
+			}
+			if (live0 && (p0 >> 24) != 0)
+				wvs_count<CH>(tab, p0, wbyte, 1u);
+			if (live1 && (p1 >> 24) != 0)
+				wvs_count<CH>(tab, p1, wbyte, 65536u);
+		}
+		__syncthreads();
+
+		/* flush: lane -> 4 adjacent columns of one output row (255 - value), 16 B per store.
+		 * Output texel bytes B,G,R,X = channels 0,1,2 and 0 (src/waveform.c:250-254; X never written).
+		 * Streaming (nt) stores: the table is not read again here and must not displace the frames in L2. */
+		uint8_t *table = dst + ((size_t)ub.frame * bands + ub.band) * ((size_t)SCOPE_WVS_ROWS * W * 4);
+		const u32 xg = threadIdx.x & 15u; /* columns 4*xg .. 4*xg+3 of the strip = words 2*xg, 2*xg+1 */
+		auto gather = [&](u32 value, u32 g, u32(&o)[4]) {
+			o[0] = o[1] = o[2] = o[3] = 0;
+			if (CH & 1) {
+				const uint2 c = *(const uint2 *)&tab[slot0 * WVS_CH_WORDS + (value << 5) + 2u * g];
+				o[0] |= min(c.x & 0xffffu, 255u);
+				o[1] |= min(c.x >> 16, 255u);
+				o[2] |= min(c.y & 0xffffu, 255u);
+				o[3] |= min(c.y >> 16, 255u);
+			}
+			if (CH & 2) {
+				const uint2 c = *(const uint2 *)&tab[slot1 * WVS_CH_WORDS + (value << 5) + 2u * g];
+				o[0] |= min(c.x & 0xffffu, 255u) << 8;
+				o[1] |= min(c.x >> 16, 255u) << 8;
+				o[2] |= min(c.y & 0xffffu, 255u) << 8;
+				o[3] |= min(c.y >> 16, 255u) << 8;
+			}
+			if (CH & 4) {
+				const uint2 c = *(const uint2 *)&tab[slot2 * WVS_CH_WORDS + (value << 5) + 2u * g];
+				o[0] |= min(c.x & 0xffffu, 255u) << 16;
+				o[1] |= min(c.x >> 16, 255u) << 16;
+				o[2] |= min(c.y & 0xffffu, 255u) << 16;
+				o[3] |= min(c.y >> 16, 255u) << 16;
+			}
+		};
+		if (WIDE) {
+			/* width % 4 == 0 and a 16-byte aligned table: a fixed number of unconditional vector stores per
+			 * lane (lanes past the right edge repeat the strip's last column group), so the waits of the
+			 * next unit's first batch can be counted exactly and do not include these stores. */
+			const u32 groups = (min(W - xs, SCOPE_WVS_STRIP)) >> 2;
+			const u32 g = min(xg, groups - 1u);
+			scope_v4 *ocol = (scope_v4 *)(table + (size_t)(xs + (g << 2)) * 4);
+#pragma unroll
+			for (u32 i = 0; i < 256u / (SCOPE_BLOCK / 16u); i++) {
+				const u32 value = (threadIdx.x >> 4) + i * (SCOPE_BLOCK / 16u);
+				u32 o[4];
+				gather(value, g, o);
+				const scope_v4 t = {o[0], o[1], o[2], o[3]};
+				__builtin_nontemporal_store(t, ocol + (size_t)(255u - value) * (W >> 2));
+			}
+		} else {
+			const u32 xo = xs + (xg << 2);
+			for (u32 value = threadIdx.x >> 4; value < 256u; value += blockDim.x >> 4) {
+				u32 o[4];
+				gather(value, xg, o);
+				u32 *orow = (u32 *)(table + ((size_t)(255u - value) * W + xo) * 4);
+				for (u32 j = 0; j < 4; j++)
+					if (xo + j < W)
+						orow[j] = o[j];
+			}
+		}
+		__syncthreads(); /* the table is zeroed again next */
+	};
+	u32 unit_b = blockIdx.x; /* < total: the grid never exceeds the unit count */
+	run_unit(unit_b, std::false_type());
+	for (unit_b += gridDim.x; unit_b < total; unit_b += gridDim.x)
+		run_unit(unit_b, std::true_type());
 #undef WVS_ISSUE
 #undef WVS_BIN
-	}
-	__syncthreads();
-
-	/* flush: lane -> 4 adjacent columns of one output row (255 - value), 16 B per store.
-	 * Output texel bytes B,G,R,X = channels 0,1,2 and 0 (src/waveform.c:250-254; X never written). */
-	uint8_t *table = dst + ((size_t)frame * bands + band) * ((size_t)SCOPE_WVS_ROWS * W * 4);
-	const u32 xg = threadIdx.x & 15u; /* columns 4*xg .. 4*xg+3 of the strip */
-	const u32 shift = (xg >= 8u) ? 16u : 0u;
-	const u32 woff = (xg & 7u) << 2;
-	const u32 xo = strip * SCOPE_WVS_STRIP + (xg << 2);
-	const bool vec_ok = ((W & 3u) == 0) && ((((size_t)table) & 15u) == 0);
-	for (u32 value = threadIdx.x >> 4; value < 256u; value += blockDim.x >> 4) {
-		u32 o[4] = {0, 0, 0, 0};
-		if (CH & 1) {
-			const uint4 c = *(const uint4 *)&tab[slot0 * WVS_CH_WORDS + (value << 5) + woff];
-			o[0] |= min((c.x >> shift) & 0xffffu, 255u);
-			o[1] |= min((c.y >> shift) & 0xffffu, 255u);
-			o[2] |= min((c.z >> shift) & 0xffffu, 255u);
-			o[3] |= min((c.w >> shift) & 0xffffu, 255u);
-		}
-		if (CH & 2) {
-			const uint4 c = *(const uint4 *)&tab[slot1 * WVS_CH_WORDS + (value << 5) + woff];
-			o[0] |= min((c.x >> shift) & 0xffffu, 255u) << 8;
-			o[1] |= min((c.y >> shift) & 0xffffu, 255u) << 8;
-			o[2] |= min((c.z >> shift) & 0xffffu, 255u) << 8;
-			o[3] |= min((c.w >> shift) & 0xffffu, 255u) << 8;
-		}
-		if (CH & 4) {
-			const uint4 c = *(const uint4 *)&tab[slot2 * WVS_CH_WORDS + (value << 5) + woff];
-			o[0] |= min((c.x >> shift) & 0xffffu, 255u) << 16;
-			o[1] |= min((c.y >> shift) & 0xffffu, 255u) << 16;
-			o[2] |= min((c.z >> shift) & 0xffffu, 255u) << 16;
-			o[3] |= min((c.w >> shift) & 0xffffu, 255u) << 16;
-		}
-		u32 *orow = (u32 *)(table + ((size_t)(255u - value) * W + xo) * 4);
-		if (vec_ok && xo + 3 < W) {
-			*(uint4 *)orow = make_uint4(o[0], o[1], o[2], o[3]);
-		} else {
-			for (u32 j = 0; j < 4; j++)
-				if (xo + j < W)
-					orow[j] = o[j];
-		}
-	}
+#undef WVS_LANE_OFFSETS
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -921,42 +1040,44 @@ hipError_t his_pick(int unroll, int nt, int fuse, const HisArgs *a)
 
 struct WvsArgs {
 	const ScopeFrameSet *fs;
-	u32 strips, bands, lds;
+	u32 strips, bands, lds, grid;
 	ScopeK0 k0;
 	uint8_t *dst;
 	hipStream_t st;
 };
 
-template <int CH, bool FUSE> hipError_t wvs_variant(const WvsArgs *a)
+template <int CH, bool FUSE, bool WIDE> hipError_t wvs_variant(const WvsArgs *a)
 {
 	if (!a)
-		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-					   (int)WVS_LDS_BYTES);
-	hipLaunchKernelGGL((scope_wvs_kernel<CH, FUSE>), dim3(a->fs->n_frames * a->strips * a->bands), dim3(SCOPE_BLOCK),
-			   a->lds, a->st, *a->fs, a->strips, a->bands, a->k0, a->dst);
+		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE, WIDE>,
+					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WVS_LDS_BYTES);
+	hipLaunchKernelGGL((scope_wvs_kernel<CH, FUSE, WIDE>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, *a->fs,
+			   a->strips, a->bands, a->k0, a->dst);
 	return hipGetLastError();
 }
-template <int CH> hipError_t wvs_pick_fuse(int fuse, const WvsArgs *a)
+template <int CH> hipError_t wvs_pick_shape(int fuse, int wide, const WvsArgs *a)
 {
-	return fuse ? wvs_variant<CH, true>(a) : wvs_variant<CH, false>(a);
+	if (fuse)
+		return wide ? wvs_variant<CH, true, true>(a) : wvs_variant<CH, true, false>(a);
+	return wide ? wvs_variant<CH, false, true>(a) : wvs_variant<CH, false, false>(a);
 }
-hipError_t wvs_pick(u32 chmask, int fuse, const WvsArgs *a)
+hipError_t wvs_pick(u32 chmask, int fuse, int wide, const WvsArgs *a)
 {
 	switch (chmask & 7u) {
 	case 1:
-		return wvs_pick_fuse<1>(fuse, a);
+		return wvs_pick_shape<1>(fuse, wide, a);
 	case 2:
-		return wvs_pick_fuse<2>(fuse, a);
+		return wvs_pick_shape<2>(fuse, wide, a);
 	case 3:
-		return wvs_pick_fuse<3>(fuse, a);
+		return wvs_pick_shape<3>(fuse, wide, a);
 	case 4:
-		return wvs_pick_fuse<4>(fuse, a);
+		return wvs_pick_shape<4>(fuse, wide, a);
 	case 5:
-		return wvs_pick_fuse<5>(fuse, a);
+		return wvs_pick_shape<5>(fuse, wide, a);
 	case 6:
-		return wvs_pick_fuse<6>(fuse, a);
+		return wvs_pick_shape<6>(fuse, wide, a);
 	default:
-		return wvs_pick_fuse<7>(fuse, a);
+		return wvs_pick_shape<7>(fuse, wide, a);
 	}
 }
 
@@ -976,9 +1097,9 @@ hipError_t scope_kernels_init(void)
 					e = his_pick(unroll, nt, fuse, NULL);
 			}
 	for (u32 chmask = 1; chmask <= 7; chmask++)
-		for (int fuse = 0; fuse < 2; fuse++)
+		for (int shape = 0; shape < 4; shape++)
 			if (e == hipSuccess)
-				e = wvs_pick(chmask, fuse, NULL);
+				e = wvs_pick(chmask, shape & 1, shape >> 1, NULL);
 	return e;
 }
 
@@ -1019,15 +1140,24 @@ hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t c
 }
 
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint8_t *dst, const ScopeTuning &tn, hipStream_t st)
+			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st)
 {
 	const u32 strips = (fs.width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
 	const u32 nch = (chmask & 1u) + ((chmask >> 1) & 1u) + ((chmask >> 2) & 1u);
 	if (nch == 0)
 		return hipErrorInvalidValue; /* the C-ABI zero-fills such tables itself */
-	(void)tn;
-	const WvsArgs a = {&fs, strips, bands, nch * WVS_CH_WORDS * 4u, scope_k0_matrix(colorspace), dst, st};
-	return wvs_pick(chmask, fuse_k0, &a);
+	/* The vector path (8-byte texel-pair loads, 16-byte table stores) needs width % 4 == 0, 8-byte aligned
+	 * rows and a 16-byte aligned table; anything else takes the 4-byte path. */
+	int wide = tn.wvs_wide && (fs.width & 3u) == 0 && (fs.linesize & 7u) == 0 && (((size_t)dst) & 15u) == 0;
+	for (u32 f = 0; wide && f < fs.n_frames; f++)
+		wide = (((size_t)fs.plane[f]) & 7u) == 0;
+	/* persistent workgroups: as many as are resident at once (LDS- or thread-limited), each walks units */
+	const u32 lds = nch * WVS_CH_WORDS * 4u;
+	const u32 resident = max(1u, min((u32)(SCOPE_CU_LDS_BYTES / lds), (u32)(2048u / SCOPE_BLOCK))) * max(1u, num_cu);
+	const u32 total = fs.n_frames * strips * bands;
+	const u32 grid = (tn.wvs_persist && total > resident) ? resident : total;
+	const WvsArgs a = {&fs, strips, bands, lds, grid, scope_k0_matrix(colorspace), dst, st};
+	return wvs_pick(chmask, fuse_k0, wide, &a);
 }
 
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,

@@ -38,6 +38,18 @@ __device__ __forceinline__ unsigned scope_load_row_nt(const unsigned char *row, 
 	return __builtin_nontemporal_load((const __attribute__((address_space(1))) unsigned *)(base + lane_off));
 }
 
+/* The same for two adjacent texels (8 bytes, 8-byte aligned). */
+typedef unsigned scope_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ scope_u2 scope_load_row2_nt(const unsigned char *row, unsigned lane_off)
+{
+	typedef const __attribute__((address_space(1))) unsigned char *gptr;
+	const unsigned long long a = (unsigned long long)row;
+	const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+	const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+	gptr base = (gptr)(((unsigned long long)hi << 32) | lo);
+	return __builtin_nontemporal_load((const __attribute__((address_space(1))) scope_u2 *)(base + lane_off));
+}
+
 __device__ __forceinline__ unsigned scope_wave_sum(unsigned x)
 {
 #pragma unroll

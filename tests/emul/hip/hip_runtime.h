@@ -31,6 +31,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) ((void)(*(p) = (v)))
 static inline uint32_t __brev(uint32_t v)
 {
 	uint32_t r = 0;
@@ -40,6 +41,9 @@ static inline uint32_t __brev(uint32_t v)
 }
 
 /* ---- vector / launch types ---------------------------------------------------------------- */
+struct alignas(8) uint2 {
+	uint32_t x, y;
+};
 struct alignas(16) uint4 {
 	uint32_t x, y, z, w;
 };

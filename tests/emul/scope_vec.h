@@ -33,6 +33,15 @@ static inline unsigned scope_load_row_nt(const unsigned char *row, unsigned lane
 	return *(const unsigned *)(row + lane_off);
 }
 
+struct scope_u2 {
+	unsigned x, y;
+};
+static inline scope_u2 scope_load_row2_nt(const unsigned char *row, unsigned lane_off)
+{
+	const unsigned *p = (const unsigned *)(row + lane_off);
+	return scope_u2{p[0], p[1]};
+}
+
 static inline unsigned scope_wave_sum(unsigned x)
 {
 	return x;

@@ -67,8 +67,22 @@ def test_waveform_saturation_and_bands(emul_ctx, oracle):
     with pc.options(emul_ctx, slices=5):  # five row bands -> partial tables + saturating reduce
         pc.check_waveform(emul_ctx, oracle, 64, 600, 2, 0x70)
         pc.check_waveform(emul_ctx, oracle, 66, 40, 1, 0x07)  # width % 4 != 0: single band fallback
-    with pc.options(emul_ctx, **{"wvs.unroll": 4, "nt": 1}):
+    with pc.options(emul_ctx, **{"wvs.wide": 0}):
         pc.check_waveform(emul_ctx, oracle, 70, 100, 5, 0x07)
+    pc.check_waveform(emul_ctx, oracle, 70, 101, 5, 0x07)  # odd row count: the single-row tail
+    pc.check_waveform(emul_ctx, oracle, 71, 33, 1, 0x50)  # odd width: 4-byte loads
+    pc.check_waveform(emul_ctx, oracle, 70, 34, 1, 0x20, 70 * 4 + 4)  # pitch % 8 == 4: 4-byte loads
+    pc.check_waveform(emul_ctx, oracle, 1, 1, 1, 0x07)
+
+
+@pytest.mark.parametrize("persist", [0, 1])
+def test_waveform_unit_walk(emul_ctx, oracle, persist):
+    """More units than resident workgroups: a workgroup walks several (frame, strip) units with one load stream."""
+    with pc.options(emul_ctx, **{"wvs.persist": persist}):
+        pc.check_waveform(emul_ctx, oracle, 130, 21, 9, 0x20)  # 27 units, odd rows, ragged last strip
+        pc.check_waveform(emul_ctx, oracle, 64, 150, 14, 0x07)  # more batches than one slot pair per wave
+        with pc.options(emul_ctx, slices=3):
+            pc.check_waveform(emul_ctx, oracle, 66, 50, 7, 0x05)  # bands of different heights
 
 
 def test_waveform_fused_k0(emul_ctx, oracle):

@@ -92,11 +92,26 @@ def test_component_masks(hip_ctx, oracle, comp):
     pc.check_histogram_counts(hip_ctx, oracle, 330, 77, 5, comp)
 
 
-@pytest.mark.parametrize("unroll", [4, 8])
-def test_waveform_unroll(hip_ctx, oracle, unroll):
-    with pc.options(hip_ctx, **{"wvs.unroll": unroll}):
+@pytest.mark.parametrize("persist", [0, 1])
+def test_waveform_unit_walk(hip_ctx, oracle, persist):
+    """More units than resident workgroups (256 CUs): a workgroup walks several units with one load stream."""
+    with pc.options(hip_ctx, **{"wvs.persist": persist}):
+        pc.check_waveform(hip_ctx, oracle, 3840, 35, 9, 0x07)  # 540 units of 3 channels on 256 CUs
+        pc.check_waveform(hip_ctx, oracle, 3838, 34, 12, 0x20)  # 720 one-channel units, ragged last strip
+        with pc.options(hip_ctx, slices=7):
+            pc.check_waveform(hip_ctx, oracle, 1920, 100, 3, 0x50)  # 630 units, bands of different heights
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_waveform_load_shapes(hip_ctx, oracle, wide):
+    """8-byte texel-pair loads vs 4-byte loads; odd widths / 4-byte pitches take the 4-byte path either way."""
+    with pc.options(hip_ctx, **{"wvs.wide": wide}):
         pc.check_waveform(hip_ctx, oracle, 640, 360, 1, 0x07)
-        pc.check_waveform(hip_ctx, oracle, 64, 700, 3, 0x07)
+        pc.check_waveform(hip_ctx, oracle, 64, 701, 3, 0x07)  # odd row count: the single-row tail
+        pc.check_waveform(hip_ctx, oracle, 331, 77, 5, 0x50)  # odd width
+        pc.check_waveform(hip_ctx, oracle, 330, 78, 5, 0x20, 330 * 4 + 4)  # pitch % 8 == 4
+        pc.check_waveform(hip_ctx, oracle, 2, 1, 1, 0x07)
+        pc.check_waveform(hip_ctx, oracle, 1, 3, 1, 0x07)
 
 
 @pytest.mark.parametrize("cs", [1, 2])

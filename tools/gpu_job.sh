@@ -14,7 +14,7 @@ for s in $stages; do
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; rc=$? ;;
     tests) timeout 900 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; rc=$? ;;
     bench) timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; rc=$? ;;
-    sweep) timeout 900 python tools/sweep.py --out $out/sweep.jsonl > $out/sweep.out 2> $out/sweep.log; rc=$? ;;
+    sweep) timeout 900 python tools/sweep.py $SWEEP_EXTRA --out $out/sweep.jsonl > $out/sweep.out 2> $out/sweep.log; rc=$? ;;
     prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof -o vss -- \
              python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu) > $out/prof.log 2>&1; rc=$? ;;
     lds)   timeout 300 ./tools/lds_atomic_bench > $out/lds_atomic.txt 2>&1; rc=$? ;;
@@ -42,7 +42,7 @@ done
 tail -5 $out/smoke.log $out/tests.log 2>/dev/null
 cat $out/bench.json 2>/dev/null
 tail -3 $out/bench.err 2>/dev/null
-grep -E "vss_batch|ref" $out/sweep.log 2>/dev/null | head -50
+grep -E "${SWEEP_GREP:-vss_batch|ref}" $out/sweep.log 2>/dev/null | head -80
 cat $out/lds_atomic.txt 2>/dev/null
 cat $out/lds_trace.txt 2>/dev/null
 find $out/prof -name "*stats*" 2>/dev/null | head

@@ -48,7 +48,9 @@ def main():
     ap.add_argument("--out", default="gpurun_out/sweep.jsonl")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--sections", default="ABCDEFG", help="which lettered sections to run")
     args = ap.parse_args()
+    sec = args.sections.upper()
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     out = open(args.out, "w")
 
@@ -107,111 +109,120 @@ def main():
         ctx.sync()
 
     # ---- A: vectorscope, batch launch: merge x lane groups x hash x unroll x nt x distribution ---------
-    defaults = {"vss.merge": 3, "vss.unroll": 4, "vss.hash": 0, "vss.groups": 3, "nt": 1}
+    if "A" in sec:
+        defaults = {"vss.merge": 3, "vss.unroll": 4, "vss.hash": 0, "vss.groups": 3, "nt": 1}
 
-    def vss_run(batch, d, **opt):
-        for k, v in {**defaults, **opt}.items():
+        def vss_run(batch, d, **opt):
+            for k, v in {**defaults, **opt}.items():
+                ctx.set_option(k, v)
+            k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
+            report("vss_batch", k, wall, l, n, 65536, dist=d, **{kk.replace("vss.", ""): vv for kk, vv in {**defaults, **opt}.items()})
+
+        for d in dists:
+            rgb, yuv = data[d]
+            batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
+            for merge in (0, 2, 3):
+                for groups in (0, 2, 3):
+                    for hash_ in (0, 1):
+                        for nt in (0, 1):
+                            vss_run(batch, d, **{"vss.merge": merge, "vss.groups": groups, "vss.hash": hash_, "nt": nt})
+            for unroll in (2, 8):
+                vss_run(batch, d, **{"vss.unroll": unroll})
+                vss_run(batch, d, **{"vss.unroll": unroll, "vss.hash": 1, "vss.groups": 2})
+            vss_run(batch, d, **{"vss.merge": 1})
+        for k, v in defaults.items():
             ctx.set_option(k, v)
-        k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
-        report("vss_batch", k, wall, l, n, 65536, dist=d, **{kk.replace("vss.", ""): vv for kk, vv in {**defaults, **opt}.items()})
-
-    for d in dists:
-        rgb, yuv = data[d]
-        batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
-        for merge in (0, 2, 3):
-            for groups in (0, 2, 3):
-                for hash_ in (0, 1):
-                    for nt in (0, 1):
-                        vss_run(batch, d, **{"vss.merge": merge, "vss.groups": groups, "vss.hash": hash_, "nt": nt})
-        for unroll in (2, 8):
-            vss_run(batch, d, **{"vss.unroll": unroll})
-            vss_run(batch, d, **{"vss.unroll": unroll, "vss.hash": 1, "vss.groups": 2})
-        vss_run(batch, d, **{"vss.merge": 1})
-    for k, v in defaults.items():
-        ctx.set_option(k, v)
 
     # ---- B: how many workgroups share a frame (units per launch = frames * slices) ------------------
-    rgb, yuv = data["uniform"]
-    batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
-    for slices in (1, 2, 4, 8, 16, 32, 64):
-        ctx.set_option("slices", slices)
-        k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
-        report("vss_slices", k, wall, l, n, 65536, dist="uniform", slices=slices)
-    ctx.set_option("slices", 0)
+    if "B" in sec:
+        rgb, yuv = data["uniform"]
+        batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
+        for slices in (1, 2, 4, 8, 16, 32, 64):
+            ctx.set_option("slices", slices)
+            k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
+            report("vss_slices", k, wall, l, n, 65536, dist="uniform", slices=slices)
+        ctx.set_option("slices", 0)
 
     # ---- C: one frame per call (the reference's per-callback situation), frames rotate ---------------
-    singles = [ctx.make_device_batch(yuv[i:i + 1], 4 * W, W, H, planes_are_rgb=False) for i in range(n)]
-    for slices in (256, 128, 64, 32):
-        ctx.set_option("slices", slices)
+    if "C" in sec:
+        rgb, yuv = data["uniform"]
+        singles = [ctx.make_device_batch(yuv[i:i + 1], 4 * W, W, H, planes_are_rgb=False) for i in range(n)]
+        for slices in (256, 128, 64, 32):
+            ctx.set_option("slices", slices)
 
-        def run_all():
-            for i in range(n):
-                ctx.vectorscope_batch_dev(singles[i], tab[i], sync=False)
-        k, wall, l = timed(ctx, run_all, reps=3, warm=1)
-        report("vss_single", k, wall, l, n, 65536, dist="uniform", slices=slices)
-    ctx.set_option("slices", 0)
+            def run_all():
+                for i in range(n):
+                    ctx.vectorscope_batch_dev(singles[i], tab[i], sync=False)
+            k, wall, l = timed(ctx, run_all, reps=3, warm=1)
+            report("vss_single", k, wall, l, n, 65536, dist="uniform", slices=slices)
+        ctx.set_option("slices", 0)
 
     # ---- D: fused K0 ---------------------------------------------------------------------------------
-    for d in dists[:2]:
-        rgb, yuv = data[d]
-        batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-        k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch_rgb, tab, sync=False))
-        report("vss_fused_k0", k, wall, l, n, 65536, dist=d)
+    if "D" in sec:
+        for d in dists[:2]:
+            rgb, yuv = data[d]
+            batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+            k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch_rgb, tab, sync=False))
+            report("vss_fused_k0", k, wall, l, n, 65536, dist=d)
 
     # ---- E: histogram ----------------------------------------------------------------------------------
-    cnt = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
-    for d in dists:
-        rgb, yuv = data[d]
-        batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-        for unroll in (2, 4, 8):
-            for nt in (0, 1):
-                ctx.set_option("his.unroll", unroll)
-                ctx.set_option("nt", nt)
-                for comp in (0x07, 0x02):
-                    k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt, sync=False))
-                    report("his_batch", k, wall, l, n, 4096, dist=d, unroll=unroll, nt=nt, comp=hex(comp))
-    ctx.set_option("his.unroll", 2)
-    ctx.set_option("nt", 1)
+    if "E" in sec:
+        cnt = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+        for d in dists:
+            rgb, yuv = data[d]
+            batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+            for unroll in (2, 4, 8):
+                for nt in (0, 1):
+                    ctx.set_option("his.unroll", unroll)
+                    ctx.set_option("nt", nt)
+                    for comp in (0x07, 0x02):
+                        k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt, sync=False))
+                        report("his_batch", k, wall, l, n, 4096, dist=d, unroll=unroll, nt=nt, comp=hex(comp))
+        ctx.set_option("his.unroll", 2)
+        ctx.set_option("nt", 1)
 
     # ---- F: waveform ------------------------------------------------------------------------------------
-    nw = min(n, 16)
-    wtab = torch.empty((nw, 256 * W * 4), dtype=torch.uint8, device="cuda")
-    for d in dists:
-        rgb, yuv = data[d]
-        batch_rgb = ctx.make_device_batch(rgb[:nw], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-        batch_yuv = ctx.make_device_batch(yuv[:nw], 4 * W, W, H, planes_are_rgb=False)
-        for unroll in (4, 8, 16):
-            for nt in (0, 1):
-                ctx.set_option("wvs.unroll", unroll)
-                ctx.set_option("nt", nt)
-                for comp, bt in ((0x07, batch_rgb), (0x04, batch_rgb), (0x20, batch_yuv)):
-                    k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(bt, comp, wtab, sync=False), reps=10)
-                    report("wvs_batch", k, wall, l, nw, 256 * W * 4, dist=d, unroll=unroll, nt=nt, comp=hex(comp))
-    ctx.set_option("wvs.unroll", 4)
-    ctx.set_option("nt", 1)
-    # single-frame waveform (row bands + saturating reduce)
-    rgb, yuv = data["uniform"]
-    one = ctx.make_device_batch(rgb[:1], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-    k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(one, 0x07, wtab[0], sync=False))
-    report("wvs_single", k, wall, l, 1, 256 * W * 4, dist="uniform")
+    if "F" in sec:
+        wtab_all = torch.empty((n, 256 * W * 4), dtype=torch.uint8, device="cuda")
+        for d in dists:
+            rgb, yuv = data[d]
+            for nw in sorted({min(n, 16), n}):
+                wtab = wtab_all[:nw]
+                batch_rgb = ctx.make_device_batch(rgb[:nw], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+                batch_yuv = ctx.make_device_batch(yuv[:nw], 4 * W, W, H, planes_are_rgb=False)
+                for wide, persist in ((0, 1), (1, 0), (1, 1)):
+                    ctx.set_option("wvs.wide", wide)
+                    ctx.set_option("wvs.persist", persist)
+                    for comp, bt in ((0x07, batch_rgb), (0x05, batch_rgb), (0x04, batch_rgb), (0x20, batch_yuv)):
+                        k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(bt, comp, wtab, sync=False), reps=10)
+                        report("wvs_batch", k, wall, l, nw, 256 * W * 4, dist=d, wide=wide, persist=persist, comp=hex(comp))
+        ctx.set_option("wvs.wide", 1)
+        ctx.set_option("wvs.persist", 1)
+        wtab = wtab_all
+        # single-frame waveform (row bands + saturating reduce)
+        rgb, yuv = data["uniform"]
+        one = ctx.make_device_batch(rgb[:1], 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+        k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(one, 0x07, wtab[0], sync=False))
+        report("wvs_single", k, wall, l, 1, 256 * W * 4, dist="uniform")
 
     # ---- G: the plugin's situation: ONE pageable host plane per synchronous call (PCIe-inclusive) -----------
-    import numpy as np
+    if "G" in sec:
+        import numpy as np
 
-    host_yuv = data["uniform"][1][0].cpu().numpy()
-    host_rgb = data["uniform"][0][0].cpu().numpy()
-    for name, fn in (("vectorscope", lambda: ctx.vectorscope(yuv=host_yuv, width=W)),
-                     ("waveform_rgb", lambda: ctx.waveform(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07)),
-                     ("histogram_rgb", lambda: ctx.histogram(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07))):
-        for _ in range(3):
-            fn()
-        t0 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            fn()
-        ms = (time.perf_counter() - t0) / reps * 1e3
-        emit(dict(tag="host_call", scope=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1),
-                  gpix=round(W * H / (ms * 1e-3) / 1e9, 2), note="pageable host plane in, table out, synchronous"))
+        host_yuv = data["uniform"][1][0].cpu().numpy()
+        host_rgb = data["uniform"][0][0].cpu().numpy()
+        for name, fn in (("vectorscope", lambda: ctx.vectorscope(yuv=host_yuv, width=W)),
+                         ("waveform_rgb", lambda: ctx.waveform(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07)),
+                         ("histogram_rgb", lambda: ctx.histogram(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07))):
+            for _ in range(3):
+                fn()
+            t0 = time.perf_counter()
+            reps = 20
+            for _ in range(reps):
+                fn()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            emit(dict(tag="host_call", scope=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1),
+                      gpix=round(W * H / (ms * 1e-3) / 1e9, 2), note="pageable host plane in, table out, synchronous"))
 
     out.close()
     ctx.close()
