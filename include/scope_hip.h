@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SCOPE_ABI_VERSION 1
+#define SCOPE_ABI_VERSION 2
 
 /* ---- status codes (negative errno style) -------------------------------------------------- */
 #define SCOPE_OK 0
@@ -113,6 +113,27 @@ int scope_abi_version(void);
 int scope_convert_rgb_yuv(scope_ctx *ctx, const uint8_t *rgb, uint32_t rgb_linesize, uint8_t *yuv,
 			  uint32_t yuv_linesize, uint32_t width, uint32_t height, int colorspace, uint32_t flags);
 
+/* ---- capture-side pre-steps: target_scale and ROI crop --------------------------------------
+ * Replaces the scaled render + sub-region draw of cm_render_target: the target is rendered at
+ * 1/target_scale of its size (src/common.c:249-250, :141-168) and an ROI source with a valid rectangle
+ * stages only that rectangle, given in SCALED coordinates (:272-282, :202-206; src/roi.c:478-499).
+ * The reference leaves the down-scale to the target source's sampler; here it is pinned to point
+ * sampling at the centre of each scale x scale cell (integer only):
+ *   dst(i, j) = src((x + i) * scale + scale / 2, (y + j) * scale + scale / 2),  i < cx, j < cy.
+ * cx == 0 or cy == 0 selects the whole scaled frame (x, y ignored), which is what the reference does
+ * for a non-ROI source or an invalid rectangle.  SCOPE_EINVAL when scale == 0, the scaled frame is
+ * empty or the rectangle leaves it. */
+struct scope_region {
+	uint32_t scale;        /* target_scale, 1..128 in the reference's UI (src/common.c:123) */
+	uint32_t x, y, cx, cy; /* ROI origin and size in scaled texels */
+};
+/* Size of the staged plane for a width x height target. */
+int scope_region_size(uint32_t width, uint32_t height, const struct scope_region *region, uint32_t *out_width,
+		      uint32_t *out_height);
+/* src and dst are both host or both device (SCOPE_IN_DEVICE); planes of BGRA8 texels. */
+int scope_stage_region(scope_ctx *ctx, const uint8_t *src, uint32_t src_linesize, uint32_t width, uint32_t height,
+		       const struct scope_region *region, uint8_t *dst, uint32_t dst_linesize, uint32_t flags);
+
 /* ---- K1: vectorscope -----------------------------------------------------------------------
  * Replaces vss_draw_vectorscope(dbuf, surface_data) (src/vectorscope.c:217-238).
  * out = uint8[256][256].  Needs sd->yuv_data, or sd->rgb_data with SCOPE_FUSE_K0. */
@@ -186,15 +207,20 @@ void scope_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, i
 typedef struct scope_pipe scope_pipe;
 
 struct scope_pipe_config {
-	uint32_t width, height;
+	uint32_t width, height;  /* of the submitted (full-size) frames */
 	uint32_t depth;          /* frames in flight, 1..16; the reference uses 3 */
 	int colorspace;          /* for the fused K0 */
 	uint32_t wvs_components; /* 0 = no waveform */
 	uint32_t his_components; /* 0 = no histogram */
 	int want_vectorscope;
+	/* target_scale and ROI applied on the GPU after the upload (scope_stage_region semantics).
+	 * region.scale == 0 means 1; the scopes then see the staged size (scope_pipe_size()). */
+	struct scope_region region;
 };
 
 int scope_pipe_create(scope_ctx *ctx, const struct scope_pipe_config *cfg, scope_pipe **out);
+/* Width and height of the plane the scopes reduce (= the waveform table's width). */
+int scope_pipe_size(const scope_pipe *pipe, uint32_t *width, uint32_t *height);
 void scope_pipe_destroy(scope_pipe *pipe);
 /* Enqueue one RGB frame (bytes B,G,R,A).  SCOPE_EAGAIN when `depth` frames are already in flight. */
 int scope_pipe_submit(scope_pipe *pipe, const uint8_t *rgb_host, uint32_t linesize);

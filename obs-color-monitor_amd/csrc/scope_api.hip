@@ -159,6 +159,32 @@ int result_end(scope_ctx *ctx, void *user_out, size_t bytes, uint32_t flags, con
 	return SCOPE_OK;
 }
 
+/* Resolves a scope_region against a width x height target: scale, origin and size of the staged plane. */
+int resolve_region(uint32_t width, uint32_t height, const struct scope_region *r, uint32_t *scale, uint32_t *x,
+		   uint32_t *y, uint32_t *cx, uint32_t *cy)
+{
+	const uint32_t s = (r && r->scale) ? r->scale : 1u;
+	if (r && r->scale == 0 && (r->x | r->y | r->cx | r->cy))
+		return SCOPE_EINVAL;
+	const uint32_t sw = width / s, sh = height / s; /* src/common.c:249-250 */
+	if (sw == 0 || sh == 0)
+		return SCOPE_EINVAL; /* the reference skips the frame, :251-254 */
+	*scale = s;
+	if (!r || r->cx == 0 || r->cy == 0) {
+		*x = *y = 0;
+		*cx = sw;
+		*cy = sh;
+		return SCOPE_OK;
+	}
+	if (r->x >= sw || r->y >= sh || r->cx > sw - r->x || r->cy > sh - r->y)
+		return SCOPE_EINVAL;
+	*x = r->x;
+	*y = r->y;
+	*cx = r->cx;
+	*cy = r->cy;
+	return SCOPE_OK;
+}
+
 int check_flags(scope_ctx *ctx, uint32_t flags)
 {
 	if ((flags & SCOPE_ASYNC) && (flags & (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE)) != (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE))
@@ -596,6 +622,64 @@ int scope_convert_rgb_yuv(scope_ctx *ctx, const uint8_t *rgb, uint32_t rgb_lines
 	return SCOPE_OK;
 }
 
+int scope_region_size(uint32_t width, uint32_t height, const struct scope_region *region, uint32_t *out_width,
+		      uint32_t *out_height)
+{
+	uint32_t s, x, y, cx, cy;
+	if (!region || !out_width || !out_height || region->scale == 0)
+		return SCOPE_EINVAL;
+	const int st = resolve_region(width, height, region, &s, &x, &y, &cx, &cy);
+	if (st)
+		return st;
+	*out_width = cx;
+	*out_height = cy;
+	return SCOPE_OK;
+}
+
+int scope_stage_region(scope_ctx *ctx, const uint8_t *src, uint32_t src_linesize, uint32_t width, uint32_t height,
+		       const struct scope_region *region, uint8_t *dst, uint32_t dst_linesize, uint32_t flags)
+{
+	int st = enter(ctx);
+	if (st)
+		return st;
+	if (!src || !dst || !region || region->scale == 0)
+		return fail(ctx, SCOPE_EINVAL, "NULL argument or scale 0", hipSuccess);
+	st = check_geometry(ctx, src_linesize, width, height);
+	if (st)
+		return st;
+	uint32_t s, x, y, cx, cy;
+	if (resolve_region(width, height, region, &s, &x, &y, &cx, &cy))
+		return fail(ctx, SCOPE_EINVAL, "region outside the scaled frame", hipSuccess);
+	if ((uint64_t)cx * 4 > dst_linesize)
+		return fail(ctx, SCOPE_EINVAL, "dst_linesize < 4*cx", hipSuccess);
+	const size_t first_row = (size_t)y * s + s / 2, first_col = (size_t)x * s + s / 2;
+	if (flags & SCOPE_IN_DEVICE) {
+		if (((uintptr_t)src | (uintptr_t)dst | src_linesize | dst_linesize) & 3u)
+			return fail(ctx, SCOPE_EINVAL, "device planes must be 4-byte aligned", hipSuccess);
+		HIP_TRY(ctx, scope_launch_stage(src + first_row * src_linesize + first_col * 4, (uint64_t)s * src_linesize, s, cx, cy,
+						dst, dst_linesize, ctx->stream));
+		if (!(flags & SCOPE_ASYNC))
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return SCOPE_OK;
+	}
+	/* host planes: only the sampled rows cross PCIe, and of those only the span of sampled columns */
+	const size_t span = ((size_t)(cx - 1) * s + 1) * 4;
+	const size_t pitch = round_up(span, 16);
+	const size_t out_pitch = round_up((size_t)cx * 4, 16);
+	st = grow(ctx, &ctx->stage_in, &ctx->stage_in_bytes, round_up(pitch * cy, 256));
+	if (!st)
+		st = grow(ctx, &ctx->stage_out, &ctx->stage_out_bytes, round_up(out_pitch * cy, 256));
+	if (st)
+		return st;
+	HIP_TRY(ctx, hipMemcpy2DAsync(ctx->stage_in, pitch, src + first_row * src_linesize + first_col * 4,
+				      (size_t)s * src_linesize, span, cy, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, scope_launch_stage(ctx->stage_in, pitch, s, cx, cy, ctx->stage_out, (uint32_t)out_pitch, ctx->stream));
+	HIP_TRY(ctx, hipMemcpy2DAsync(dst, dst_linesize, ctx->stage_out, out_pitch, (size_t)cx * 4, cy, hipMemcpyDeviceToHost,
+				      ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return SCOPE_OK;
+}
+
 int scope_vectorscope(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t flags, uint8_t *out)
 {
 	int st = enter(ctx);
@@ -917,7 +1001,8 @@ int scope_display_histogram(scope_ctx *ctx, const float *tex, const uint32_t *hi
 #define SCOPE_PIPE_MAX_DEPTH 16
 
 struct scope_pipe_slot {
-	uint8_t *dev_rgb;
+	uint8_t *dev_rgb;   /* what crossed PCIe: the frame, or just its sampled rows */
+	uint8_t *dev_stage; /* the scaled / cropped plane (NULL when the region is the whole frame at scale 1) */
 	uint8_t *dev_vss, *dev_wvs;
 	uint32_t *dev_his;
 	uint8_t *host_tables; /* pinned: vss | wvs | his back to back */
@@ -928,6 +1013,9 @@ struct scope_pipe {
 	scope_ctx *ctx;
 	struct scope_pipe_config cfg;
 	size_t pitch, vss_bytes, wvs_bytes, his_bytes;
+	uint32_t scale, rx, ry, rw, rh; /* resolved region: the scopes see an rw x rh plane */
+	size_t span, stage_pitch;       /* bytes of a source row that are uploaded; pitch of dev_stage */
+	bool staged;
 	hipStream_t up, down;
 	scope_pipe_slot slot[SCOPE_PIPE_MAX_DEPTH];
 	uint64_t submitted, collected;
@@ -947,6 +1035,8 @@ void scope_pipe_destroy(scope_pipe *p)
 		scope_pipe_slot *s = &p->slot[i];
 		if (s->dev_rgb)
 			(void)hipFree(s->dev_rgb);
+		if (s->dev_stage)
+			(void)hipFree(s->dev_stage);
 		if (s->dev_vss)
 			(void)hipFree(s->dev_vss);
 		if (s->dev_wvs)
@@ -979,20 +1069,33 @@ int scope_pipe_create(scope_ctx *ctx, const struct scope_pipe_config *cfg, scope
 	st = check_geometry(ctx, cfg->width * 4, cfg->width, cfg->height);
 	if (st)
 		return st;
+	uint32_t rs, rx, ry, rw, rh;
+	if (resolve_region(cfg->width, cfg->height, &cfg->region, &rs, &rx, &ry, &rw, &rh))
+		return fail(ctx, SCOPE_EINVAL, "pipeline region outside the scaled frame", hipSuccess);
 	scope_pipe *p = (scope_pipe *)calloc(1, sizeof *p);
 	if (!p)
 		return SCOPE_ENOMEM;
 	p->ctx = ctx;
 	p->cfg = *cfg;
-	p->pitch = round_up((size_t)cfg->width * 4, 16);
+	p->scale = rs;
+	p->rx = rx;
+	p->ry = ry;
+	p->rw = rw;
+	p->rh = rh;
+	p->staged = rs != 1; /* a pure crop is done by the 2-D upload itself */
+	p->span = ((size_t)(rw - 1) * rs + 1) * 4; /* first to last sampled texel of a row */
+	p->pitch = round_up(p->span, 16);
+	p->stage_pitch = round_up((size_t)rw * 4, 16);
 	p->vss_bytes = cfg->want_vectorscope ? SCOPE_VSS_BINS : 0;
-	p->wvs_bytes = (cfg->wvs_components & 0x77u) ? (size_t)SCOPE_WV_SIZE * cfg->width * 4 : 0;
+	p->wvs_bytes = (cfg->wvs_components & 0x77u) ? (size_t)SCOPE_WV_SIZE * rw * 4 : 0;
 	p->his_bytes = (cfg->his_components & 0x77u) ? SCOPE_HIS_WORDS * sizeof(uint32_t) : 0;
 	bool ok = hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking) == hipSuccess &&
 		  hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking) == hipSuccess;
 	for (uint32_t i = 0; ok && i < cfg->depth; i++) {
 		scope_pipe_slot *s = &p->slot[i];
-		ok = hipMalloc((void **)&s->dev_rgb, round_up(p->pitch * cfg->height, 256)) == hipSuccess;
+		ok = hipMalloc((void **)&s->dev_rgb, round_up(p->pitch * rh, 256)) == hipSuccess;
+		if (ok && p->staged)
+			ok = hipMalloc((void **)&s->dev_stage, round_up(p->stage_pitch * rh, 256)) == hipSuccess;
 		if (ok && p->vss_bytes)
 			ok = hipMalloc((void **)&s->dev_vss, p->vss_bytes) == hipSuccess;
 		if (ok && p->wvs_bytes)
@@ -1013,6 +1116,15 @@ int scope_pipe_create(scope_ctx *ctx, const struct scope_pipe_config *cfg, scope
 	return SCOPE_OK;
 }
 
+int scope_pipe_size(const scope_pipe *p, uint32_t *width, uint32_t *height)
+{
+	if (!p || !width || !height)
+		return SCOPE_EINVAL;
+	*width = p->rw;
+	*height = p->rh;
+	return SCOPE_OK;
+}
+
 int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
 {
 	if (!p || !rgb_host)
@@ -1026,31 +1138,42 @@ int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
 	if (p->submitted - p->collected >= p->cfg.depth)
 		return SCOPE_EAGAIN;
 	scope_pipe_slot *s = &p->slot[p->submitted % p->cfg.depth];
-	const uint32_t w = p->cfg.width, h = p->cfg.height;
+	const uint32_t w = p->rw, h = p->rh;
 	const uint32_t dev_flags = SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE | SCOPE_ASYNC;
 
-	/* upload stream: the RGB plane only -- half the bytes of the reference's RGB+YUV staging surface */
-	HIP_TRY(ctx, hipMemcpy2DAsync(s->dev_rgb, p->pitch, rgb_host, linesize, (size_t)w * 4, h, hipMemcpyHostToDevice, p->up));
+	/* upload stream: the RGB plane only -- half the bytes of the reference's RGB+YUV staging surface -- and of
+	 * it only the rows (and the span of columns) that target_scale / the ROI sample */
+	const uint8_t *first = rgb_host + ((size_t)p->ry * p->scale + p->scale / 2) * linesize +
+			       ((size_t)p->rx * p->scale + p->scale / 2) * 4;
+	HIP_TRY(ctx, hipMemcpy2DAsync(s->dev_rgb, p->pitch, first, (size_t)p->scale * linesize, p->span, h,
+				      hipMemcpyHostToDevice, p->up));
 	HIP_TRY(ctx, hipEventRecord(s->uploaded, p->up));
 
 	/* compute stream: three reductions of the same HBM-resident plane, K0 fused where YUV is needed */
 	HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->uploaded, 0));
 	const uint8_t *plane[1] = {s->dev_rgb};
+	uint32_t pitch = (uint32_t)p->pitch;
+	if (p->staged) {
+		HIP_TRY(ctx, scope_launch_stage(s->dev_rgb, p->pitch, p->scale, w, h, s->dev_stage, (uint32_t)p->stage_pitch,
+						ctx->stream));
+		plane[0] = s->dev_stage;
+		pitch = (uint32_t)p->stage_pitch;
+	}
 	if (p->vss_bytes) {
-		st = run_vectorscope(ctx, plane, 1, (uint32_t)p->pitch, w, h, 1, p->cfg.colorspace, dev_flags, s->dev_vss);
+		st = run_vectorscope(ctx, plane, 1, pitch, w, h, 1, p->cfg.colorspace, dev_flags, s->dev_vss);
 		if (st)
 			return st;
 	}
 	if (p->wvs_bytes) {
 		const uint32_t c = p->cfg.wvs_components;
-		st = run_waveform(ctx, plane, 1, (uint32_t)p->pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace,
+		st = run_waveform(ctx, plane, 1, pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace,
 				  dev_flags, s->dev_wvs);
 		if (st)
 			return st;
 	}
 	if (p->his_bytes) {
 		const uint32_t c = p->cfg.his_components;
-		st = run_histogram(ctx, plane, 1, (uint32_t)p->pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace,
+		st = run_histogram(ctx, plane, 1, pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace,
 				   dev_flags, s->dev_his);
 		if (st)
 			return st;

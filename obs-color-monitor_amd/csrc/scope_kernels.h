@@ -73,6 +73,11 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
 			    uint32_t *dst, const ScopeTuning &tn, hipStream_t st);
 
+/* Capture pre-steps: dst(i, j) = texel at src + j*row_pitch + i*col_step*4, i < cx, j < cy (the caller folds
+ * scale and ROI origin into src / row_pitch / col_step).  All pointers and pitches 4-byte aligned. */
+hipError_t scope_launch_stage(const uint8_t *src, uint64_t row_pitch, uint32_t col_step, uint32_t cx, uint32_t cy,
+			      uint8_t *dst, uint32_t dst_linesize, hipStream_t st);
+
 /* K2.  dst = uint8[n_frames][bands][256][width][4]; combine with scope_launch_sat_reduce when
  * bands > 1.  chmask as above (bit c -> byte c of the output texel). */
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,

@@ -814,6 +814,36 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 #undef WVS_LANE_OFFSETS
 }
 
+/* Capture-side pre-steps: point-sampled 1/scale down-scale and ROI crop in one pass (cm_render_target,
+ * src/common.c:249-250,272-282).  `src` points at the first sampled texel, `row_pitch` is the distance in
+ * bytes between sampled rows and `col_step` the distance in texels between sampled columns.  A lane
+ * produces four adjacent output texels of one row (one 16-byte store when the destination allows it);
+ * only the source rows and cache lines that hold a sampled texel are read. */
+__global__ __launch_bounds__(256) void scope_stage_kernel(const uint8_t *src, u64 row_pitch, u32 col_step, u32 cx, u32 cy,
+							 uint8_t *dst, u32 dst_linesize, u32 vec)
+{
+	const u32 quads = (cx + 3u) >> 2;
+	const u64 cells = (u64)quads * cy;
+	for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (u64)gridDim.x * blockDim.x) {
+		const u32 j = (u32)(c / quads);
+		const u32 i0 = (u32)(c - (u64)j * quads) << 2;
+		const uint8_t *row = src + (size_t)j * row_pitch;
+		uint8_t *orow = dst + (size_t)j * dst_linesize + (size_t)i0 * 4;
+		u32 t[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (u32 k = 0; k < 4; k++)
+			if (i0 + k < cx)
+				t[k] = *(const u32 *)(row + (size_t)(i0 + k) * col_step * 4);
+		if (vec && i0 + 3 < cx) {
+			*(uint4 *)orow = make_uint4(t[0], t[1], t[2], t[3]);
+		} else {
+			for (u32 k = 0; k < 4; k++)
+				if (i0 + k < cx)
+					((u32 *)orow)[k] = t[k];
+		}
+	}
+}
+
 /* ------------------------------------------------------------------------------------------
  * K0 standalone, partial-table reductions, multi-GPU helpers
  * ---------------------------------------------------------------------------------------- */
@@ -1101,6 +1131,21 @@ hipError_t scope_kernels_init(void)
 			if (e == hipSuccess)
 				e = wvs_pick(chmask, shape & 1, shape >> 1, NULL);
 	return e;
+}
+
+hipError_t scope_launch_stage(const uint8_t *src, uint64_t row_pitch, uint32_t col_step, uint32_t cx, uint32_t cy,
+			      uint8_t *dst, uint32_t dst_linesize, hipStream_t st)
+{
+	const u32 vec = ((dst_linesize & 15u) == 0 && (((uintptr_t)dst) & 15u) == 0) ? 1u : 0u;
+	const u64 cells = (u64)((cx + 3u) >> 2) * cy;
+	u32 blocks = (u32)((cells + 255) / 256);
+	if (blocks > 256 * 16)
+		blocks = 256 * 16;
+	if (blocks == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(scope_stage_kernel, dim3(blocks), dim3(256), 0, st, src, (u64)row_pitch, col_step, cx, cy, dst,
+			   dst_linesize, vec);
+	return hipGetLastError();
 }
 
 hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *dst, uint32_t dst_linesize,

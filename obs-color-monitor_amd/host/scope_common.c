@@ -164,6 +164,20 @@ void cm_tick(void *data, float unused)
 		cm_start_thread(src);
 }
 
+/* src/common.c:260-268: the consumer is a full ring behind -> this frame is not staged. */
+static bool drop_if_behind(struct cm_source *src)
+{
+	pthread_mutex_lock(&src->pipeline_mutex);
+	const bool behind = src->i_write_queue == src->i_read_queue;
+	if (behind) {
+		src->i_staging_queue = -1;
+		src->frames_dropped++;
+		pthread_cond_broadcast(&src->pipeline_cond);
+	}
+	pthread_mutex_unlock(&src->pipeline_mutex);
+	return behind;
+}
+
 bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
 		      uint32_t height)
 {
@@ -172,16 +186,9 @@ bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t
 	if (!has_rgb && !has_yuv)
 		return false;
 
-	pthread_mutex_lock(&src->pipeline_mutex);
-	if (src->i_write_queue == src->i_read_queue) { /* consumer a full ring behind: drop, :260-268 */
-		src->i_staging_queue = -1;
-		src->frames_dropped++;
-		pthread_cond_broadcast(&src->pipeline_cond);
-		pthread_mutex_unlock(&src->pipeline_mutex);
+	if (drop_if_behind(src))
 		return false;
-	}
-	const int w = src->i_write_queue; /* the consumer never takes slot i_write_queue */
-	pthread_mutex_unlock(&src->pipeline_mutex);
+	const int w = src->i_write_queue; /* only the producer moves it; the consumer never takes this slot */
 
 	/* src/common.c:272-282: the ROI rectangle, when valid, selects the sub-rectangle that is staged */
 	uint32_t x = 0, y = 0, cx = width, cy = height;
@@ -228,6 +235,61 @@ bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t
 	pthread_cond_broadcast(&src->pipeline_cond);
 	pthread_mutex_unlock(&src->pipeline_mutex);
 	return true;
+}
+
+bool cm_render_target(struct cm_source *src, const uint8_t *target_rgb, uint32_t linesize, uint32_t target_width,
+		      uint32_t target_height)
+{
+	const bool has_rgb = !src->bypass && (src->flags & CM_FLAG_CONVERT_RGB);
+	const bool has_yuv = !src->bypass && (src->flags & CM_FLAG_CONVERT_YUV);
+	if (!has_rgb && !has_yuv)
+		return false;
+	const uint32_t scale = src->target_scale > 0 ? (uint32_t)src->target_scale : 1u;
+	const uint32_t scaled_width = target_width / scale, scaled_height = target_height / scale; /* :249-250 */
+	if (scaled_width == 0 || scaled_height == 0)
+		return false; /* :251-254 */
+
+	if (drop_if_behind(src)) /* before spending GPU time, as the reference does (:260-268) */
+		return false;
+
+	struct scope_region region = {scale, 0, 0, 0, 0};
+	if ((src->flags & CM_FLAG_ROI) && 0 <= src->x0 && src->x0 < src->x1 && 0 <= src->y0 && src->y0 < src->y1 &&
+	    (uint32_t)src->x1 <= scaled_width && (uint32_t)src->y1 <= scaled_height) { /* :272-282 */
+		region.x = (uint32_t)src->x0;
+		region.y = (uint32_t)src->y0;
+		region.cx = (uint32_t)(src->x1 - src->x0);
+		region.cy = (uint32_t)(src->y1 - src->y0);
+	}
+	uint32_t cx, cy;
+	if (scope_region_size(target_width, target_height, &region, &cx, &cy) != SCOPE_OK)
+		return false;
+	const uint32_t out_linesize = cx * 4;
+	const size_t plane = (size_t)out_linesize * cy;
+	uint8_t *stacked = bzalloc(plane * 2);
+	if (!stacked)
+		return false;
+	/* RGB rows first, YUV rows after them -- the staged surface's layout (:284-291) */
+	int st = scope_stage_region(cm_gpu(), target_rgb, linesize, target_width, target_height, &region, stacked,
+				    out_linesize, 0);
+	if (st == SCOPE_OK && has_yuv)
+		st = scope_convert_rgb_yuv(cm_gpu(), stacked, out_linesize, stacked + plane, out_linesize, cx, cy,
+					   src->colorspace, 0);
+	bool staged = false;
+	if (st == SCOPE_OK) {
+		/* the rectangle is already applied: stage the planes as they are */
+		const uint32_t flags = src->flags;
+		src->flags &= ~(uint32_t)CM_FLAG_ROI;
+		if (has_rgb)
+			staged = cm_stage_surface(src, stacked, out_linesize, cx, cy);
+		else { /* YUV only: the surface holds just the YUV rows */
+			staged = cm_stage_surface(src, stacked + plane, out_linesize, cx, cy);
+		}
+		src->flags = flags;
+	} else {
+		blog(LOG_ERROR, "[obs-color-monitor] cm_render_target: %s (%s)", scope_strerror(st), scope_last_error(cm_gpu()));
+	}
+	bfree(stacked);
+	return staged;
 }
 
 void cm_drain(struct cm_source *src)

@@ -93,6 +93,13 @@ void cm_tick(void *data, float unused);                                         
  * consumer is a full ring behind and the frame was dropped (src/common.c:260-268). */
 bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
 		      uint32_t height);
+/* The whole producer half of cm_render_target (src/common.c:223-333) for a host that holds the target's
+ * full-size RGB frame: down-scale by target_scale (:249-250), crop to the ROI rectangle given in scaled
+ * pixels (:272-282), convert the YUV rows (render_rgb_yuv, :170-221) -- all on the GPU through the C-ABI
+ * (scope_stage_region, scope_convert_rgb_yuv) -- and stage the result.  Returns false when nothing was
+ * staged: the scaled size is zero (:251-254), the consumer is a ring behind (:260-268), or the GPU failed. */
+bool cm_render_target(struct cm_source *src, const uint8_t *target_rgb, uint32_t linesize, uint32_t target_width,
+		      uint32_t target_height);
 /* Blocks until every staged surface has been through the callback (test/bench helper). */
 void cm_drain(struct cm_source *src);
 

@@ -441,6 +441,21 @@ static void roi_get_defaults(obs_data_t *settings)
 	obs_data_set_default_int(settings, "roi_y1", -1);
 }
 
+/* The same for a host that holds the full-size RGB target: scale, crop and K0 run on the GPU. */
+bool roi_target_render_full(struct roi_source *src, const uint8_t *target_rgb, uint32_t linesize, uint32_t target_width,
+			    uint32_t target_height)
+{
+	src->interleave_rendered = true;
+	if (src->i_interleave != 0 && src->n_interleave > 0)
+		return true; /* this frame is skipped */
+
+	cm_render_target(&src->cm, target_rgb, linesize, target_width, target_height);
+
+	if (src->n_interleave <= 0)
+		return true;
+	return false;
+}
+
 bool roi_target_render(struct roi_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
 		       uint32_t height)
 {

@@ -88,6 +88,8 @@ void roi_unregister_source(struct roi_source *src, struct cm_source *cm); /* src
 void roi_update_flags(struct roi_source *src);                            /* flag merge of roi_tick, src/roi.c:534-540 */
 /* src/roi.c:266-277 with the host's captured planes in place of the OBS render: stages the frame
  * unless this tick is skipped by interleaving.  Returns what the reference returns. */
+bool roi_target_render_full(struct roi_source *src, const uint8_t *target_rgb, uint32_t linesize, uint32_t target_width,
+			    uint32_t target_height);
 bool roi_target_render(struct roi_source *src, const uint8_t *video_data, uint32_t linesize, uint32_t width,
 		       uint32_t height);
 

@@ -33,7 +33,8 @@ ABI_SYMBOLS = (
     "scope_table_widen_u8_u32", "scope_table_clamp_u32_u8",
     "scope_table_pack_u8_u16x2", "scope_table_unpack_clamp_u16x2_u8",
     "scope_ctx_profile", "scope_ctx_kernel_ms",
-    "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect",
+    "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect", "scope_pipe_size",
+    "scope_region_size", "scope_stage_region",
     "scope_display_vectorscope", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
 )
 
@@ -64,9 +65,16 @@ class Batch(C.Structure):
     ]
 
 
+class Region(C.Structure):
+    """struct scope_region: target_scale and the ROI rectangle in scaled texels (cx or cy == 0: whole frame)."""
+
+    _fields_ = [("scale", C.c_uint32), ("x", C.c_uint32), ("y", C.c_uint32), ("cx", C.c_uint32), ("cy", C.c_uint32)]
+
+
 class PipeConfig(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_uint32), ("colorspace", C.c_int),
-                ("wvs_components", C.c_uint32), ("his_components", C.c_uint32), ("want_vectorscope", C.c_int)]
+                ("wvs_components", C.c_uint32), ("his_components", C.c_uint32), ("want_vectorscope", C.c_int),
+                ("region", Region)]
 
 
 class DeviceInfo(C.Structure):
@@ -128,6 +136,9 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_pipe_destroy": (None, [vp]),
         "scope_pipe_submit": (i32, [vp, vp, u32]),
         "scope_pipe_collect": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "scope_pipe_size": (i32, [vp, C.POINTER(u32), C.POINTER(u32)]),
+        "scope_region_size": (i32, [u32, u32, C.POINTER(Region), C.POINTER(u32), C.POINTER(u32)]),
+        "scope_stage_region": (i32, [vp, vp, u32, u32, u32, C.POINTER(Region), vp, u32, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
@@ -208,6 +219,29 @@ class ScopeContext:
         self._check(self.L.scope_convert_rgb_yuv(self.h, _hptr(rgb), rgb.shape[1], _hptr(out), out.shape[1], width, h,
                                                  colorspace, 0))
         return out
+
+    def region_size(self, width, height, scale, x=0, y=0, cx=0, cy=0):
+        r = Region(scale, x, y, cx, cy)
+        ow, oh = C.c_uint32(), C.c_uint32()
+        st = self.L.scope_region_size(width, height, C.byref(r), C.byref(ow), C.byref(oh))
+        if st != OK:
+            raise ScopeError(st, "bad region")
+        return int(ow.value), int(oh.value)
+
+    def stage_region(self, plane, width, scale, x=0, y=0, cx=0, cy=0, out_linesize=None):
+        """target_scale + ROI crop of a host plane (cm_render_target's pre-steps); returns the staged plane."""
+        h = plane.shape[0]
+        ow, oh = self.region_size(width, h, scale, x, y, cx, cy)
+        out = np.full((oh, out_linesize or ow * 4), 0xA5, dtype=np.uint8)
+        r = Region(scale, x, y, cx, cy)
+        self._check(self.L.scope_stage_region(self.h, _hptr(plane), plane.shape[1], width, h, C.byref(r), _hptr(out),
+                                              out.shape[1], 0))
+        return out
+
+    def stage_region_dev(self, src_dev, src_linesize, width, height, region, dst_dev, dst_linesize, sync=True):
+        r = Region(*region)
+        self._check(self.L.scope_stage_region(self.h, _dptr(src_dev), src_linesize, width, height, C.byref(r),
+                                              _dptr(dst_dev), dst_linesize, IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC)))
 
     def vectorscope(self, yuv=None, rgb=None, width=0, colorspace=2, fuse_k0=False, out=None):
         out = np.full((256, 256), 0xEE, dtype=np.uint8) if out is None else out
@@ -357,12 +391,17 @@ class ScopePipe:
     """scope_pipe: `depth` frames in flight over upload / compute / download streams."""
 
     def __init__(self, ctx: ScopeContext, width, height, depth=3, colorspace=2, wvs_components=COMP_RGB,
-                 his_components=COMP_RGB, want_vectorscope=True):
-        self.ctx, self.w, self.h = ctx, width, height
-        self.cfg = PipeConfig(width, height, depth, colorspace, wvs_components, his_components, int(want_vectorscope))
+                 his_components=COMP_RGB, want_vectorscope=True, region=(0, 0, 0, 0, 0)):
+        """region = (target_scale, x, y, cx, cy); the scopes then see self.w x self.h = the staged size."""
+        self.ctx = ctx
+        self.cfg = PipeConfig(width, height, depth, colorspace, wvs_components, his_components, int(want_vectorscope),
+                              Region(*region))
         h = C.c_void_p()
         ctx._check(ctx.L.scope_pipe_create(ctx.h, C.byref(self.cfg), C.byref(h)))
         self.h_pipe = h
+        ow, oh = C.c_uint32(), C.c_uint32()
+        ctx._check(ctx.L.scope_pipe_size(h, C.byref(ow), C.byref(oh)))
+        self.w, self.h = int(ow.value), int(oh.value)
 
     def close(self):
         if getattr(self, "h_pipe", None):

@@ -259,6 +259,31 @@ static uint32_t disp_n_components(uint32_t components)
 	return n;
 }
 
+int oracle_region_size(uint32_t width, uint32_t height, uint32_t scale, uint32_t *scaled_w, uint32_t *scaled_h)
+{
+	if (scale == 0)
+		return -1;
+	*scaled_w = width / scale; /* src/common.c:249-250 */
+	*scaled_h = height / scale;
+	return 0;
+}
+
+int oracle_stage_region(const uint8_t *src, uint32_t src_linesize, uint32_t width, uint32_t height, uint32_t scale,
+			uint32_t x, uint32_t y, uint32_t cx, uint32_t cy, uint8_t *dst, uint32_t dst_linesize)
+{
+	uint32_t sw, sh;
+	if (oracle_region_size(width, height, scale, &sw, &sh))
+		return -1;
+	if (cx == 0 || cy == 0 || x >= sw || y >= sh || cx > sw - x || cy > sh - y)
+		return -1;
+	for (uint32_t j = 0; j < cy; j++) {
+		const uint8_t *row = src + (size_t)((y + j) * scale + scale / 2) * src_linesize;
+		for (uint32_t i = 0; i < cx; i++)
+			memcpy(dst + (size_t)j * dst_linesize + (size_t)i * 4, row + (size_t)((x + i) * scale + scale / 2) * 4, 4);
+	}
+	return 0;
+}
+
 void oracle_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, int display, uint32_t *out_w,
 			 uint32_t *out_h)
 {

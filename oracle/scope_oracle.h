@@ -87,6 +87,17 @@ void oracle_display_histogram(uint8_t *out, const float *tex, const uint32_t *hi
 void oracle_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, int display, uint32_t *out_w,
 			 uint32_t *out_h);
 
+/* Capture-side pre-steps of cm_render_target: the target is rendered at 1/scale of its size
+ * (src/common.c:249-250, :141-168) and, for an ROI source with a valid rectangle, only the sub-rectangle
+ * (x, y, cx, cy) -- in SCALED coordinates -- is drawn into the staged surface (:272-282, :202-206).
+ * The reference leaves the down-scale to the target source's own sampler; this restatement pins it to
+ * point sampling at the centre of each scale x scale cell:
+ *   dst(i, j) = src((x + i) * scale + scale / 2, (y + j) * scale + scale / 2).
+ * Returns 0, or -1 when scale == 0 or the rectangle is empty / outside the scaled frame. */
+int oracle_region_size(uint32_t width, uint32_t height, uint32_t scale, uint32_t *scaled_w, uint32_t *scaled_h);
+int oracle_stage_region(const uint8_t *src, uint32_t src_linesize, uint32_t width, uint32_t height, uint32_t scale,
+			uint32_t x, uint32_t y, uint32_t cx, uint32_t cy, uint8_t *dst, uint32_t dst_linesize);
+
 /* Deterministic frame generator shared by tests and bench (xorshift64).
  * dist: 1 uniform, 2 concentrated (128 + U{-8..7}), 3 flat (R,G,B)=(0xC6,0xCC,0xD7),
  *       4 eight vertical colour bars, 5 uniform with alpha==0 on a 16x16 checker.

@@ -64,6 +64,9 @@ class COracle:
         L.oracle_display_waveform.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         L.oracle_display_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
         L.oracle_display_size.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.oracle_stage_region.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.oracle_stage_region.restype = C.c_int
         L.oracle_fill_frame.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64]
         L.oracle_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         L.oracle_fnv1a64.restype = C.c_uint64
@@ -125,6 +128,17 @@ class COracle:
         self.lib.oracle_histogram_level(_ptr(tex), _ptr(hi), width, height, components, logscale, level_fixed, level_ratio)
         return tex.view(np.float32).reshape(256, 4), hi
 
+
+    def stage_region(self, plane, width, scale, x=0, y=0, cx=0, cy=0):
+        """Scale + crop of cm_render_target; cx == 0 or cy == 0 selects the whole scaled frame."""
+        h = plane.shape[0]
+        cx = cx or width // scale
+        cy = cy or h // scale
+        out = np.empty((cy, cx * 4), dtype=np.uint8)
+        rc = self.lib.oracle_stage_region(_ptr(plane), plane.shape[1], width, h, scale, x, y, cx, cy, _ptr(out), cx * 4)
+        if rc:
+            raise ValueError("bad region")
+        return out
 
     # -- display shaders D1-D3 -----------------------------------------------------------------
     def display_size(self, base_w, base_h, components, display):
@@ -248,3 +262,14 @@ def np_histogram_counts(rgb, yuv, width, components):
         if components & mask:
             out[:, slot] = np.bincount(t[..., byte][keep], minlength=256)
     return out
+
+
+def np_stage_region(plane, width, scale, x=0, y=0, cx=0, cy=0):
+    """Scale + ROI crop of cm_render_target (src/common.c:249-250,272-282), point-sampled at cell centres."""
+    h = plane.shape[0]
+    cx = cx or width // scale
+    cy = cy or h // scale
+    t = _texels(plane, width)  # [h][width][4]
+    rows = (np.arange(cy) + y) * scale + scale // 2
+    cols = (np.arange(cx) + x) * scale + scale // 2
+    return np.ascontiguousarray(t[rows][:, cols]).reshape(cy, cx * 4)

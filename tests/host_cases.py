@@ -37,6 +37,10 @@ class Host:
         L.scope_host_cm.argtypes = [C.c_void_p]
         L.cm_stage_surface.restype = C.c_bool
         L.cm_stage_surface.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.cm_render_target.restype = C.c_bool
+        L.cm_render_target.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.roi_target_render_full.restype = C.c_bool
+        L.roi_target_render_full.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.cm_drain.argtypes = [C.c_void_p]
         L.roi_register_source.argtypes = [C.c_void_p, C.c_void_p]
         L.roi_unregister_source.argtypes = [C.c_void_p, C.c_void_p]
@@ -74,6 +78,11 @@ class Host:
         """surface: numpy [sheight, linesize] stacked planes."""
         return bool(self.L.cm_stage_surface(self.L.scope_host_cm(obj), surface.ctypes.data_as(C.c_void_p),
                                             surface.shape[1], width, height))
+
+    def render_target(self, obj, target_rgb, width, height):
+        """target_rgb: numpy [height, linesize], the full-size frame OBS would render the target into."""
+        return bool(self.L.cm_render_target(self.L.scope_host_cm(obj), target_rgb.ctypes.data_as(C.c_void_p),
+                                            target_rgb.shape[1], width, height))
 
     def drain(self, obj):
         self.L.cm_drain(self.L.scope_host_cm(obj))
@@ -199,4 +208,41 @@ def run_host_checks(host, oracle, w=96, h=40):
     for obj in (vss, wvs):
         host.L.roi_unregister_source(roi, host.L.scope_host_cm(obj))
     for info_, obj in ((vinfo, vss), (winfo, wvs), (roi_info, roi)):
+        info_.destroy(obj)
+
+    # -- the whole producer half on a full-size target: target_scale, ROI, K0 on the GPU (common.c:223-333) ----
+    tw, th = 2 * w + 1, 2 * h + 1  # odd: the scaled size is floor(target / scale) (common.c:249-250)
+    target = oracle.fill_frame(tw, th, 1, 99, 4 * tw + 8)
+    info, vss = host.create("vectorscope_source", colorspace=1)  # target_scale defaults to 2 (vectorscope.c:157)
+    info.video_tick(vss, 0.0)
+    assert host.render_target(vss, target, tw, th)
+    host.drain(vss)
+    scaled = oracle.stage_region(target, tw, 2)
+    assert scaled.shape == (h, 4 * w)
+    got, cs = host.vss_table(vss)
+    assert cs == 1 and np.array_equal(got, oracle.vectorscope(oracle.rgb_to_yuv(scaled, w, 1), w))
+    assert not host.render_target(vss, target[:1], tw, 1)  # scaled height 0: nothing staged (common.c:251-254)
+    info.destroy(vss)
+
+    x0, y0, x1, y1 = 3, 2, 3 + 41, 2 + 17  # rectangle in SCALED pixels (common.c:272-282)
+    roi_info, roi = host.create("colormonitor_roi", interleave=0, target_scale=3, roi_x0=x0, roi_y0=y0, roi_x1=x1, roi_y1=y1)
+    winfo, wvs = host.create("waveform_source", components=0x07)
+    hinfo, his = host.create("histogram_source", components=0x70)
+    for info_, obj in ((winfo, wvs), (hinfo, his)):
+        host.L.roi_register_source(roi, host.L.scope_host_cm(obj))
+        info_.video_tick(obj, 0.0)
+    roi_info.video_tick(roi, 0.0)
+    tw, th = 3 * 60 + 2, 3 * 30 + 1
+    target = oracle.fill_frame(tw, th, 5, 123)
+    host.L.roi_target_render_full(roi, target.ctypes.data_as(C.c_void_p), target.shape[1], tw, th)
+    host.drain(roi)
+    crop = oracle.stage_region(target, tw, 3, x0, y0, x1 - x0, y1 - y0)
+    crop_yuv = oracle.rgb_to_yuv(crop, x1 - x0, 2)
+    assert np.array_equal(host.wvs_table(wvs), oracle.waveform(crop, crop_yuv, x1 - x0, 0x07))
+    want_f, want_hi = oracle.histogram(crop, crop_yuv, x1 - x0, 0x70)
+    got_f, got_hi = host.his_table(his)
+    assert np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32)) and got_hi == list(want_hi)
+    for obj in (wvs, his):
+        host.L.roi_unregister_source(roi, host.L.scope_host_cm(obj))
+    for info_, obj in ((winfo, wvs), (hinfo, his), (roi_info, roi)):
         info_.destroy(obj)

@@ -4,6 +4,7 @@ Every function drives the product path through the C-ABI (via obs_color_monitor_
 and compares with oracle/ on the same seeded input.  Integer tables must be bit-exact.
 """
 import numpy as np
+import pytest
 
 DISTS = {1: "uniform", 2: "concentrated", 3: "flat", 4: "bars", 5: "alpha_holes"}
 # (components) the reference UI exposes + single channels (BASELINE config 3) + odd masks
@@ -203,22 +204,56 @@ def check_device_path(ctx, oracle, to_dev, to_host, w, h, linesize, n=2, offset=
     return hy, hr
 
 
-def check_pipeline(ctx, oracle, w, h, n_frames=7, depth=3, linesize=None):
-    """scope_pipe: frames in flight over three streams; every frame's three tables bit-exact, in order."""
+REGIONS = ((1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (3, 0, 0, 0, 0), (1, 5, 3, 17, 9), (2, 1, 2, 7, 5), (4, 0, 1, 3, 2), (128, 0, 0, 0, 0))
+
+
+def check_stage_region(ctx, oracle, w, h, linesize=None, regions=REGIONS):
+    """target_scale + ROI crop (scope_stage_region) against the oracle, host planes in and out."""
+    import numpy as np
+    import scope_oracle
+
+    linesize = linesize or 4 * w
+    plane = oracle.fill_frame(w, h, 1, 4242, linesize)
+    for scale, x, y, cx, cy in regions:
+        sw, sh = w // scale, h // scale
+        if sw == 0 or sh == 0 or (cx and (x + cx > sw or y + cy > sh)):
+            with pytest.raises(Exception):
+                ctx.stage_region(plane, w, scale, x, y, cx, cy)
+            continue
+        want = oracle.stage_region(plane, w, scale, x, y, cx, cy)
+        assert np.array_equal(want, scope_oracle.np_stage_region(plane, w, scale, x, y, cx, cy))
+        assert ctx.region_size(w, h, scale, x, y, cx, cy) == (want.shape[1] // 4, want.shape[0])
+        got = ctx.stage_region(plane, w, scale, x, y, cx, cy)
+        assert_same(got, want, f"stage_region {w}x{h} scale {scale} roi {(x, y, cx, cy)}")
+        ow = want.shape[1] // 4
+        padded = ctx.stage_region(plane, w, scale, x, y, cx, cy, out_linesize=ow * 4 + 12)
+        assert_same(padded[:, :ow * 4], want, "stage_region padded pitch")
+        assert (padded[:, ow * 4:] == 0xA5).all(), "stage_region wrote into the pitch padding"
+
+
+def check_pipeline(ctx, oracle, w, h, n_frames=7, depth=3, linesize=None, region=(0, 0, 0, 0, 0)):
+    """scope_pipe: frames in flight over three streams; every frame's three tables bit-exact, in order.
+    With a region the frames are scaled / cropped on the GPU first (cm_render_target's pre-steps)."""
     import obs_color_monitor_amd as ocm
 
     linesize = linesize or 4 * w
     frames_ = [oracle.fill_frame(w, h, 1 + i % 5, 900 + i, linesize) for i in range(n_frames)]
-    pipe = ocm.ScopePipe(ctx, w, h, depth=depth, colorspace=2, wvs_components=0x07, his_components=0x70)
+    pipe = ocm.ScopePipe(ctx, w, h, depth=depth, colorspace=2, wvs_components=0x07, his_components=0x70, region=region)
+    full_w = w
     try:
         assert pipe.collect() is None
         done = 0
 
         def check(i, got):
-            yuv = oracle.rgb_to_yuv(frames_[i], w, 2)
+            rgb, w = frames_[i], full_w
+            if region[0]:
+                rgb = oracle.stage_region(rgb, full_w, *region)  # tight pitch
+                w = rgb.shape[1] // 4
+            assert (pipe.w, pipe.h) == (w, rgb.shape[0])
+            yuv = oracle.rgb_to_yuv(rgb, w, 2)
             assert_same(got[0], oracle.vectorscope(yuv, w), f"pipe frame {i} vectorscope")
-            assert_same(got[1], oracle.waveform(frames_[i], yuv, w, 0x07), f"pipe frame {i} waveform")
-            assert_same(got[2], oracle.histogram_counts(frames_[i], yuv, w, 0x70), f"pipe frame {i} histogram")
+            assert_same(got[1], oracle.waveform(rgb, yuv, w, 0x07), f"pipe frame {i} waveform")
+            assert_same(got[2], oracle.histogram_counts(rgb, yuv, w, 0x70), f"pipe frame {i} histogram")
 
         for i, f in enumerate(frames_):
             while not pipe.submit(f.ctypes.data, f.shape[1]):

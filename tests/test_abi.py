@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(hip_lib_path):
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in include/scope_hip.h but not exported"
     lib.scope_abi_version.restype = ctypes.c_int
-    assert lib.scope_abi_version() == 1
+    assert lib.scope_abi_version() == 2
 
 
 def test_c_abi_only_c_types(hip_lib_path):

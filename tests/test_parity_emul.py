@@ -142,5 +142,25 @@ def test_frame_pipeline(emul_ctx, oracle):
     pc.check_pipeline(emul_ctx, oracle, 70, 20, n_frames=5, depth=2, linesize=4 * 70 + 24)
 
 
+@pytest.mark.parametrize("region", [(2, 0, 0, 0, 0), (1, 3, 2, 33, 11), (3, 1, 1, 20, 4)])
+def test_frame_pipeline_scaled_and_cropped(emul_ctx, oracle, region):
+    """target_scale and the ROI rectangle applied on the device before the scopes."""
+    pc.check_pipeline(emul_ctx, oracle, 70, 20, n_frames=4, depth=2, linesize=4 * 70 + 24, region=region)
+
+
+@pytest.mark.parametrize("w,h,ls", [(70, 36, None), (64, 33, 64 * 4 + 20), (129, 5, None), (1, 1, None)])
+def test_stage_region(emul_ctx, oracle, w, h, ls):
+    pc.check_stage_region(emul_ctx, oracle, w, h, ls)
+
+
+def test_stage_region_rejects_bad_arguments(emul_ctx, oracle):
+    import obs_color_monitor_amd as ocm
+
+    plane = oracle.fill_frame(16, 8, 1, 1)
+    for bad in ((0, 0, 0, 0, 0), (2, 8, 0, 1, 1), (2, 0, 0, 9, 1), (2, 7, 3, 2, 2), (32, 0, 0, 0, 0)):
+        with pytest.raises(ocm.ScopeError):
+            emul_ctx.stage_region(plane, 16, *bad)
+
+
 def test_display_post_passes(emul_ctx, oracle):
     pc.check_display(emul_ctx, oracle, 35, 20)

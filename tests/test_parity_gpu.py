@@ -284,6 +284,36 @@ def test_frame_pipeline_streams(hip_ctx, oracle):
     pc.check_pipeline(hip_ctx, oracle, 3840, 2160, n_frames=5, depth=3)
 
 
+@pytest.mark.parametrize("region", [(2, 0, 0, 0, 0), (1, 100, 50, 333, 111), (3, 7, 5, 200, 100)])
+def test_frame_pipeline_scaled_and_cropped(hip_ctx, oracle, region):
+    """target_scale (the reference's default is 2) and the ROI rectangle on the device."""
+    pc.check_pipeline(hip_ctx, oracle, 1280, 720, n_frames=5, depth=3, region=region)
+
+
+def test_frame_pipeline_4k_default_scale(hip_ctx, oracle):
+    pc.check_pipeline(hip_ctx, oracle, 3840, 2160, n_frames=4, depth=3, region=(2, 0, 0, 0, 0))
+
+
+@pytest.mark.parametrize("w,h,ls", [(640, 360, None), (1279, 301, 1279 * 4 + 20), (3840, 2160, None)])
+def test_stage_region(hip_ctx, oracle, w, h, ls):
+    pc.check_stage_region(hip_ctx, oracle, w, h, ls)
+
+
+def test_stage_region_device_planes(hip_ctx, oracle):
+    import torch
+
+    w, h = 1920, 1080
+    plane = oracle.fill_frame(w, h, 1, 77)
+    src = torch.from_numpy(plane).cuda()
+    for region in ((2, 0, 0, 0, 0), (5, 3, 2, 100, 60), (1, 11, 7, 640, 360)):
+        want = oracle.stage_region(plane, w, *region)
+        dst = torch.full((want.shape[0], want.shape[1] + 16), 0xA5, dtype=torch.uint8, device="cuda")
+        hip_ctx.stage_region_dev(src, w * 4, w, h, region, dst, dst.shape[1])
+        got = dst.cpu().numpy()
+        pc.assert_same(got[:, :want.shape[1]], want, f"device stage_region {region}")
+        assert (got[:, want.shape[1]:] == 0xA5).all()
+
+
 def test_display_post_passes(hip_ctx, oracle):
     """tables -> scope pictures on the GPU, every display technique."""
     pc.check_display(hip_ctx, oracle, 70, 40)
