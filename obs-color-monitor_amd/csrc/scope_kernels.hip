@@ -75,6 +75,76 @@ __device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool nee
 	return out;
 }
 
+/* ---- the fast path ------------------------------------------------------------------------------
+ * The fp32 chain above costs ~33 VALU instructions per texel and makes every fused kernel VALU-bound.
+ * The value it approximates is T = c_r R + c_g G + c_b B + 255 off + 0.5 with output floor(T) (no clamp is
+ * ever active for 8-bit inputs), which three 24-bit integer multiply-adds give directly in 2^-23 fixed
+ * point: E = C_r R + C_g G + C_b B + K, output E >> 23.  The two disagree only where T is within ~2.5e-5 of
+ * an integer, i.e. where fp32 rounding decides: an exhaustive run over all 2^24 colours, both matrices and
+ * all three rows finds every such colour within 211 units (2^-23) of a step.  So K carries a guard of 256
+ * units, `slack` = min over the rows of (E & (2^23 - 1)), and a texel with slack < 512 is "near a step":
+ * it is recomputed with the fp32 chain (a wave votes per cell; 6e-5 .. 1e-3 of all colours).  Black is an
+ * exact tie (V = 128.0) on which both paths agree, and common (letterbox bars): it is exempt.
+ * tests/test_parity_gpu.py runs all 2^24 colours through this code against the oracle. */
+__device__ __forceinline__ int scope_mad24(int a, int b, int c)
+{
+	return __mul24(a, b) + c; /* v_mad_i32_i24 */
+}
+
+__device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool need_uv, bool need_y, u32 &slack)
+{
+	const int b = (int)(px & 0xffu), g = (int)((px >> 8) & 0xffu), r = (int)((px >> 16) & 0xffu);
+	const u32 mask = (1u << SCOPE_K0_FX_SHIFT) - 1u;
+	u32 out = 0xff000000u;
+	slack = 0xffffffffu;
+	if (need_uv) {
+		const u32 eu = (u32)scope_mad24(k.fu[0], r, scope_mad24(k.fu[1], g, scope_mad24(k.fu[2], b, k.fu[3])));
+		const u32 ev = (u32)scope_mad24(k.fv[0], r, scope_mad24(k.fv[1], g, scope_mad24(k.fv[2], b, k.fv[3])));
+		slack = min(eu & mask, ev & mask);
+		out |= (eu >> SCOPE_K0_FX_SHIFT) | ((ev >> (SCOPE_K0_FX_SHIFT - 16)) & 0x00ff0000u);
+	}
+	if (need_y) {
+		const u32 ey = (u32)scope_mad24(k.fy[0], r, scope_mad24(k.fy[1], g, scope_mad24(k.fy[2], b, k.fy[3])));
+		slack = min(slack, ey & mask);
+		out |= (ey >> (SCOPE_K0_FX_SHIFT - 8)) & 0x0000ff00u;
+	}
+	return out;
+}
+
+/* N texels of one lane, in place.  The votes are wave-wide: a cell is redone in fp32 by the whole wave when any
+ * lane holds a texel near a step (identical results for the other lanes, that is what the exhaustive test says). */
+template <int N> __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, bool need_uv, bool need_y)
+{
+	u32 t[N], slack[N], worst = 0xffffffffu;
+#pragma unroll
+	for (int j = 0; j < N; j++) {
+		t[j] = scope_k0_fixed(p[j], k, need_uv, need_y, slack[j]);
+		worst = min(worst, slack[j]);
+	}
+	if (__ballot(worst < 2u * SCOPE_K0_FX_GUARD) != 0) {
+		bool redo = false;
+#pragma unroll
+		for (int j = 0; j < N; j++)
+			redo |= slack[j] < 2u * SCOPE_K0_FX_GUARD && (p[j] & 0x00ffffffu) != 0;
+		if (__ballot(redo) != 0) {
+#pragma unroll
+			for (int j = 0; j < N; j++)
+				p[j] = scope_k0_texel(p[j], k, need_uv, need_y);
+			return;
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < N; j++)
+		p[j] = t[j];
+}
+
+static void k0_fixed_row(const float c[3], double offset, int out[4])
+{
+	for (int i = 0; i < 3; i++)
+		out[i] = (int)lrint((double)c[i] * (double)(1 << SCOPE_K0_FX_SHIFT));
+	out[3] = (int)llrint((255.0 * offset + 0.5) * (double)(1 << SCOPE_K0_FX_SHIFT)) + SCOPE_K0_FX_GUARD;
+}
+
 ScopeK0 scope_k0_matrix(int colorspace)
 {
 	/* src/common.c:207-208: colorspace == 1 -> 601, anything else -> 709 */
@@ -88,6 +158,10 @@ ScopeK0 scope_k0_matrix(int colorspace)
 		k.yr = +0.212600f, k.yg = +0.715200f, k.yb = +0.072200f;
 		k.vr = +0.439216f, k.vg = -0.398941f, k.vb = -0.040273f;
 	}
+	const float cu[3] = {k.ur, k.ug, k.ub}, cy[3] = {k.yr, k.yg, k.yb}, cv[3] = {k.vr, k.vg, k.vb};
+	k0_fixed_row(cu, (double)0.5f - (double)0.00390625f, k.fu);
+	k0_fixed_row(cy, 0.0, k.fy);
+	k0_fixed_row(cv, (double)0.5f, k.fv);
 	return k;
 }
 
@@ -356,14 +430,14 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 				       [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
 					       u32 idx[U][4];
 #pragma unroll
-					       for (int k = 0; k < U; k++)
+					       for (int k = 0; k < U; k++) {
+						       u32 p[4] = {q[k][0], q[k][1], q[k][2], q[k][3]};
+						       if (FUSE)
+							       scope_k0_cell<4>(p, k0, true, false);
 #pragma unroll
-						       for (int j = 0; j < 4; j++) {
-							       u32 p = q[k][j];
-							       if (FUSE)
-								       p = scope_k0_texel(p, k0, true, false);
-							       idx[k][j] = vss_bin(p);
-						       }
+						       for (int j = 0; j < 4; j++)
+							       idx[k][j] = vss_bin(p[j]);
+					       }
 					       /* MERGE 3: ONE vote per batch (16 pixels per lane): does at least a quarter of the wave
 						* hold nothing but single-colour cells?  Then it sits on flat content and runs
 						* this batch in absorb mode; noisy video never passes the vote and only pays the
@@ -398,11 +472,11 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 				       [&](const u32(&q)[U], const bool(&ok)[U]) {
 #pragma unroll
 					       for (int k = 0; k < U; k++) {
-						       u32 p0 = q[k];
+						       u32 p0[1] = {q[k]};
 						       if (FUSE)
-							       p0 = scope_k0_texel(p0, k0, true, false);
+							       scope_k0_cell<1>(p0, k0, true, false);
 						       if (ok[k])
-							       vss_add<HASH>(tab, vss_bin(p0), 1);
+							       vss_add<HASH>(tab, vss_bin(p0[0]), 1);
 					       }
 				       });
 	}
@@ -487,26 +561,26 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 		scope_stream<4, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing,
 				       [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
 #pragma unroll
-					       for (int k = 0; k < U; k++)
+					       for (int k = 0; k < U; k++) {
+						       u32 p[4] = {q[k][0], q[k][1], q[k][2], q[k][3]};
+						       if (FUSE)
+							       scope_k0_cell<4>(p, k0, need_uv, need_y);
 #pragma unroll
-						       for (int j = 0; j < 4; j++) {
-							       u32 p = q[k][j];
-							       if (FUSE)
-								       p = scope_k0_texel(p, k0, need_uv, need_y);
+						       for (int j = 0; j < 4; j++)
 							       if (ok[k])
-								       his_add(tab, p, chmask, rep);
-						       }
+								       his_add(tab, p[j], chmask, rep);
+					       }
 				       });
 	} else {
 		scope_stream<1, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing,
 				       [&](const u32(&q)[U], const bool(&ok)[U]) {
 #pragma unroll
 					       for (int k = 0; k < U; k++) {
-						       u32 p0 = q[k];
+						       u32 p0[1] = {q[k]};
 						       if (FUSE)
-							       p0 = scope_k0_texel(p0, k0, need_uv, need_y);
+							       scope_k0_cell<1>(p0, k0, need_uv, need_y);
 						       if (ok[k])
-							       his_add(tab, p0, chmask, rep);
+							       his_add(tab, p0[0], chmask, rep);
 					       }
 				       });
 	}
@@ -689,11 +763,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 		{                                                                                             \
 			if (!ok[k])                                                                           \
 				continue;                                                                     \
-			u32 p0 = v[k][0], p1 = v[k][1];                                                       \
-			if (FUSE) {                                                                           \
-				p0 = scope_k0_texel(p0, k0, need_uv, need_y);                                 \
-				p1 = scope_k0_texel(p1, k0, need_uv, need_y);                                 \
-			}                                                                                     \
+			u32 pp_[2] = {v[k][0], v[k][1]};                                                      \
+			if (FUSE)                                                                             \
+				scope_k0_cell<2>(pp_, k0, need_uv, need_y);                                   \
+			const u32 p0 = pp_[0], p1 = pp_[1];                                                   \
 			if (live0 && (p0 >> 24) != 0) /* src/waveform.c:247-248 */                            \
 				wvs_count<CH>(tab, p0, wbyte, 1u);                                            \
 			if (live1 && (p1 >> 24) != 0)                                                         \
@@ -859,21 +932,18 @@ __global__ __launch_bounds__(256) void scope_k0_kernel(const uint8_t *src, u32 s
 		for (u32 c = gid; c < total; c += stride) {
 			const u32 row = c / ncols_a, col = c - row * ncols_a;
 			const uint4 q = *(const uint4 *)(src + (size_t)row * src_linesize + (size_t)col * 16);
-			uint4 o;
-			o.x = scope_k0_texel(q.x, k0, true, true);
-			o.y = scope_k0_texel(q.y, k0, true, true);
-			o.z = scope_k0_texel(q.z, k0, true, true);
-			o.w = scope_k0_texel(q.w, k0, true, true);
-			*(uint4 *)(dst + (size_t)row * dst_linesize + (size_t)col * 16) = o;
+			u32 t[4] = {q.x, q.y, q.z, q.w};
+			scope_k0_cell<4>(t, k0, true, true);
+			*(uint4 *)(dst + (size_t)row * dst_linesize + (size_t)col * 16) = make_uint4(t[0], t[1], t[2], t[3]);
 		}
 	}
 	if (ncols_b) {
 		const u32 total = rows * ncols_b;
 		for (u32 c = gid; c < total; c += stride) {
 			const u32 row = c / ncols_b, col = c - row * ncols_b;
-			const u32 q = *(const u32 *)(src + (size_t)row * src_linesize + xbyte_b + (size_t)col * 4);
-			*(u32 *)(dst + (size_t)row * dst_linesize + xbyte_b + (size_t)col * 4) =
-				scope_k0_texel(q, k0, true, true);
+			u32 t[1] = {*(const u32 *)(src + (size_t)row * src_linesize + xbyte_b + (size_t)col * 4)};
+			scope_k0_cell<1>(t, k0, true, true);
+			*(u32 *)(dst + (size_t)row * dst_linesize + xbyte_b + (size_t)col * 4) = t[0];
 		}
 	}
 }

@@ -160,6 +160,12 @@ static inline int __ffsll(long long v)
 {
 	return __builtin_ffsll(v);
 }
+static inline int __mul24(int a, int b)
+{
+	/* v_mul_i32_i24: operands are the sign-extended low 24 bits, result the low 32 bits of the product */
+	const int64_t x = (int32_t)((uint32_t)a << 8) >> 8, y = (int32_t)((uint32_t)b << 8) >> 8;
+	return (int)(uint32_t)(uint64_t)(x * y);
+}
 static inline int __popcll(unsigned long long v)
 {
 	return __builtin_popcountll(v);

@@ -1,6 +1,7 @@
 """Parity of the product sources against the oracle WITHOUT a GPU: csrc/*.hip compiled for the CPU
 by tests/emul (thread-per-GPU-thread executor).  Small frames only; the -m gpu tests repeat these
 on the real kernels and add the full BASELINE sizes."""
+import numpy as np
 import pytest
 
 import parity_cases as pc
@@ -164,3 +165,13 @@ def test_stage_region_rejects_bad_arguments(emul_ctx, oracle):
 
 def test_display_post_passes(emul_ctx, oracle):
     pc.check_display(emul_ctx, oracle, 35, 20)
+
+
+@pytest.mark.parametrize("cs", [1, 2])
+def test_k0_all_colours_fixed_point_path(emul_ctx, oracle, cs):
+    """Every one of the 2^24 colours through K0.  In the emulator a wave is one lane, so each texel decides on its
+    own between the fixed-point result and the fp32 redo: every colour the guard does not flag is checked on the
+    fast path alone (on the GPU a flagged neighbour would pull the whole wave onto the fp32 path)."""
+    v = np.arange(1 << 24, dtype=np.uint32) | np.uint32(0xFF000000)
+    rgb = v.view(np.uint8).reshape(4096, 4096 * 4)
+    pc.assert_same(emul_ctx.convert_rgb_yuv(rgb, 4096, cs), oracle.rgb_to_yuv(rgb, 4096, cs), f"K0 exhaustive cs{cs}")

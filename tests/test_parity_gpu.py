@@ -154,6 +154,26 @@ def test_k0_all_colours(hip_ctx, oracle, cs):
     pc.assert_same(got, want, f"K0 exhaustive cs{cs}")
 
 
+@pytest.mark.parametrize("cs", [1, 2])
+def test_fused_k0_all_colours(hip_ctx, oracle, cs):
+    """The fused kernels convert on the fly (fixed-point fast path + fp32 redo near a step): all 2^24 colours through
+    the histogram (exact u32 counts of U, Y and V), the luma waveform and the vectorscope."""
+    v = np.arange(1 << 24, dtype=np.uint32) | np.uint32(0xFF000000)
+    rgb = v.view(np.uint8).reshape(4096, 4096 * 4)
+    yuv = oracle.rgb_to_yuv(rgb, 4096, cs)
+    got, st = hip_ctx.histogram_counts(rgb=rgb, width=4096, components=0x70, colorspace=cs, fuse_k0=True)
+    assert st == 0
+    pc.assert_same(got, oracle.histogram_counts(None, yuv, 4096, 0x70), f"fused histogram, all colours, cs{cs}")
+    got, st = hip_ctx.vectorscope(rgb=rgb, width=4096, colorspace=cs, fuse_k0=True)
+    pc.assert_same(got, oracle.vectorscope(yuv, 4096), f"fused vectorscope, all colours, cs{cs}")
+    # a shuffled copy: the unsaturated counters of the waveform see every colour in a different column
+    perm = np.random.default_rng(7).permutation(1 << 24)
+    rgb2 = np.ascontiguousarray(v[perm]).view(np.uint8).reshape(4096, 4096 * 4)
+    yuv2 = oracle.rgb_to_yuv(rgb2, 4096, cs)
+    got, st = hip_ctx.waveform(rgb=rgb2, width=4096, components=0x20, colorspace=cs, fuse_k0=True)
+    pc.assert_same(got, oracle.waveform(None, yuv2, 4096, 0x20), f"fused luma waveform, all colours, cs{cs}")
+
+
 # ---------------------------------------------------------------------------------- full sizes ---
 
 

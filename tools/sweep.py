@@ -157,13 +157,22 @@ def main():
             report("vss_single", k, wall, l, n, 65536, dist="uniform", slices=slices)
         ctx.set_option("slices", 0)
 
-    # ---- D: fused K0 ---------------------------------------------------------------------------------
+    # ---- D: fused K0 (scopes reading RGB planes; the conversion runs inside the accumulation kernel) --------
     if "D" in sec:
-        for d in dists[:2]:
+        cnt_d = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+        wtab_d = torch.empty((n, 256 * W * 4), dtype=torch.uint8, device="cuda")
+        for d in dists:
             rgb, yuv = data[d]
-            batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-            k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch_rgb, tab, sync=False))
-            report("vss_fused_k0", k, wall, l, n, 65536, dist=d)
+            for cs in (2, 1):
+                batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=cs)
+                k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch_rgb, tab, sync=False))
+                report("vss_fused_k0", k, wall, l, n, 65536, dist=d, colorspace=cs)
+                for comp in (0x70, 0x20):
+                    k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt_d, sync=False))
+                    report("his_fused_k0", k, wall, l, n, 4096, dist=d, colorspace=cs, comp=hex(comp))
+                    k, wall, l = timed(ctx, lambda: ctx.waveform_batch_dev(batch_rgb, comp, wtab_d, sync=False), reps=10)
+                    report("wvs_fused_k0", k, wall, l, n, 256 * W * 4, dist=d, colorspace=cs, comp=hex(comp))
+        del cnt_d, wtab_d
 
     # ---- E: histogram ----------------------------------------------------------------------------------
     if "E" in sec:
