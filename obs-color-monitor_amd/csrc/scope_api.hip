@@ -16,6 +16,7 @@
 #include <string.h>
 
 #define SCOPE_PROFILE_SLOTS 512u
+#define SCOPE_FOLD_MAX_SLICES 16u /* more partials than this: one workgroup summing them is slower than a kernel */
 
 struct scope_ctx {
 	int device;
@@ -28,6 +29,7 @@ struct scope_ctx {
 	size_t stage_in_bytes;
 	uint8_t *stage_out; /* tables on their way to a host buffer */
 	size_t stage_out_bytes;
+	uint32_t *tickets; /* SCOPE_MAX_FRAMES arrival counters of the in-kernel reduction; zero between launches */
 	ScopeTuning tn;
 	int slices_override;
 	int profile;
@@ -332,15 +334,20 @@ int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint
 		uint32_t *dst = (uint32_t *)(dev_out + (size_t)f0 * table);
 		const uint32_t slices = pick_slices(ctx, nf, 1);
 		if (slices == 1) {
-			TIMED_LAUNCH(ctx, scope_launch_his(fs, 1, chmask, fuse, colorspace, dst, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_his(fs, 1, chmask, fuse, colorspace, dst, NULL, NULL, ctx->tn, ctx->stream));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * table);
 			if (st)
 				return st;
-			TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, (uint32_t *)ctx->partial, ctx->tn,
-						      ctx->stream));
-			HIP_TRY(ctx, scope_launch_sum_reduce((const uint32_t *)ctx->partial, dst, nf, slices, SCOPE_HIS_WORDS,
-							     ctx->stream));
+			if (ctx->tn.fold && slices <= SCOPE_FOLD_MAX_SLICES) {
+				TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, (uint32_t *)ctx->partial, dst,
+							      ctx->tickets, ctx->tn, ctx->stream));
+			} else {
+				TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, (uint32_t *)ctx->partial, NULL,
+							      NULL, ctx->tn, ctx->stream));
+				HIP_TRY(ctx, scope_launch_sum_reduce((const uint32_t *)ctx->partial, dst, nf, slices, SCOPE_HIS_WORDS,
+								     ctx->stream));
+			}
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -473,6 +480,9 @@ int scope_ctx_create(int device, scope_ctx **out)
 	}
 	ctx->stream = ctx->own_stream;
 	bool ok = scope_kernels_init() == hipSuccess;
+	ok = ok && hipMalloc((void **)&ctx->tickets, SCOPE_MAX_FRAMES * sizeof(uint32_t)) == hipSuccess &&
+	     hipMemsetAsync(ctx->tickets, 0, SCOPE_MAX_FRAMES * sizeof(uint32_t), ctx->stream) == hipSuccess &&
+	     hipStreamSynchronize(ctx->stream) == hipSuccess;
 	for (uint32_t i = 0; ok && i < 2 * SCOPE_PROFILE_SLOTS; i++)
 		ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
 	if (!ok) {
@@ -486,6 +496,7 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.his_unroll = 2;
 	ctx->tn.wvs_wide = 1;
 	ctx->tn.wvs_persist = 1;
+	ctx->tn.fold = 1;
 	ctx->tn.nt_loads = 1;
 	ctx->err[0] = 0;
 	*out = ctx;
@@ -504,6 +515,8 @@ void scope_ctx_destroy(scope_ctx *ctx)
 		(void)hipFree(ctx->stage_in);
 	if (ctx->stage_out)
 		(void)hipFree(ctx->stage_out);
+	if (ctx->tickets)
+		(void)hipFree(ctx->tickets);
 	for (uint32_t i = 0; i < 2 * SCOPE_PROFILE_SLOTS; i++)
 		if (ctx->ev[i])
 			(void)hipEventDestroy(ctx->ev[i]);
@@ -571,6 +584,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.nt_loads = value;
 	else if (!strcmp(key, "his.unroll"))
 		ctx->tn.his_unroll = value;
+	else if (!strcmp(key, "fold"))
+		ctx->tn.fold = value != 0;
 	else if (!strcmp(key, "wvs.persist"))
 		ctx->tn.wvs_persist = value != 0;
 	else if (!strcmp(key, "wvs.wide"))

@@ -53,6 +53,7 @@ struct ScopeTuning {
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3 */
 	int his_unroll;      /* 2 or 4 */
+	int fold;            /* 1: histogram partials are summed by the last workgroup of a frame when they are few */
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
 	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */
 	int nt_loads;        /* 1: non-temporal pixel loads */
@@ -73,10 +74,12 @@ hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *d
 hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
 			    const ScopeTuning &tn, hipStream_t st);
 
-/* K3.  dst = uint32[n_frames][slices][1024]; combine with scope_launch_sum_reduce when slices > 1.
+/* K3.  dst = uint32[n_frames][slices][1024]; with slices > 1 the partials are summed either by the kernel itself
+ * -- folded = uint32[n_frames][1024] and tickets = uint32[n_frames], zero before the first launch and left zero by
+ * every launch: the last workgroup of a frame does it -- or, with folded == NULL, by scope_launch_sum_reduce.
  * chmask bit c = count byte c of the texel (bit0 -> slot 2, bit1 -> slot 1, bit2 -> slot 0). */
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint32_t *dst, const ScopeTuning &tn, hipStream_t st);
+			    uint32_t *dst, uint32_t *folded, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st);
 
 /* Capture pre-steps: dst(i, j) = texel at src + j*row_pitch + i*col_step*4, i < cx, j < cy (the caller folds
  * scale and ROI origin into src / row_pitch / col_step).  All pointers and pitches 4-byte aligned. */

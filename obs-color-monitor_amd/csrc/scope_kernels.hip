@@ -199,6 +199,51 @@ template <bool NT, typename V> __device__ __forceinline__ V scope_load(const V *
 	return *p;
 }
 
+/* "Last workgroup reduces": every workgroup of a group (the slices of one frame) calls this after writing its
+ * partial table to global memory; it returns true, in every thread, for the workgroup that arrives last, which
+ * may then read all the partials.  The caller resets the ticket when done, so a zero-initialised ticket array
+ * serves every launch on the stream.
+ *
+ * No fences: an agent-scope release/acquire pair costs a write-back plus an invalidate of the XCD's whole L2
+ * (buffer_wbl2 / buffer_inv) per workgroup, which doubled the run time of the vectorscope kernel when tried.
+ * Instead the partial tables are written and read with agent-scope accesses (sc1: they go through to the
+ * device-coherent level, nothing stays dirty or stale in a per-XCD L2), the writer waits for its stores to be
+ * acknowledged (vmcnt(0)) before it takes a ticket, and the ticket is an agent-scope atomic.  Such accesses are
+ * slow, so this only pays for small tables and few partials: the histogram's 4 KiB tables (+2.4 % on the batch);
+ * the vectorscope's 64 KiB tables lost 7 % this way and keep their reduce kernel. */
+__device__ __forceinline__ bool scope_last_arrival(u32 *ticket, u32 group_size, u32 *lds_flag)
+{
+	__builtin_amdgcn_s_waitcnt(0); /* this thread's partial-table stores have been acknowledged */
+	__syncthreads();
+	if (threadIdx.x == 0)
+		*lds_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == group_size - 1u;
+	__syncthreads();
+	return *lds_flag != 0;
+}
+
+/* min(sum over `slices` partial tables, 255) for 16 byte-wide bins; slices <= 256, so the packed 16-bit lanes
+ * (max 256*255 = 65280) cannot overflow.  p points at the bins in the first partial, `stride` uint4s apart. */
+__device__ __forceinline__ uint4 scope_sat_sum16(const uint4 *p, u64 stride, u32 slices)
+{
+	u32 ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};
+	for (u32 s = 0; s < slices; s++) {
+		const uint4 q = p[(u64)s * stride];
+		ev[0] += q.x & 0x00ff00ffu;
+		od[0] += (q.x >> 8) & 0x00ff00ffu;
+		ev[1] += q.y & 0x00ff00ffu;
+		od[1] += (q.y >> 8) & 0x00ff00ffu;
+		ev[2] += q.z & 0x00ff00ffu;
+		od[2] += (q.z >> 8) & 0x00ff00ffu;
+		ev[3] += q.w & 0x00ff00ffu;
+		od[3] += (q.w >> 8) & 0x00ff00ffu;
+	}
+	u32 r[4];
+	for (int j = 0; j < 4; j++)
+		r[j] = min(ev[j] & 0xffffu, 255u) | (min(od[j] & 0xffffu, 255u) << 8) | (min(ev[j] >> 16, 255u) << 16) |
+		       (min(od[j] >> 16, 255u) << 24);
+	return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
 /* Slice s of S of `total` cells. */
 __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
 {
@@ -588,7 +633,7 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 
 template <int U, bool NT, bool FUSE>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
-							       u32 xbyte_b, u32 chmask, ScopeK0 k0, u32 *dst)
+							       u32 xbyte_b, u32 chmask, ScopeK0 k0, u32 *dst, u32 *folded, u32 *tickets)
 {
 	u32 *tab = scope_lds;
 	const u32 unit = blockIdx.x;
@@ -616,7 +661,23 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
 			for (u32 j = 0; j < 32; j++)
 				sum += tab[base + ((j + value) & 31u)];
 		}
-		out[t] = sum;
+		if (folded)
+			__hip_atomic_store(&out[t], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else
+			out[t] = sum;
+	}
+
+	/* folded != NULL: the last workgroup of a frame sums the frame's partial count tables */
+	if (folded && scope_last_arrival(&tickets[frame], slices, &tab[0])) {
+		const u32 *part = dst + (size_t)frame * slices * SCOPE_HIS_WORDS;
+		for (u32 t = threadIdx.x; t < SCOPE_HIS_WORDS; t += blockDim.x) {
+			u32 sum = 0;
+			for (u32 sl = 0; sl < slices; sl++)
+				sum += __hip_atomic_load(&part[(size_t)sl * SCOPE_HIS_WORDS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			folded[(size_t)frame * SCOPE_HIS_WORDS + t] = sum;
+		}
+		if (threadIdx.x == 0)
+			tickets[frame] = 0;
 	}
 }
 
@@ -957,23 +1018,7 @@ __global__ __launch_bounds__(256) void scope_sat_reduce_kernel(const uint8_t *pa
 	if (g >= len16)
 		return;
 	const uint4 *p = (const uint4 *)part + (u64)frame * slices * len16 + g;
-	u32 ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};
-	for (u32 s = 0; s < slices; s++) {
-		const uint4 q = p[(u64)s * len16];
-		ev[0] += q.x & 0x00ff00ffu;
-		od[0] += (q.x >> 8) & 0x00ff00ffu;
-		ev[1] += q.y & 0x00ff00ffu;
-		od[1] += (q.y >> 8) & 0x00ff00ffu;
-		ev[2] += q.z & 0x00ff00ffu;
-		od[2] += (q.z >> 8) & 0x00ff00ffu;
-		ev[3] += q.w & 0x00ff00ffu;
-		od[3] += (q.w >> 8) & 0x00ff00ffu;
-	}
-	u32 r[4];
-	for (int j = 0; j < 4; j++)
-		r[j] = min(ev[j] & 0xffffu, 255u) | (min(od[j] & 0xffffu, 255u) << 8) | (min(ev[j] >> 16, 255u) << 16) |
-		       (min(od[j] >> 16, 255u) << 24);
-	((uint4 *)out)[(u64)frame * len16 + g] = make_uint4(r[0], r[1], r[2], r[3]);
+	((uint4 *)out)[(u64)frame * len16 + g] = scope_sat_sum16(p, len16, slices);
 }
 
 __global__ __launch_bounds__(256) void scope_sum_reduce_kernel(const u32 *part, u32 *out, u32 slices, u32 len)
@@ -1110,7 +1155,7 @@ struct HisArgs {
 	u32 slices, chmask;
 	Regions rg;
 	ScopeK0 k0;
-	u32 *dst;
+	u32 *dst, *folded, *tickets;
 	hipStream_t st;
 };
 
@@ -1120,7 +1165,8 @@ template <int U, bool NT, bool FUSE> hipError_t his_variant(const HisArgs *a)
 		return hipFuncSetAttribute((const void *)scope_his_kernel<U, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
 					   (int)HIS_LDS_BYTES);
 	hipLaunchKernelGGL((scope_his_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), HIS_LDS_BYTES,
-			   a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->chmask, a->k0, a->dst);
+			   a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->chmask, a->k0, a->dst, a->folded,
+			   a->tickets);
 	return hipGetLastError();
 }
 template <int U, bool NT> hipError_t his_pick_fuse(int fuse, const HisArgs *a)
@@ -1248,9 +1294,11 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 }
 
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint32_t *dst, const ScopeTuning &tn, hipStream_t st)
+			    uint32_t *dst, uint32_t *folded, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st)
 {
-	const HisArgs a = {&fs, slices, chmask, split_regions(fs), scope_k0_matrix(colorspace), dst, st};
+	if (!tickets || slices < 2)
+		folded = NULL;
+	const HisArgs a = {&fs, slices, chmask, split_regions(fs), scope_k0_matrix(colorspace), dst, folded, tickets, st};
 	return his_pick(tn.his_unroll, tn.nt_loads, fuse_k0, &a);
 }
 

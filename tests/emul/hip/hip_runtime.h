@@ -160,6 +160,15 @@ static inline int __ffsll(long long v)
 {
 	return __builtin_ffsll(v);
 }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+static inline void __threadfence()
+{
+	__sync_synchronize();
+}
 static inline int __mul24(int a, int b)
 {
 	/* v_mul_i32_i24: operands are the sign-extended low 24 bits, result the low 32 bits of the product */

@@ -167,6 +167,17 @@ def test_display_post_passes(emul_ctx, oracle):
     pc.check_display(emul_ctx, oracle, 35, 20)
 
 
+@pytest.mark.parametrize("fold", [0, 1])
+def test_partial_tables_combined_in_kernel_or_by_reduce_kernel(emul_ctx, oracle, fold):
+    """slices > 1: partial tables are combined by a reduce kernel or (histogram, few partials) by the last workgroup."""
+    with pc.options(emul_ctx, fold=fold, slices=5):
+        for _ in range(3):  # the arrival tickets must be back at zero after every launch
+            pc.check_vectorscope(emul_ctx, oracle, 70, 100, 2)  # saturated bins: saturating add of clamped partials
+            pc.check_histogram_counts(emul_ctx, oracle, 70, 100, 5, 0x07)
+    with pc.options(emul_ctx, fold=fold):
+        pc.check_batches(emul_ctx, oracle, 33, 9, 3)
+
+
 @pytest.mark.parametrize("cs", [1, 2])
 def test_k0_all_colours_fixed_point_path(emul_ctx, oracle, cs):
     """Every one of the 2^24 colours through K0.  In the emulator a wave is one lane, so each texel decides on its

@@ -92,6 +92,22 @@ def test_component_masks(hip_ctx, oracle, comp):
     pc.check_histogram_counts(hip_ctx, oracle, 330, 77, 5, comp)
 
 
+@pytest.mark.parametrize("fold", [0, 1])
+def test_partial_tables_combined_in_kernel_or_by_reduce_kernel(hip_ctx, oracle, fold):
+    """slices > 1: partial tables are combined by a reduce kernel or -- histogram, at most 16 partials per frame --
+    by the last workgroup of the frame.  Repeated launches check that the arrival tickets are back at zero each
+    time; 256 partials per frame is the single-frame case on 256 CUs (always the reduce kernel)."""
+    with pc.options(hip_ctx, fold=fold):
+        for _ in range(4):
+            pc.check_vectorscope(hip_ctx, oracle, 1920, 1080, 2)  # one frame -> 256 slices, saturated bins
+            pc.check_histogram_counts(hip_ctx, oracle, 1920, 1080, 5, 0x07)
+        pc.check_batches(hip_ctx, oracle, 640, 360, 7)
+        pc.check_batches(hip_ctx, oracle, 320, 180, 32)  # 8 partials per frame: folded in-kernel
+        with pc.options(hip_ctx, fold=fold, slices=3):
+            for _ in range(3):
+                pc.check_batches(hip_ctx, oracle, 640, 360, 5)
+
+
 @pytest.mark.parametrize("persist", [0, 1])
 def test_waveform_unit_walk(hip_ctx, oracle, persist):
     """More units than resident workgroups (256 CUs): a workgroup walks several units with one load stream."""
