@@ -197,8 +197,10 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")))
-        if world == 1 and (pmc["workload"], pmc["frames_per_step"], pmc["width"], pmc["height"]) == (wl, n, w, h) and not args.option:
-            traffic = pmc["bytes_per_launch"]
+        for e in pmc.get("entries", [pmc]):
+            if world == 1 and (e["workload"], e["frames_per_step"], e["width"], e["height"]) == (wl, n, w, h) and not args.option \
+                    and args.dist == "uniform" and args.components == 0x07:
+                traffic = e["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     kern_avg_ms = kernel_ms / launches if launches else float("nan")

@@ -28,11 +28,14 @@ for s in $stages; do
            done; rc=$?
            python tools/pmc_summary.py $out/pmc_sq_* $out/pmc_sq2_* > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt ;;
     traffic) # HBM bytes per launch: FETCH_SIZE and WRITE_SIZE in separate PMC passes (TCC slots), kernel trace only
-           for c in FETCH_SIZE WRITE_SIZE; do
-             (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_$c -o p -- \
-                python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --settle-seconds 0.2 --no-cpu $BENCH_EXTRA) > $out/pmc_$c.log 2>&1
+           for wl in ${PMC_WORKLOADS:-vectorscope}; do
+             for c in FETCH_SIZE WRITE_SIZE; do
+               (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_${wl}_$c -o p -- \
+                  python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --settle-seconds 0.2 --no-cpu --workload $wl $BENCH_EXTRA) > $out/pmc_${wl}_$c.log 2>&1
+             done
            done; rc=$?
-           python tools/pmc_summary.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_traffic.txt 2>&1; cat $out/pmc_traffic.txt ;;
+           python tools/pmc_summary.py $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE > $out/pmc_traffic.txt 2>&1; cat $out/pmc_traffic.txt
+           python tools/pmc_traffic_json.py $out > $out/pmc_traffic.json 2>> $out/pmc_traffic.txt; cat $out/pmc_traffic.json ;;
     stream) (timeout 600 python tools/stream_bench.py > $out/stream_max.json 2> $out/stream.err; timeout 600 python tools/stream_bench.py --target-fps 240 --frames 720 > $out/stream_240.json 2>> $out/stream.err); rc=$?; cat $out/stream_max.json $out/stream_240.json; tail -3 $out/stream.err ;;
     trace) (python tools/lds_trace_gen.py /tmp/lds_traces.bin 2> $out/lds_trace_model.txt && timeout 300 ./tools/lds_trace_bench /tmp/lds_traces.bin > $out/lds_trace.txt 2>&1); rc=$?; paste -d'|' $out/lds_trace_model.txt $out/lds_trace.txt | cut -c1-200 > $out/lds_trace_both.txt ;;
     *) echo "unknown stage $s"; rc=99 ;;
