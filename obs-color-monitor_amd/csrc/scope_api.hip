@@ -297,6 +297,13 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 		/* the partial tables are combined 16 bytes at a time */
 		if (bands > 1 && ((table & 15u) || (((uintptr_t)dst) & 15u)))
 			bands = 1;
+		/* the kernel counts in 16 bits per column and band: a band holds at most 65535 rows */
+		const uint32_t min_bands = (height + 65534u) / 65535u;
+		if (bands < min_bands) {
+			if (((uintptr_t)dst) & 15u)
+				return fail(ctx, SCOPE_EINVAL, "frames taller than 65535 rows need a 16-byte aligned table", hipSuccess);
+			bands = min_bands; /* <= 256 partials, the reduction's limit: width * height < 2^31 */
+		}
 		if (bands == 1) {
 			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->num_cu, ctx->tn, ctx->stream));
 		} else {

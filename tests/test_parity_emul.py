@@ -76,6 +76,14 @@ def test_waveform_saturation_and_bands(emul_ctx, oracle):
     pc.check_waveform(emul_ctx, oracle, 1, 1, 1, 0x07)
 
 
+def test_waveform_taller_than_16_bit_counters(emul_ctx, oracle):
+    """More than 65535 rows: the 16-bit per-band counters force at least two row bands (flat frame: every row hits
+    the same counter of its column)."""
+    pc.check_waveform(emul_ctx, oracle, 2, 70000, 3, 0x07)
+    with pc.options(emul_ctx, slices=1):
+        pc.check_waveform(emul_ctx, oracle, 1, 65546, 3, 0x04)  # one band would wrap to 10
+
+
 @pytest.mark.parametrize("persist", [0, 1])
 def test_waveform_unit_walk(emul_ctx, oracle, persist):
     """More units than resident workgroups: a workgroup walks several (frame, strip) units with one load stream."""

@@ -108,6 +108,13 @@ def test_partial_tables_combined_in_kernel_or_by_reduce_kernel(hip_ctx, oracle, 
                 pc.check_batches(hip_ctx, oracle, 640, 360, 5)
 
 
+def test_waveform_taller_than_16_bit_counters(hip_ctx, oracle):
+    """More than 65535 rows: the 16-bit per-band counters force at least two row bands."""
+    pc.check_waveform(hip_ctx, oracle, 8, 70000, 3, 0x07)
+    with pc.options(hip_ctx, slices=1):
+        pc.check_waveform(hip_ctx, oracle, 300, 65546, 3, 0x20)  # one band would wrap to 10
+
+
 @pytest.mark.parametrize("persist", [0, 1])
 def test_waveform_unit_walk(hip_ctx, oracle, persist):
     """More units than resident workgroups (256 CUs): a workgroup walks several units with one load stream."""
