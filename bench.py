@@ -275,6 +275,45 @@ def main():
                       f"single color-monitor thread) over frame 0 of the same batch, {cpu_t:.1f} s; "
                       f"host has {os.cpu_count()} cores; excludes the reference's GPU->CPU readback",
         }
+        # courtesy: every host core, row/column tiles with private tables; same tables, checked here
+        threads = os.cpu_count() or 1
+        cpu_model = "?"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+
+        def all_cores(nthreads, reps=1):
+            if wl in ("vectorscope", "vectorscope_rgb"):
+                return o.vectorscope_mt(plane_yuv, w, nthreads, reps)
+            if wl == "waveform":
+                return o.waveform_mt(plane_rgb, plane_yuv, w, args.components, nthreads, reps)
+            return o.histogram_counts_mt(plane_rgb, plane_yuv, w, args.components, nthreads, reps)
+
+        one = (o.vectorscope(plane_yuv, w) if wl in ("vectorscope", "vectorscope_rgb") else
+               o.waveform(plane_rgb, plane_yuv, w, args.components) if wl == "waveform" else
+               o.histogram_counts(plane_rgb, plane_yuv, w, args.components))
+        mt_same = bool(np.array_equal(all_cores(threads).astype(np.int64).reshape(-1), one.astype(np.int64).reshape(-1)))
+        mt_reps = 20  # per call; thread start-up is paid once per call
+        best = None
+        for nthreads in sorted({t for t in (16, 32, 64, 128, 256, threads) if t <= threads}):
+            all_cores(nthreads, 2)
+            t_start, calls = time.perf_counter(), 0
+            while time.perf_counter() - t_start < min(args.cpu_seconds, 10.0) / 8 or calls < 1:
+                all_cores(nthreads, mt_reps)
+                calls += 1
+            rate = calls * mt_reps * w * h / (time.perf_counter() - t_start) / 1e9
+            if best is None or rate > best[0]:
+                best = (rate, nthreads, calls)
+        result["cpu_baseline"]["all_cores"] = {
+            "value": round(best[0], 3), "unit": "Gpix/s", "cores": best[1], "host_cores": threads, "cpu": cpu_model,
+            "same_table": mt_same,
+            "sample": f"best of 16..{threads} POSIX threads: {best[2]} calls x {mt_reps} passes over frame 0 (row tiles with "
+                      "private tables; column tiles for the waveform; thread start-up once per call)",
+        }
         del plane
 
     if rank == 0:

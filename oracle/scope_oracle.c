@@ -259,6 +259,180 @@ static uint32_t disp_n_components(uint32_t components)
 	return n;
 }
 
+/* ------------------------------------------- multi-threaded courtesy baselines ---- */
+
+#include <pthread.h>
+#include <stdlib.h>
+
+struct mt_job {
+	const struct oracle_surface *sd;
+	const uint8_t *plane;
+	uint32_t components;
+	uint32_t tid, threads;
+	uint32_t reps;            /* timing aid: the tile is reduced this many times (tables restarted each time) */
+	uint32_t *private_counts; /* vectorscope: [65536]; histogram: [1024] */
+	uint8_t *out;             /* waveform: the shared table, threads own disjoint columns */
+};
+
+static void *mt_vectorscope(void *arg)
+{
+	struct mt_job *j = arg;
+	const struct oracle_surface *sd = j->sd;
+	const uint32_t r0 = (uint32_t)((uint64_t)sd->height * j->tid / j->threads);
+	const uint32_t r1 = (uint32_t)((uint64_t)sd->height * (j->tid + 1) / j->threads);
+	for (uint32_t rep = 0; rep < j->reps; rep++) {
+		memset(j->private_counts, 0, 65536 * sizeof(uint32_t));
+		for (uint32_t row = r0; row < r1; row++) {
+			const uint8_t *px = sd->yuv_data + (size_t)sd->linesize * row;
+			for (uint32_t col = 0; col < sd->width; col++, px += 4)
+				j->private_counts[px[0] + 256u * (255u - px[2])]++;
+		}
+	}
+	return NULL;
+}
+
+static void *mt_histogram(void *arg)
+{
+	struct mt_job *j = arg;
+	const struct oracle_surface *sd = j->sd;
+	const int on_b = (j->components & 0x11) != 0, on_g = (j->components & 0x22) != 0, on_r = (j->components & 0x44) != 0;
+	const uint32_t r0 = (uint32_t)((uint64_t)sd->height * j->tid / j->threads);
+	const uint32_t r1 = (uint32_t)((uint64_t)sd->height * (j->tid + 1) / j->threads);
+	for (uint32_t rep = 0; rep < j->reps; rep++) {
+		memset(j->private_counts, 0, 1024 * sizeof(uint32_t));
+		for (uint32_t row = r0; row < r1; row++) {
+			const uint8_t *px = j->plane + (size_t)sd->linesize * row;
+			for (uint32_t col = 0; col < sd->width; col++, px += 4) {
+				if (px[3] == 0)
+					continue;
+				if (on_r)
+					j->private_counts[px[2] * 4 + 0]++;
+				if (on_g)
+					j->private_counts[px[1] * 4 + 1]++;
+				if (on_b)
+					j->private_counts[px[0] * 4 + 2]++;
+			}
+		}
+	}
+	return NULL;
+}
+
+static void *mt_waveform(void *arg)
+{
+	/* column tiles: a column's counters depend on that column only, so threads never share a counter */
+	struct mt_job *j = arg;
+	const struct oracle_surface *sd = j->sd;
+	const size_t rowbytes = (size_t)sd->width * 4;
+	const uint32_t c0 = (uint32_t)((uint64_t)sd->width * j->tid / j->threads);
+	const uint32_t c1 = (uint32_t)((uint64_t)sd->width * (j->tid + 1) / j->threads);
+	int on[3];
+	for (int c = 0; c < 3; c++)
+		on[c] = (j->components & (0x11u << c)) != 0;
+	for (uint32_t rep = 0; rep < j->reps; rep++) {
+		for (uint32_t v = 0; v < 256 && c1 > c0; v++) /* this thread's columns of the table */
+			memset(j->out + v * rowbytes + (size_t)c0 * 4, 0, (size_t)(c1 - c0) * 4);
+		for (uint32_t row = 0; row < sd->height; row++) {
+			const uint8_t *px = j->plane + (size_t)sd->linesize * row + (size_t)c0 * 4;
+			for (uint32_t col = c0; col < c1; col++, px += 4) {
+				if (px[3] == 0)
+					continue;
+				for (int c = 0; c < 3; c++)
+					if (on[c])
+						sat_inc_u8(j->out + (255u - px[c]) * rowbytes + (size_t)col * 4 + c);
+			}
+		}
+	}
+	return NULL;
+}
+
+static int mt_run(void *(*fn)(void *), struct mt_job *jobs, uint32_t threads)
+{
+	pthread_t *th = malloc(sizeof(pthread_t) * threads);
+	if (!th)
+		return -1;
+	uint32_t started = 0;
+	int rc = 0;
+	for (; started < threads; started++)
+		if (pthread_create(&th[started], NULL, fn, &jobs[started]) != 0) {
+			rc = -1;
+			break;
+		}
+	for (uint32_t i = 0; i < started; i++)
+		pthread_join(th[i], NULL);
+	free(th);
+	return rc;
+}
+
+int oracle_vectorscope_mt(uint8_t *out, const struct oracle_surface *sd, uint32_t threads, uint32_t reps)
+{
+	memset(out, 0, 65536);
+	if (threads == 0)
+		return -1;
+	if (!sd->yuv_data)
+		return 0;
+	struct mt_job *jobs = calloc(threads, sizeof *jobs);
+	uint32_t *priv = calloc((size_t)threads * 65536, sizeof(uint32_t));
+	int rc = (jobs && priv) ? 0 : -1;
+	if (!rc) {
+		for (uint32_t t = 0; t < threads; t++)
+			jobs[t] = (struct mt_job){sd, sd->yuv_data, 0, t, threads, reps ? reps : 1, priv + (size_t)t * 65536, NULL};
+		rc = mt_run(mt_vectorscope, jobs, threads);
+		for (uint32_t i = 0; i < 65536 && !rc; i++) {
+			uint64_t sum = 0;
+			for (uint32_t t = 0; t < threads; t++)
+				sum += priv[(size_t)t * 65536 + i];
+			out[i] = sum > 255 ? 255 : (uint8_t)sum;
+		}
+	}
+	free(priv);
+	free(jobs);
+	return rc;
+}
+
+int oracle_histogram_counts_mt(uint32_t *counts, const struct oracle_surface *sd, uint32_t components, uint32_t threads,
+			       uint32_t reps)
+{
+	memset(counts, 0, 1024 * sizeof(uint32_t));
+	if (threads == 0)
+		return -1;
+	const uint8_t *plane = pick_plane(sd, components);
+	if (!plane)
+		return 0;
+	struct mt_job *jobs = calloc(threads, sizeof *jobs);
+	uint32_t *priv = calloc((size_t)threads * 1024, sizeof(uint32_t));
+	int rc = (jobs && priv) ? 0 : -1;
+	if (!rc) {
+		for (uint32_t t = 0; t < threads; t++)
+			jobs[t] = (struct mt_job){sd, plane, components, t, threads, reps ? reps : 1, priv + (size_t)t * 1024, NULL};
+		rc = mt_run(mt_histogram, jobs, threads);
+		for (uint32_t i = 0; i < 1024 && !rc; i++)
+			for (uint32_t t = 0; t < threads; t++)
+				counts[i] += priv[(size_t)t * 1024 + i];
+	}
+	free(priv);
+	free(jobs);
+	return rc;
+}
+
+int oracle_waveform_mt(uint8_t *out, const struct oracle_surface *sd, uint32_t components, uint32_t threads, uint32_t reps)
+{
+	memset(out, 0, (size_t)sd->width * 4 * 256);
+	if (threads == 0)
+		return -1;
+	const uint8_t *plane = pick_plane(sd, components);
+	if (!plane)
+		return 0;
+	struct mt_job *jobs = calloc(threads, sizeof *jobs);
+	int rc = jobs ? 0 : -1;
+	if (!rc) {
+		for (uint32_t t = 0; t < threads; t++)
+			jobs[t] = (struct mt_job){sd, plane, components, t, threads, reps ? reps : 1, NULL, out};
+		rc = mt_run(mt_waveform, jobs, threads);
+	}
+	free(jobs);
+	return rc;
+}
+
 int oracle_region_size(uint32_t width, uint32_t height, uint32_t scale, uint32_t *scaled_w, uint32_t *scaled_h)
 {
 	if (scale == 0)

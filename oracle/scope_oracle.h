@@ -87,6 +87,17 @@ void oracle_display_histogram(uint8_t *out, const float *tex, const uint32_t *hi
 void oracle_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, int display, uint32_t *out_w,
 			 uint32_t *out_h);
 
+/* "Courtesy" CPU baselines: the same tables from `threads` POSIX threads, each reducing a tile of rows
+ * into private u32 counters that are summed (and, for the u8 tables, clamped at 255) at the end -- what a
+ * multi-core host could do at best; the reference itself runs one thread.  Results equal the single-thread
+ * functions bit for bit.  `reps` (>= 1) is a timing aid: every thread reduces its tile that many times, restarting
+ * its counters each time, so thread start-up is paid once per call.  Return 0, or -1 when threads == 0 or
+ * memory runs out. */
+int oracle_vectorscope_mt(uint8_t *out, const struct oracle_surface *sd, uint32_t threads, uint32_t reps);
+int oracle_histogram_counts_mt(uint32_t *counts, const struct oracle_surface *sd, uint32_t components, uint32_t threads,
+			       uint32_t reps);
+int oracle_waveform_mt(uint8_t *out, const struct oracle_surface *sd, uint32_t components, uint32_t threads, uint32_t reps);
+
 /* Capture-side pre-steps of cm_render_target: the target is rendered at 1/scale of its size
  * (src/common.c:249-250, :141-168) and, for an ROI source with a valid rectangle, only the sub-rectangle
  * (x, y, cx, cy) -- in SCALED coordinates -- is drawn into the staged surface (:272-282, :202-206).

@@ -64,6 +64,9 @@ class COracle:
         L.oracle_display_waveform.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         L.oracle_display_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
         L.oracle_display_size.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.oracle_vectorscope_mt.argtypes = [C.c_void_p, C.POINTER(_Surface), C.c_uint32, C.c_uint32]
+        L.oracle_waveform_mt.argtypes = [C.c_void_p, C.POINTER(_Surface), C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_histogram_counts_mt.argtypes = [C.c_void_p, C.POINTER(_Surface), C.c_uint32, C.c_uint32, C.c_uint32]
         L.oracle_stage_region.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.oracle_stage_region.restype = C.c_int
@@ -128,6 +131,25 @@ class COracle:
         self.lib.oracle_histogram_level(_ptr(tex), _ptr(hi), width, height, components, logscale, level_fixed, level_ratio)
         return tex.view(np.float32).reshape(256, 4), hi
 
+
+    # -- multi-threaded courtesy baselines (same results) --------------------------------
+    def vectorscope_mt(self, yuv, width, threads, reps=1):
+        out = np.empty((256, 256), dtype=np.uint8)
+        sd = self._surface(None, yuv, width, 2)
+        assert self.lib.oracle_vectorscope_mt(_ptr(out), C.byref(sd), threads, reps) == 0
+        return out
+
+    def waveform_mt(self, rgb, yuv, width, components, threads, reps=1):
+        out = np.empty((256, width, 4), dtype=np.uint8)
+        sd = self._surface(rgb, yuv, width, 2)
+        assert self.lib.oracle_waveform_mt(_ptr(out), C.byref(sd), components, threads, reps) == 0
+        return out
+
+    def histogram_counts_mt(self, rgb, yuv, width, components, threads, reps=1):
+        out = np.empty((256, 4), dtype=np.uint32)
+        sd = self._surface(rgb, yuv, width, 2)
+        assert self.lib.oracle_histogram_counts_mt(_ptr(out), C.byref(sd), components, threads, reps) == 0
+        return out
 
     def stage_region(self, plane, width, scale, x=0, y=0, cx=0, cy=0):
         """Scale + crop of cm_render_target; cx == 0 or cy == 0 selects the whole scaled frame."""
