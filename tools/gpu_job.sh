@@ -17,6 +17,7 @@ for s in $stages; do
     sweep) timeout 900 python tools/sweep.py $SWEEP_EXTRA --out $out/sweep.jsonl > $out/sweep.out 2> $out/sweep.log; rc=$? ;;
     prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof -o vss -- \
              python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu) > $out/prof.log 2>&1; rc=$? ;;
+    hbm)   timeout 300 ./tools/hbm_read_bench > $out/hbm_read.txt 2>&1; rc=$?; sort -k7 -n -r $out/hbm_read.txt | head -12 ;;
     lds)   timeout 300 ./tools/lds_atomic_bench > $out/lds_atomic.txt 2>&1; rc=$? ;;
     sweepq) timeout 900 python tools/sweep.py --quick --out $out/sweep.jsonl > $out/sweep.out 2> $out/sweep.log; rc=$? ;;
     pmc)   # PMC passes on their own (no --stats / sys-trace), per the MI355X guide

@@ -1,0 +1,98 @@
+// What does a plain streaming read reach on this chip?  The yardstick for the scope kernels' roofline fractions:
+// every variant reads the same 1 GiB (32 x 4K BGRA8 frames' worth) of HBM-resident data with 16-byte loads and
+// reduces it to one word per lane (XOR), so nothing but the loads can be the bound.
+//   build: hipcc --offload-arch=gfx950 -O3 -o tools/hbm_read_bench tools/hbm_read_bench.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef uint32_t v4 __attribute__((vector_size(16)));
+
+template <int U, bool NT> __global__ __launch_bounds__(1024) void read_kernel(const v4 *src, uint64_t n16, uint32_t *sink)
+{
+	// workgroup g streams its contiguous share; lanes interleave at 16 B (a wave covers 1 KiB per load)
+	const uint64_t per = (n16 + gridDim.x - 1) / gridDim.x;
+	const uint64_t b0 = (uint64_t)blockIdx.x * per, b1 = (b0 + per < n16) ? b0 + per : n16;
+	v4 acc = {0, 0, 0, 0};
+	uint64_t i = b0 + threadIdx.x;
+	for (; i + (uint64_t)(U - 1) * blockDim.x < b1; i += (uint64_t)U * blockDim.x) {
+		v4 t[U];
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			t[k] = NT ? __builtin_nontemporal_load(src + i + (uint64_t)k * blockDim.x) : src[i + (uint64_t)k * blockDim.x];
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			acc ^= t[k];
+	}
+	for (; i < b1; i += blockDim.x)
+		acc ^= src[i];
+	const uint32_t r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+	if (r == 0x12345678u)
+		sink[0] = r; // never true for the test pattern; keeps the loads alive
+}
+
+template <int U, bool NT> static float run(const v4 *src, uint64_t n16, uint32_t *sink, int grid, int block, int reps)
+{
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0);
+	hipEventCreate(&e1);
+	for (int i = 0; i < 3; i++)
+		hipLaunchKernelGGL((read_kernel<U, NT>), dim3(grid), dim3(block), 0, 0, src, n16, sink);
+	hipEventRecord(e0, 0);
+	for (int i = 0; i < reps; i++)
+		hipLaunchKernelGGL((read_kernel<U, NT>), dim3(grid), dim3(block), 0, 0, src, n16, sink);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	return ms / reps;
+}
+
+__global__ void fill_kernel(uint32_t *p, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		p[i] = (uint32_t)(i * 2654435761u) | 1u;
+}
+
+int main()
+{
+	const uint64_t bytes = 32ull * 3840 * 2160 * 4;
+	const uint64_t n16 = bytes / 16;
+	uint32_t *buf, *sink;
+	if (hipMalloc((void **)&buf, bytes) != hipSuccess || hipMalloc((void **)&sink, 64) != hipSuccess) {
+		fprintf(stderr, "hipMalloc failed\n");
+		return 1;
+	}
+	hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf, bytes / 4);
+	hipDeviceSynchronize();
+	// clocks up
+	for (int i = 0; i < 200; i++)
+		hipLaunchKernelGGL((read_kernel<4, true>), dim3(256), dim3(1024), 0, 0, (const v4 *)buf, n16, sink);
+	hipDeviceSynchronize();
+	printf("# %llu bytes per pass; GB/s = bytes / time of one kernel (HIP events over 50 back-to-back launches)\n",
+	       (unsigned long long)bytes);
+	const int grids[] = {256, 512, 1024, 2048, 8192, 32768};
+	const int blocks[] = {1024, 512, 256};
+	for (int nt = 0; nt < 2; nt++)
+		for (int u = 0; u < 3; u++)
+			for (int b : blocks)
+				for (int g : grids) {
+					float ms;
+					if (nt)
+						ms = u == 0 ? run<2, true>((const v4 *)buf, n16, sink, g, b, 50)
+						   : u == 1 ? run<4, true>((const v4 *)buf, n16, sink, g, b, 50)
+							    : run<8, true>((const v4 *)buf, n16, sink, g, b, 50);
+					else
+						ms = u == 0 ? run<2, false>((const v4 *)buf, n16, sink, g, b, 50)
+						   : u == 1 ? run<4, false>((const v4 *)buf, n16, sink, g, b, 50)
+							    : run<8, false>((const v4 *)buf, n16, sink, g, b, 50);
+					printf("nt=%d unroll=%d block=%4d grid=%6d  %8.4f ms  %8.1f GB/s\n", nt, u == 0 ? 2 : u == 1 ? 4 : 8, b, g,
+					       ms, bytes / (ms * 1e-3) / 1e9);
+				}
+	hipFree(buf);
+	hipFree(sink);
+	return 0;
+}
