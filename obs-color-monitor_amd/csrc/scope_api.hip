@@ -498,9 +498,10 @@ int scope_ctx_create(int device, scope_ctx **out)
 	}
 	ctx->tn.vss_merge = 3;
 	ctx->tn.vss_unroll = 4;
+	ctx->tn.vss_fused_unroll = 2;
 	ctx->tn.vss_hash = 0;
 	ctx->tn.vss_groups_log2 = 3;
-	ctx->tn.his_unroll = 2;
+	ctx->tn.his_unroll = 1;
 	ctx->tn.wvs_wide = 1;
 	ctx->tn.wvs_persist = 1;
 	ctx->tn.fold = 1;
@@ -583,6 +584,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.vss_merge = value;
 	else if (!strcmp(key, "vss.unroll"))
 		ctx->tn.vss_unroll = value;
+	else if (!strcmp(key, "vss.fused_unroll"))
+		ctx->tn.vss_fused_unroll = value;
 	else if (!strcmp(key, "vss.hash"))
 		ctx->tn.vss_hash = value;
 	else if (!strcmp(key, "vss.groups"))

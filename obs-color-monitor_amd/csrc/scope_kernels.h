@@ -49,10 +49,11 @@ struct ScopeK0 {
 /* Tunables the host may flip for A/B runs (scope_ctx_set_option). */
 struct ScopeTuning {
 	int vss_merge;       /* 0 plain adds, 1|2 absorb mode always, 3 absorb mode by wave vote (default) */
-	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 4 or 8 */
+	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 1, 2 or 4 */
+	int vss_fused_unroll; /* the same for the fused-K0 form (VALU-bound: a shallower pipeline is enough) */
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3 */
-	int his_unroll;      /* 2 or 4 */
+	int his_unroll;      /* 1, 2 or 4; more bytes in flight than ~32 KiB per CU LOWER the achieved bandwidth */
 	int fold;            /* 1: histogram partials are summed by the last workgroup of a frame when they are few */
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
 	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */

@@ -693,7 +693,9 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
  * ---------------------------------------------------------------------------------------- */
 
 #define WVS_CH_WORDS 8192u
-#define WVS_U 4 /* row pairs per wave per batch; two batches in flight */
+#ifndef WVS_U
+#define WVS_U 2 /* row pairs per wave per batch; two batches in flight (measured: 2 beats 4 by 4 %, 1 loses 17 %) */
+#endif
 
 /* Counter of (value, column c of the strip): 16-bit half (c & 1) of word value*32 + (c >> 1).
  *
@@ -1143,11 +1145,11 @@ template <int U> hipError_t vss_pick_nt(int nt, int merge, int fuse, int hash, c
 }
 hipError_t vss_pick(int unroll, int nt, int merge, int fuse, int hash, const VssArgs *a)
 {
-	if (merge >= 3 && unroll > 4)
-		unroll = 4; /* the adaptive variant keeps a whole batch of bin indices live: 8 cells would spill */
-	if (unroll <= 4)
-		return vss_pick_nt<4>(nt, merge, fuse, hash, a);
-	return vss_pick_nt<8>(nt, merge, fuse, hash, a);
+	if (unroll <= 1)
+		return vss_pick_nt<1>(nt, merge, fuse, hash, a);
+	if (unroll == 2)
+		return vss_pick_nt<2>(nt, merge, fuse, hash, a);
+	return vss_pick_nt<4>(nt, merge, fuse, hash, a);
 }
 
 struct HisArgs {
@@ -1179,7 +1181,9 @@ template <int U> hipError_t his_pick_nt(int nt, int fuse, const HisArgs *a)
 }
 hipError_t his_pick(int unroll, int nt, int fuse, const HisArgs *a)
 {
-	if (unroll <= 2)
+	if (unroll <= 1)
+		return his_pick_nt<1>(nt, fuse, a);
+	if (unroll == 2)
 		return his_pick_nt<2>(nt, fuse, a);
 	return his_pick_nt<4>(nt, fuse, a);
 }
@@ -1232,7 +1236,7 @@ hipError_t wvs_pick(u32 chmask, int fuse, int wide, const WvsArgs *a)
 hipError_t scope_kernels_init(void)
 {
 	hipError_t e = hipSuccess;
-	for (int unroll = 2; unroll <= 8; unroll *= 2)
+	for (int unroll = 1; unroll <= 4; unroll *= 2)
 		for (int nt = 0; nt < 2; nt++)
 			for (int fuse = 0; fuse < 2; fuse++) {
 				for (int merge = 0; merge < 4; merge++)
@@ -1290,7 +1294,7 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 	if (glog2 > 3)
 		glog2 = 3; /* lane groups of >= 8 lanes: every request still covers a whole 128-byte line */
 	const VssArgs a = {&fs, slices, glog2, split_regions(fs), scope_k0_matrix(colorspace), dst, st};
-	return vss_pick(tn.vss_unroll, tn.nt_loads, tn.vss_merge, fuse_k0, tn.vss_hash, &a);
+	return vss_pick(fuse_k0 ? tn.vss_fused_unroll : tn.vss_unroll, tn.nt_loads, tn.vss_merge, fuse_k0, tn.vss_hash, &a);
 }
 
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,

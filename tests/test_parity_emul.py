@@ -28,7 +28,7 @@ def test_vectorscope_merge_and_hash_variants(emul_ctx, oracle, merge, hash_):
 
 
 @pytest.mark.parametrize("groups", [0, 1, 2, 3])
-@pytest.mark.parametrize("unroll", [2, 4])
+@pytest.mark.parametrize("unroll", [1, 2, 4])
 def test_vectorscope_lane_groups(emul_ctx, oracle, groups, unroll):
     """Lane groups walk separate streams of the slice; every split must cover each pixel once."""
     with pc.options(emul_ctx, **{"vss.groups": groups, "vss.unroll": unroll, "nt": groups & 1}):

@@ -45,7 +45,7 @@ def test_geometry_all_scopes(hip_ctx, oracle, w, h, ls):
 
 
 @pytest.mark.parametrize("merge", [0, 1, 2, 3])
-@pytest.mark.parametrize("unroll", [2, 4])
+@pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("hash_", [0, 1])
 def test_vectorscope_variants(hip_ctx, oracle, merge, unroll, hash_):
     with pc.options(hip_ctx, **{"vss.merge": merge, "vss.unroll": unroll, "vss.hash": hash_}):

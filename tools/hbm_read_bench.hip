@@ -32,6 +32,72 @@ template <int U, bool NT> __global__ __launch_bounds__(1024) void read_kernel(co
 		sink[0] = r; // never true for the test pattern; keeps the loads alive
 }
 
+// Persistent workgroups, chunk-interleaved: workgroup g reads chunks g, g+G, g+2G, ... of blockDim*U*16 bytes, so the
+// chip as a whole sweeps memory linearly (what a huge grid of small workgroups does) and every lane keeps two batches
+// of U loads in flight (ping-pong), as the scope kernels do.  STREAMS > 1 splits a wave into lane groups that read
+// STREAMS far-apart sub-ranges of the workgroup's data instead (the vectorscope's lane groups).
+template <int U, bool NT, int MODE> __global__ __launch_bounds__(1024) void read_pp(const v4 *src, uint64_t n16, uint32_t *sink)
+{
+	v4 acc = {0, 0, 0, 0};
+	const uint64_t chunk = (uint64_t)blockDim.x * U;
+	const uint64_t nchunks = n16 / chunk; // the tail is ignored (< 0.01 %)
+	v4 a[U], b[U];
+	auto idx = [&](uint64_t c, int k) -> uint64_t {
+		if (MODE == 0) // interleaved chunks
+			return (c * gridDim.x + blockIdx.x) * chunk + (uint64_t)k * blockDim.x + threadIdx.x;
+		// contiguous share per workgroup (MODE 1), optionally 8 lane-group streams inside it (MODE 2)
+		const uint64_t per = nchunks / gridDim.x;
+		if (MODE == 1)
+			return ((uint64_t)blockIdx.x * per + c) * chunk + (uint64_t)k * blockDim.x + threadIdx.x;
+		const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, grp = lane >> 3, sub = lane & 7u;
+		const uint64_t stream_cells = per * chunk / 8; // cells per lane-group stream
+		const uint64_t base = (uint64_t)blockIdx.x * per * chunk + grp * stream_cells;
+		// within a stream: waves interleave 8 lanes (128 B) each
+		return base + (c * U + k) * (uint64_t)(blockDim.x >> 3) + wave * 8u + sub;
+	};
+	const uint64_t mine = (MODE == 0) ? (nchunks - blockIdx.x + gridDim.x - 1) / gridDim.x : nchunks / gridDim.x;
+	auto issue = [&](v4(&t)[U], uint64_t c) {
+		const uint64_t cc = c < mine ? c : 0;
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			t[k] = NT ? __builtin_nontemporal_load(src + idx(cc, k)) : src[idx(cc, k)];
+	};
+	auto use = [&](v4(&t)[U]) {
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			acc ^= t[k];
+	};
+	issue(a, 0);
+	for (uint64_t c = 0; c < mine; c += 2) {
+		issue(b, c + 1);
+		use(a);
+		issue(a, c + 2);
+		use(b);
+	}
+	const uint32_t r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+	if (r == 0x12345678u)
+		sink[0] = r;
+}
+
+template <int U, bool NT, int MODE> static float run_pp(const v4 *src, uint64_t n16, uint32_t *sink, int grid, int block, int reps)
+{
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0);
+	hipEventCreate(&e1);
+	for (int i = 0; i < 3; i++)
+		hipLaunchKernelGGL((read_pp<U, NT, MODE>), dim3(grid), dim3(block), 0, 0, src, n16, sink);
+	hipEventRecord(e0, 0);
+	for (int i = 0; i < reps; i++)
+		hipLaunchKernelGGL((read_pp<U, NT, MODE>), dim3(grid), dim3(block), 0, 0, src, n16, sink);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	return ms / reps;
+}
+
 template <int U, bool NT> static float run(const v4 *src, uint64_t n16, uint32_t *sink, int grid, int block, int reps)
 {
 	hipEvent_t e0, e1;
@@ -92,6 +158,16 @@ int main()
 					printf("nt=%d unroll=%d block=%4d grid=%6d  %8.4f ms  %8.1f GB/s\n", nt, u == 0 ? 2 : u == 1 ? 4 : 8, b, g,
 					       ms, bytes / (ms * 1e-3) / 1e9);
 				}
+	printf("# persistent workgroups with two batches in flight: mode 0 chunk-interleaved, 1 contiguous share, 2 contiguous share\n"
+	       "# walked as 8 lane-group streams\n");
+#define PP(U, MODE)                                                                                                     \
+	for (int b : {1024, 512, 256})                                                                                  \
+		for (int g : {256, 512}) {                                                                              \
+			const float ms = run_pp<U, true, MODE>((const v4 *)buf, n16, sink, g, b, 50);                   \
+			printf("pp nt=1 unroll=%d mode=%d block=%4d grid=%6d  %8.4f ms  %8.1f GB/s\n", U, MODE, b, g, ms,      \
+			       bytes / (ms * 1e-3) / 1e9);                                                              \
+		}
+	PP(1, 0) PP(2, 0) PP(4, 0) PP(1, 1) PP(2, 1) PP(4, 1) PP(1, 2) PP(2, 2) PP(4, 2)
 	hipFree(buf);
 	hipFree(sink);
 	return 0;

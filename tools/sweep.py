@@ -126,7 +126,7 @@ def main():
                     for hash_ in (0, 1):
                         for nt in (0, 1):
                             vss_run(batch, d, **{"vss.merge": merge, "vss.groups": groups, "vss.hash": hash_, "nt": nt})
-            for unroll in (2, 8):
+            for unroll in (1, 2):
                 vss_run(batch, d, **{"vss.unroll": unroll})
                 vss_run(batch, d, **{"vss.unroll": unroll, "vss.hash": 1, "vss.groups": 2})
             vss_run(batch, d, **{"vss.merge": 1})
@@ -180,14 +180,14 @@ def main():
         for d in dists:
             rgb, yuv = data[d]
             batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-            for unroll in (2, 4, 8):
+            for unroll in (1, 2, 4):
                 for nt in (0, 1):
                     ctx.set_option("his.unroll", unroll)
                     ctx.set_option("nt", nt)
                     for comp in (0x07, 0x02):
                         k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt, sync=False))
                         report("his_batch", k, wall, l, n, 4096, dist=d, unroll=unroll, nt=nt, comp=hex(comp))
-        ctx.set_option("his.unroll", 2)
+        ctx.set_option("his.unroll", 1)
         ctx.set_option("nt", 1)
 
     # ---- F: waveform ------------------------------------------------------------------------------------
@@ -232,6 +232,33 @@ def main():
             ms = (time.perf_counter() - t0) / reps * 1e3
             emit(dict(tag="host_call", scope=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1),
                       gpix=round(W * H / (ms * 1e-3) / 1e9, 2), note="pageable host plane in, table out, synchronous"))
+
+    # ---- H: bytes in flight: loads per lane per batch (two batches in flight) for K1 and K3 -------------------
+    if "H" in sec:
+        cnt_h = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+        for d in dists:
+            rgb, yuv = data[d]
+            batch = ctx.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
+            batch_rgb = ctx.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+            for unroll in (1, 2, 4):
+                for merge in (0, 3):
+                    for groups in (0, 2, 3):
+                        for k, v in {"vss.merge": merge, "vss.unroll": unroll, "vss.hash": 0, "vss.groups": groups, "nt": 1}.items():
+                            ctx.set_option(k, v)
+                        k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch, tab, sync=False))
+                        report("vss_inflight", k, wall, l, n, 65536, dist=d, unroll=unroll, merge=merge, groups=groups)
+                ctx.set_option("vss.merge", 3)
+                ctx.set_option("vss.groups", 3)
+                ctx.set_option("vss.fused_unroll", unroll)
+                k, wall, l = timed(ctx, lambda: ctx.vectorscope_batch_dev(batch_rgb, tab, sync=False))
+                report("vss_fused_inflight", k, wall, l, n, 65536, dist=d, unroll=unroll)
+                ctx.set_option("his.unroll", unroll)
+                for comp in (0x07, 0x02):
+                    k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt_h, sync=False))
+                    report("his_inflight", k, wall, l, n, 4096, dist=d, unroll=unroll, comp=hex(comp))
+        ctx.set_option("vss.unroll", 4)
+        ctx.set_option("vss.fused_unroll", 2)
+        ctx.set_option("his.unroll", 1)
 
     out.close()
     ctx.close()
