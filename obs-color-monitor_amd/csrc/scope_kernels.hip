@@ -470,6 +470,8 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		}
 		since_clamp += px;
 	};
+	u32 vote_clock = 0;          /* wave-uniform: every lane runs the same batches */
+	bool absorb_verdict = false; /* wave-uniform: comes out of a ballot */
 	if (VECW == 4) {
 		scope_stream<4, U, NT>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch,
 				       [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
@@ -483,18 +485,23 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 						       for (int j = 0; j < 4; j++)
 							       idx[k][j] = vss_bin(p[j]);
 					       }
-					       /* MERGE 3: ONE vote per batch (16 pixels per lane): does at least a quarter of the wave
-						* hold nothing but single-colour cells?  Then it sits on flat content and runs
-						* this batch in absorb mode; noisy video never passes the vote and only pays the
-						* plain adds.  (A vote per cell costs more in SALU round trips than it saves.) */
+					       /* MERGE 3: a wave vote -- does at least a quarter of the wave hold nothing but
+						* single-colour cells in this batch (16 pixels per lane)?  Then it sits on flat content
+						* and runs in absorb mode; noisy video never passes the vote and only pays the plain
+						* adds.  Content is spatially coherent, so the vote is taken on every fourth batch and
+						* the verdict kept in between (either mode is exact; the choice is about speed only,
+						* and a vote per cell or even per batch costs more than it saves). */
 					       bool absorb = MERGE == 1 || MERGE == 2;
 					       if (MERGE == 3) {
-						       bool flat = true;
+						       if ((vote_clock++ & 3u) == 0) {
+							       bool flat = true;
 #pragma unroll
-						       for (int k = 0; k < U; k++)
-							       flat &= !ok[k] || ((idx[k][0] == idx[k][1]) & (idx[k][1] == idx[k][2]) &
-										  (idx[k][2] == idx[k][3]));
-						       absorb = __popcll(__ballot(flat)) >= 16;
+							       for (int k = 0; k < U; k++)
+								       flat &= !ok[k] || ((idx[k][0] == idx[k][1]) & (idx[k][1] == idx[k][2]) &
+											  (idx[k][2] == idx[k][3]));
+							       absorb_verdict = __popcll(__ballot(flat)) >= 16;
+						       }
+						       absorb = absorb_verdict;
 					       }
 					       if (absorb) {
 #pragma unroll
