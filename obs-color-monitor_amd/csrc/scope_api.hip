@@ -195,6 +195,16 @@ int check_flags(scope_ctx *ctx, uint32_t flags)
 }
 
 /* How many workgroups share one frame so that one launch covers the chip once. */
+/* The streaming kernels address a slice with 32-bit byte offsets from its first row: a frame whose rows span
+ * 2 GiB or more (huge pitch padding, or > 2^29 pixels) must be cut into at least this many slices.  0 = too big
+ * for the 256 partial tables the reductions accept. */
+uint32_t min_slices_for_span(uint32_t linesize, uint32_t height)
+{
+	const uint64_t span = (uint64_t)linesize * height;
+	const uint64_t need = span / (1ull << 31) + 1;
+	return need > 256 ? 0u : (uint32_t)need;
+}
+
 uint32_t pick_slices(const scope_ctx *ctx, uint32_t frames_in_launch, uint32_t units_per_frame)
 {
 	if (ctx->slices_override > 0)
@@ -252,7 +262,12 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 		if (st)
 			return st;
 		uint8_t *dst = dev_out + (size_t)f0 * SCOPE_VSS_BINS;
-		const uint32_t slices = pick_slices(ctx, nf, 1);
+		uint32_t slices = pick_slices(ctx, nf, 1);
+		const uint32_t min_slices = min_slices_for_span(fs.linesize, height);
+		if (min_slices == 0)
+			return fail(ctx, SCOPE_EINVAL, "pitch * height too large", hipSuccess);
+		if (slices < min_slices)
+			slices = min_slices;
 		if (slices == 1) {
 			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, ctx->tn, ctx->stream));
 		} else {
@@ -339,7 +354,12 @@ int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint
 		if (st)
 			return st;
 		uint32_t *dst = (uint32_t *)(dev_out + (size_t)f0 * table);
-		const uint32_t slices = pick_slices(ctx, nf, 1);
+		uint32_t slices = pick_slices(ctx, nf, 1);
+		const uint32_t min_slices = min_slices_for_span(fs.linesize, height);
+		if (min_slices == 0)
+			return fail(ctx, SCOPE_EINVAL, "pitch * height too large", hipSuccess);
+		if (slices < min_slices)
+			slices = min_slices;
 		if (slices == 1) {
 			TIMED_LAUNCH(ctx, scope_launch_his(fs, 1, chmask, fuse, colorspace, dst, NULL, NULL, ctx->tn, ctx->stream));
 		} else {
@@ -586,6 +606,10 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.vss_unroll = value;
 	else if (!strcmp(key, "vss.fused_unroll"))
 		ctx->tn.vss_fused_unroll = value;
+	else if (!strcmp(key, "vss.block"))
+		ctx->tn.vss_block = value;
+	else if (!strcmp(key, "his.block"))
+		ctx->tn.his_block = value;
 	else if (!strcmp(key, "vss.hash"))
 		ctx->tn.vss_hash = value;
 	else if (!strcmp(key, "vss.groups"))

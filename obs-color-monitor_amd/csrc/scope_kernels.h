@@ -54,6 +54,7 @@ struct ScopeTuning {
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3 */
 	int his_unroll;      /* 1, 2 or 4; more bytes in flight than ~32 KiB per CU LOWER the achieved bandwidth */
+	int vss_block, his_block; /* threads per workgroup (0 = SCOPE_BLOCK) */
 	int fold;            /* 1: histogram partials are summed by the last workgroup of a frame when they are few */
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
 	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */

@@ -269,16 +269,25 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	const u32 batches = (longest + step - 1u) / step;
 
 	u32 c = s0 + wave * lg + (lane & (lg - 1u));
-	u32 row = c / ncols;
-	u32 col = c - row * ncols;
 	const u32 dq = tg / ncols;
 	const u32 dr = tg - dq * ncols;
 
-	/* Loads are unconditional (lanes past their stream re-read the slice's first cell) so that the
+	/* Addresses: a wave-uniform base (the slice's first row) plus a 32-bit byte offset per lane that is
+	 * advanced incrementally -- d_off per load, plus the pitch padding whenever the column wraps -- so a load
+	 * costs a handful of 32-bit operations instead of 64-bit multiply-adds.  (The launchers keep a slice's
+	 * span below 4 GiB.)
+	 * Loads are unconditional (lanes past their stream re-read the slice's first cell) so that the
 	 * compiler can count them, and the two register sets A/B are used ping-pong without copies:
 	 * the wait before binning a batch is vmcnt(U) and the next batch stays in flight. */
+	const u32 cell_bytes = 4u * VECW;
 	const u32 row0 = c0 / ncols;
-	const size_t safe_off = (size_t)row0 * linesize + xbyte0 + (size_t)(c0 - row0 * ncols) * (4 * VECW);
+	const uint8_t *base = plane + (size_t)row0 * linesize + xbyte0;
+	const u32 safe_off = (c0 - row0 * ncols) * cell_bytes;
+	const u32 row = c / ncols;
+	u32 col = c - row * ncols;
+	u32 off = (row - row0) * linesize + col * cell_bytes;
+	const u32 d_off = dq * linesize + dr * cell_bytes;
+	const u32 wrap_off = linesize - ncols * cell_bytes; /* what a column wrap adds on top: the pitch padding */
 	vec_t va[U], vb[U];
 	bool oka[U], okb[U];
 
@@ -287,13 +296,12 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 		_Pragma("unroll") for (int k = 0; k < U; k++)                                          \
 		{                                                                                      \
 			ok[k] = (c + (u32)k * tg) < s1;                                                \
-			const size_t off = (size_t)row * linesize + xbyte0 + (size_t)col * (4 * VECW); \
-			v[k] = scope_load<NT>((const vec_t *)(plane + (ok[k] ? off : safe_off)));      \
-			row += dq;                                                                     \
+			v[k] = scope_load_base<NT, vec_t>(base, ok[k] ? off : safe_off);               \
+			off += d_off;                                                                  \
 			col += dr;                                                                     \
 			if (col >= ncols) {                                                            \
 				col -= ncols;                                                          \
-				row += 1;                                                              \
+				off += wrap_off;                                                       \
 			}                                                                              \
 		}                                                                                      \
 		c += step;                                                                             \
@@ -1112,7 +1120,7 @@ const u32 WVS_LDS_BYTES = 3u * WVS_CH_WORDS * 4u;
  * (scope_kernels_init walks all variants once with allow = true). */
 struct VssArgs {
 	const ScopeFrameSet *fs;
-	u32 slices, glog2;
+	u32 slices, glog2, block;
 	Regions rg;
 	ScopeK0 k0;
 	uint8_t *dst;
@@ -1124,7 +1132,7 @@ template <int U, bool NT, int MERGE, bool FUSE, int HASH> hipError_t vss_variant
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_vss_kernel<U, NT, MERGE, FUSE, HASH>,
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)VSS_LDS_BYTES);
-	hipLaunchKernelGGL((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK),
+	hipLaunchKernelGGL((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(a->block),
 			   VSS_LDS_BYTES, a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->k0,
 			   a->dst);
 	return hipGetLastError();
@@ -1161,7 +1169,7 @@ hipError_t vss_pick(int unroll, int nt, int merge, int fuse, int hash, const Vss
 
 struct HisArgs {
 	const ScopeFrameSet *fs;
-	u32 slices, chmask;
+	u32 slices, chmask, block;
 	Regions rg;
 	ScopeK0 k0;
 	u32 *dst, *folded, *tickets;
@@ -1173,7 +1181,7 @@ template <int U, bool NT, bool FUSE> hipError_t his_variant(const HisArgs *a)
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_his_kernel<U, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
 					   (int)HIS_LDS_BYTES);
-	hipLaunchKernelGGL((scope_his_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), HIS_LDS_BYTES,
+	hipLaunchKernelGGL((scope_his_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->slices), dim3(a->block), HIS_LDS_BYTES,
 			   a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->chmask, a->k0, a->dst, a->folded,
 			   a->tickets);
 	return hipGetLastError();
@@ -1294,13 +1302,22 @@ hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *d
 	return hipGetLastError();
 }
 
+/* threads per workgroup: a multiple of 64 up to SCOPE_BLOCK (the kernels size their loops by blockDim) */
+static u32 scope_block(int requested)
+{
+	if (requested < 64)
+		return SCOPE_BLOCK;
+	const u32 b = (u32)requested & ~63u;
+	return b > SCOPE_BLOCK ? SCOPE_BLOCK : b;
+}
+
 hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
 			    const ScopeTuning &tn, hipStream_t st)
 {
 	u32 glog2 = tn.vss_groups_log2 < 0 ? 0u : (u32)tn.vss_groups_log2;
 	if (glog2 > 3)
 		glog2 = 3; /* lane groups of >= 8 lanes: every request still covers a whole 128-byte line */
-	const VssArgs a = {&fs, slices, glog2, split_regions(fs), scope_k0_matrix(colorspace), dst, st};
+	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), split_regions(fs), scope_k0_matrix(colorspace), dst, st};
 	return vss_pick(fuse_k0 ? tn.vss_fused_unroll : tn.vss_unroll, tn.nt_loads, tn.vss_merge, fuse_k0, tn.vss_hash, &a);
 }
 
@@ -1309,7 +1326,7 @@ hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t c
 {
 	if (!tickets || slices < 2)
 		folded = NULL;
-	const HisArgs a = {&fs, slices, chmask, split_regions(fs), scope_k0_matrix(colorspace), dst, folded, tickets, st};
+	const HisArgs a = {&fs, slices, chmask, scope_block(tn.his_block), split_regions(fs), scope_k0_matrix(colorspace), dst, folded, tickets, st};
 	return his_pick(tn.his_unroll, tn.nt_loads, fuse_k0, &a);
 }
 

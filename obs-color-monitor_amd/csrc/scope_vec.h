@@ -24,7 +24,22 @@ __device__ __forceinline__ float scope_f2_hi(scope_f2 v)
 	return v.y;
 }
 
-/* Sum over the 64 lanes of a wave; every lane must be active (uniform control flow). */
+/* Load of a V at `base + lane_off`, where `base` is wave-uniform: the base is pinned into SGPRs and the access is
+ * typed as global memory, so the load uses the scalar-base + 32-bit lane-offset addressing form and no 64-bit
+ * per-lane address arithmetic is needed.  NT = streaming (non-temporal) load. */
+template <bool NT, typename V> __device__ __forceinline__ V scope_load_base(const unsigned char *base, unsigned lane_off)
+{
+	typedef const __attribute__((address_space(1))) unsigned char *gptr;
+	const unsigned long long a = (unsigned long long)base;
+	const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+	const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+	gptr b = (gptr)(((unsigned long long)hi << 32) | lo);
+	const __attribute__((address_space(1))) V *p = (const __attribute__((address_space(1))) V *)(b + lane_off);
+	if (NT)
+		return __builtin_nontemporal_load(p);
+	return *p;
+}
+
 /* Streaming (non-temporal) load of one dword at `row + lane_off`, where `row` is wave-uniform.  The row
  * pointer is pinned into SGPRs and the access is typed as global memory so that the load uses the
  * scalar-base + 32-bit lane-offset addressing form: no 64-bit per-lane address arithmetic. */
@@ -50,6 +65,7 @@ __device__ __forceinline__ scope_u2 scope_load_row2_nt(const unsigned char *row,
 	return __builtin_nontemporal_load((const __attribute__((address_space(1))) scope_u2 *)(base + lane_off));
 }
 
+/* Sum over the 64 lanes of a wave; every lane must be active (uniform control flow). */
 __device__ __forceinline__ unsigned scope_wave_sum(unsigned x)
 {
 #pragma unroll

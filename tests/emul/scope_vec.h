@@ -27,6 +27,10 @@ static inline scope_f2 operator*(scope_f2 a, scope_f2 b)
 {
 	return scope_f2{a.x * b.x, a.y * b.y};
 }
+template <bool NT, typename V> static inline V scope_load_base(const unsigned char *base, unsigned lane_off)
+{
+	return *(const V *)(base + lane_off);
+}
 /* the emulated wave has one active lane */
 static inline unsigned scope_load_row_nt(const unsigned char *row, unsigned lane_off)
 {
