@@ -100,7 +100,7 @@ void *scope_ctx_get_stream(scope_ctx *ctx);
 int scope_ctx_sync(scope_ctx *ctx);
 int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
 /* Tunables for A/B measurements: "vss.merge" 0|2|3, "vss.unroll" 1|2|4, "vss.fused_unroll" 1|2|4, "vss.hash" 0|1, "vss.groups" 0..3,
- * "his.unroll" 1|2|4, "wvs.wide" 0|1, "wvs.persist" 0|1, "fold" 0|1, "nt" 0|1, "slices" (0 = automatic partition of a frame over
+ * "his.unroll" 1|2|4, "wvs.wide" 0|1, "wvs.persist" 0|1, "wvs.per_cu" 0|1|2, "vss.block" / "his.block" 0|64..1024, "fold" 0|1, "nt" 0|1, "slices" (0 = automatic partition of a frame over
  * workgroups).  The defaults are the measured best (profiles/). */
 int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value);
 const char *scope_strerror(int status);

@@ -524,6 +524,7 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.his_unroll = 1;
 	ctx->tn.wvs_wide = 1;
 	ctx->tn.wvs_persist = 1;
+	ctx->tn.wvs_per_cu = 1;
 	ctx->tn.fold = 1;
 	ctx->tn.nt_loads = 1;
 	ctx->err[0] = 0;
@@ -620,6 +621,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.his_unroll = value;
 	else if (!strcmp(key, "fold"))
 		ctx->tn.fold = value != 0;
+	else if (!strcmp(key, "wvs.per_cu"))
+		ctx->tn.wvs_per_cu = value;
 	else if (!strcmp(key, "wvs.persist"))
 		ctx->tn.wvs_persist = value != 0;
 	else if (!strcmp(key, "wvs.wide"))

@@ -56,6 +56,8 @@ struct ScopeTuning {
 	int his_unroll;      /* 1, 2 or 4; more bytes in flight than ~32 KiB per CU LOWER the achieved bandwidth */
 	int vss_block, his_block; /* threads per workgroup (0 = SCOPE_BLOCK) */
 	int fold;            /* 1: histogram partials are summed by the last workgroup of a frame when they are few */
+	int wvs_per_cu;      /* cap on persistent waveform workgroups per CU (0 = as many as fit); 1 keeps ~32 KiB of
+			      * loads in flight per CU, which is what the HBM likes best (+5 % for 1-2 channels) */
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
 	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */
 	int nt_loads;        /* 1: non-temporal pixel loads */

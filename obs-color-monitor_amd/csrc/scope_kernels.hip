@@ -1344,7 +1344,10 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 		wide = (((size_t)fs.plane[f]) & 7u) == 0;
 	/* persistent workgroups: as many as are resident at once (LDS- or thread-limited), each walks units */
 	const u32 lds = nch * WVS_CH_WORDS * 4u;
-	const u32 resident = max(1u, min((u32)(SCOPE_CU_LDS_BYTES / lds), (u32)(2048u / SCOPE_BLOCK))) * max(1u, num_cu);
+	u32 per_cu = max(1u, min((u32)(SCOPE_CU_LDS_BYTES / lds), (u32)(2048u / SCOPE_BLOCK)));
+	if (tn.wvs_per_cu > 0 && (u32)tn.wvs_per_cu < per_cu)
+		per_cu = (u32)tn.wvs_per_cu;
+	const u32 resident = per_cu * max(1u, num_cu);
 	const u32 total = fs.n_frames * strips * bands;
 	const u32 grid = (tn.wvs_persist && total > resident) ? resident : total;
 	const WvsArgs a = {&fs, strips, bands, lds, grid, scope_k0_matrix(colorspace), dst, st};
