@@ -20,6 +20,15 @@ def tile_rows(height: int, rank: int, world: int):
     return height * rank // world, height * (rank + 1) // world
 
 
+def tile_cols(width: int, rank: int, world: int, align: int = 64):
+    """Columns [c0, c1) of the frame owned by `rank` for the waveform: whole 64-column strips (the kernel's unit), so
+    every rank's slab is produced without partial strips.  A column's counters depend on that column only, so the
+    slabs are final: no collective, just concatenate (all_gather) if one owner needs the whole table."""
+    strips = (width + align - 1) // align
+    s0, s1 = strips * rank // world, strips * (rank + 1) // world
+    return min(s0 * align, width), min(s1 * align, width)
+
+
 class TableAllReduce:
     """Double-buffered all-reduce of per-rank tables.
 

@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 import obs_color_monitor_amd as ocm  # noqa: E402
 import scope_oracle  # noqa: E402
-from obs_color_monitor_amd.row_tiles import TableAllReduce, tile_rows  # noqa: E402
+from obs_color_monitor_amd.row_tiles import TableAllReduce, tile_cols, tile_rows  # noqa: E402
 
 
 def main():
@@ -52,6 +52,21 @@ def main():
         assert np.array_equal(got.numpy().reshape(256, 256), want), "row-tiled vectorscope != whole frame"
     for got, want in zip(results32, wants32):
         assert np.array_equal(got.numpy().view(np.uint32).reshape(256, 4), want), "row-tiled histogram != whole frame"
+    # waveform: ranks own column strips and need no reduction at all
+    w2, h2 = 200, 30  # 4 strips of 64 columns, the last one ragged
+    rgb = o.fill_frame(w2, h2, 5, 77)
+    yuv = o.rgb_to_yuv(rgb, w2, 2)
+    c0, c1 = tile_cols(w2, rank, world)
+    slabs = [None] * world
+    mine, st = ctx.waveform(rgb=np.ascontiguousarray(rgb[:, 4 * c0:4 * c1]), yuv=np.ascontiguousarray(yuv[:, 4 * c0:4 * c1]),
+                            width=c1 - c0, components=0x07)
+    assert st == 0
+    dist.all_gather_object(slabs, (c0, c1, mine))
+    whole = np.zeros((256, w2, 4), dtype=np.uint8)
+    for a, b, slab in slabs:
+        whole[:, a:b] = slab
+    assert sorted((a, b) for a, b, _ in slabs)[0][0] == 0 and max(b for _, b, _ in slabs) == w2
+    assert np.array_equal(whole, o.waveform(rgb, yuv, w2, 0x07)), "column-tiled waveform != whole frame"
     # a flat frame saturates on every rank: clamped partials 255 + 255 must still give 255
     assert wants[0].max() == 255
     dist.barrier()
