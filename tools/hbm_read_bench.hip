@@ -98,6 +98,85 @@ template <int U, bool NT, int MODE> static float run_pp(const v4 *src, uint64_t 
 	return ms / reps;
 }
 
+// Wave specialisation: the first LW waves of a 1024-thread workgroup only load (two chunks of U loads per lane in
+// flight, ping-pong) and hand the data over through a double-buffered LDS ring; the other waves consume it (here:
+// XOR).  One barrier per chunk.  Is this a way to combine the shallow, small-workgroup load pattern the HBM likes with
+// the 12+ waves of compute the scope kernels need?
+template <int U, int LW> __global__ __launch_bounds__(1024) void read_split(const v4 *src, uint64_t n16, uint32_t *sink)
+{
+	extern __shared__ v4 ring[]; // 2 x CH cells
+	constexpr uint32_t NL = LW * 64u, CH = NL * U;
+	const bool loader = threadIdx.x < NL;
+	const uint64_t nchunks = n16 / CH;
+	const uint64_t mine = (nchunks - blockIdx.x + gridDim.x - 1) / gridDim.x;
+	v4 acc = {0, 0, 0, 0};
+	v4 a[U], b[U];
+	auto issue = [&](v4(&t)[U], uint64_t c) {
+		const uint64_t cc = c < mine ? c : 0;
+		const v4 *p = src + (cc * gridDim.x + blockIdx.x) * CH + threadIdx.x;
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			t[k] = __builtin_nontemporal_load(p + (uint64_t)k * NL);
+	};
+	auto hand_over = [&](v4(&t)[U], uint64_t c) {
+		v4 *w = ring + (c & 1) * CH + threadIdx.x;
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			w[k * NL] = t[k];
+	};
+	auto consume = [&](uint64_t c) {
+		const v4 *r = ring + (c & 1) * CH;
+		for (uint32_t i = threadIdx.x - NL; i < CH; i += blockDim.x - NL)
+			acc ^= r[i];
+	};
+	if (loader) {
+		issue(a, 0);
+		issue(b, 1);
+	}
+	for (uint64_t c = 0; c < mine; c += 2) {
+		if (loader) {
+			hand_over(a, c);
+			issue(a, c + 2);
+		}
+		__syncthreads();
+		if (!loader)
+			consume(c);
+		if (c + 1 < mine) {
+			if (loader) {
+				hand_over(b, c + 1);
+				issue(b, c + 3);
+			}
+			__syncthreads();
+			if (!loader)
+				consume(c + 1);
+		}
+	}
+	const uint32_t r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+	if (r == 0x12345678u)
+		sink[0] = r;
+}
+
+template <int U, int LW> static float run_split(const v4 *src, uint64_t n16, uint32_t *sink, int grid, int reps)
+{
+	const size_t lds = 2u * LW * 64u * U * 16u;
+	hipFuncSetAttribute((const void *)read_split<U, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0);
+	hipEventCreate(&e1);
+	for (int i = 0; i < 3; i++)
+		hipLaunchKernelGGL((read_split<U, LW>), dim3(grid), dim3(1024), lds, 0, src, n16, sink);
+	hipEventRecord(e0, 0);
+	for (int i = 0; i < reps; i++)
+		hipLaunchKernelGGL((read_split<U, LW>), dim3(grid), dim3(1024), lds, 0, src, n16, sink);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	return ms / reps;
+}
+
 template <int U, bool NT> static float run(const v4 *src, uint64_t n16, uint32_t *sink, int grid, int block, int reps)
 {
 	hipEvent_t e0, e1;
@@ -168,6 +247,14 @@ int main()
 			       bytes / (ms * 1e-3) / 1e9);                                                              \
 		}
 	PP(1, 0) PP(2, 0) PP(4, 0) PP(1, 1) PP(2, 1) PP(4, 1) PP(1, 2) PP(2, 2) PP(4, 2)
+	printf("# wave-specialised: LW loader waves hand chunks to the other waves of a 1024-thread workgroup through LDS\n");
+#define SP(U, LW)                                                                                                       \
+	{                                                                                                               \
+		const float ms = run_split<U, LW>((const v4 *)buf, n16, sink, 256, 50);                                 \
+		printf("split unroll=%d loader_waves=%d ring=%d KiB  %8.4f ms  %8.1f GB/s\n", U, LW, 2 * LW * 64 * U * 16 / 1024, ms, \
+		       bytes / (ms * 1e-3) / 1e9);                                                                      \
+	}
+	SP(1, 4) SP(2, 4) SP(4, 4) SP(1, 8) SP(2, 8) SP(4, 2) SP(8, 2) SP(2, 2) SP(1, 2) SP(1, 6) SP(2, 6)
 	hipFree(buf);
 	hipFree(sink);
 	return 0;
