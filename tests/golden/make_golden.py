@@ -57,4 +57,20 @@ for (w, h, dist) in ((1280, 720, 1), (3840, 2160, 1), (3840, 2160, 2), (3840, 21
         hashes[key]["waveform_07"] = f"{o.fnv(o.waveform(rgb, yuv, w, 0x07)):016x}"
         hashes[key]["waveform_20"] = f"{o.fnv(o.waveform(rgb, yuv, w, 0x20)):016x}"
 json.dump(hashes, open(os.path.join(HERE, "fullsize_hashes.json"), "w"), indent=1, sort_keys=True)
+# capture pre-steps (target_scale / ROI) and graticule geometry: hashes of the oracle's outputs on the small fixture frame
+import graticule_oracle as go  # noqa: E402
+
+extra = {"stage_region": {}, "graticule": {}}
+frame = o.fill_frame(64, 36, 1, 0, 256)
+for region in ((1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (3, 0, 0, 0, 0), (2, 3, 1, 20, 11), (1, 7, 5, 40, 17), (5, 0, 0, 0, 0)):
+    extra["stage_region"]["s%d_x%d_y%d_%dx%d" % region] = f"{o.fnv(o.stage_region(frame, 64, *region)):016x}"
+for cs in (1, 2):
+    for flags in (1, 257):
+        labels, lines = go.vectorscope(cs, flags, 0x0054FF)
+        extra["graticule"][f"vss_cs{cs}_f{flags}"] = f"{o.fnv(labels):016x}:{o.fnv(lines):016x}"
+for display, n in ((0, 3), (1, 3), (2, 3), (1, 2)):
+    extra["graticule"][f"wvs_d{display}_n{n}"] = f"{o.fnv(go.waveform(5, display, n, 1920)):016x}"
+    extra["graticule"][f"his_d{display}_n{n}"] = f"{o.fnv(go.histogram(5, 50.0, 0, 200, 0, display, n, 200)):016x}"
+json.dump(extra, open(os.path.join(HERE, "capture_graticule_hashes.json"), "w"), indent=1, sort_keys=True)
+
 print("wrote", os.path.getsize(os.path.join(HERE, "small_frames.npz")), "bytes of small fixtures and", len(hashes), "hash sets")
