@@ -134,6 +134,20 @@ int scope_region_size(uint32_t width, uint32_t height, const struct scope_region
 int scope_stage_region(scope_ctx *ctx, const uint8_t *src, uint32_t src_linesize, uint32_t width, uint32_t height,
 		       const struct scope_region *region, uint8_t *dst, uint32_t dst_linesize, uint32_t flags);
 
+/* ---- one upload, several scopes ------------------------------------------------------------
+ * The ROI / dock source hands ONE staged surface to every registered scope (roi_surface_cb, src/roi.c:329-341); the
+ * three loops then read the same host planes.  Between scope_surface_begin() and scope_surface_end() the synchronous
+ * single-surface calls (scope_vectorscope / scope_waveform / scope_histogram_counts / scope_histogram with host planes)
+ * upload each distinct plane pointer once and reuse the device copy: the dock's three scopes cost two uploads (RGB,
+ * YUV) instead of three -- or one with SCOPE_FUSE_K0 here, which never uploads the YUV plane and lets scopes that want
+ * it convert the RGB plane on the fly (equal to the YUV plane this build's own K0 makes; the plugin's plane comes from
+ * OBS's shader, so this is opt-in).  All planes inside one begin/end share one geometry; at most two distinct planes.
+ * The context is locked from begin to end (other threads' calls wait), and every entry point of a context is
+ * serialised, so one context can be shared by the plugin's pipeline threads and its render thread.
+ * scope_surface_end reports how many planes were uploaded and how many uploads were saved (both may be NULL). */
+int scope_surface_begin(scope_ctx *ctx, uint32_t flags);
+int scope_surface_end(scope_ctx *ctx, uint32_t *uploads, uint32_t *reuses);
+
 /* ---- K1: vectorscope -----------------------------------------------------------------------
  * Replaces vss_draw_vectorscope(dbuf, surface_data) (src/vectorscope.c:217-238).
  * out = uint8[256][256].  Needs sd->yuv_data, or sd->rgb_data with SCOPE_FUSE_K0. */

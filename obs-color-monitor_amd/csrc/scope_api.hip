@@ -12,6 +12,8 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <mutex>
+#include <new>
 #include <stdlib.h>
 #include <string.h>
 
@@ -29,6 +31,21 @@ struct scope_ctx {
 	size_t stage_in_bytes;
 	uint8_t *stage_out; /* tables on their way to a host buffer */
 	size_t stage_out_bytes;
+	/* Every entry point that touches the context takes this lock, so one context may be shared by the plugin's
+	 * pipeline threads and its render thread (the reference runs one "color-monitor" thread per stand-alone
+	 * source, src/common.c:375-403).  Recursive: scope_surface_begin() keeps it until scope_surface_end(). */
+	std::recursive_mutex mu;
+	/* scope_surface_begin .. scope_surface_end: host planes uploaded once and reused by every scope call that is
+	 * handed the same plane (the ROI / dock fan-out) */
+	struct {
+		bool active, fuse_k0;
+		const uint8_t *host[2]; /* host plane a device copy stands for (NULL = slot free) */
+		uint8_t *dev[2];
+		size_t dev_bytes[2];
+		uint32_t linesize, width, height; /* geometry of the cached planes */
+		uint32_t pitch;                   /* of the device copies */
+		uint32_t uploads, hits;
+	} surf;
 	uint32_t *tickets; /* SCOPE_MAX_FRAMES arrival counters of the in-kernel reduction; zero between launches */
 	ScopeTuning tn;
 	int slices_override;
@@ -122,6 +139,38 @@ int stage_planes(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 	}
 	const size_t pitch = round_up((size_t)width * 4, 16);
 	const size_t plane_bytes = round_up(pitch * height, 256);
+	if (ctx->surf.active && n == 1) { /* one upload per plane between scope_surface_begin and _end */
+		if (ctx->surf.host[0] || ctx->surf.host[1]) {
+			if (ctx->surf.linesize != linesize || ctx->surf.width != width || ctx->surf.height != height)
+				return fail(ctx, SCOPE_EINVAL, "geometry changed inside scope_surface_begin/end", hipSuccess);
+		} else {
+			ctx->surf.linesize = linesize;
+			ctx->surf.width = width;
+			ctx->surf.height = height;
+			ctx->surf.pitch = (uint32_t)pitch;
+		}
+		int slot = -1;
+		for (int k = 0; k < 2; k++)
+			if (ctx->surf.host[k] == planes[0])
+				slot = k;
+		if (slot < 0) {
+			slot = ctx->surf.host[0] ? 1 : 0;
+			if (ctx->surf.host[slot])
+				return fail(ctx, SCOPE_EINVAL, "more than two planes inside scope_surface_begin/end", hipSuccess);
+			int st2 = grow(ctx, &ctx->surf.dev[slot], &ctx->surf.dev_bytes[slot], plane_bytes);
+			if (st2)
+				return st2;
+			HIP_TRY(ctx, hipMemcpy2DAsync(ctx->surf.dev[slot], pitch, planes[0], linesize, (size_t)width * 4, height,
+						      hipMemcpyHostToDevice, ctx->stream));
+			ctx->surf.host[slot] = planes[0];
+			ctx->surf.uploads++;
+		} else {
+			ctx->surf.hits++;
+		}
+		fs->plane[0] = ctx->surf.dev[slot];
+		fs->linesize = (uint32_t)pitch;
+		return SCOPE_OK;
+	}
 	int st = grow(ctx, &ctx->stage_in, &ctx->stage_in_bytes, plane_bytes * n);
 	if (st)
 		return st;
@@ -220,14 +269,22 @@ uint32_t pick_slices(const scope_ctx *ctx, uint32_t frames_in_launch, uint32_t u
 
 /* waveform.c:228-234 == histogram.c:367-373.  Returns 1 and fills plane/fuse when a plane is
  * selectable, 0 when `components` selects none, SCOPE_ENODATA when the selected one is NULL. */
-int pick_plane(const struct scope_surface_data *sd, uint32_t components, uint32_t flags, const uint8_t **plane, int *fuse)
+/* Inside scope_surface_begin(SCOPE_FUSE_K0) .. _end the YUV plane is never uploaded: scopes that want it read the
+ * (cached) RGB plane through the fused K0 instead. */
+bool surface_prefers_fused(const scope_ctx *ctx, const struct scope_surface_data *sd)
+{
+	return ctx->surf.active && ctx->surf.fuse_k0 && sd->rgb_data != NULL;
+}
+
+int pick_plane(const scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, uint32_t flags,
+	       const uint8_t **plane, int *fuse)
 {
 	*fuse = 0;
 	if (components & 0x07u) {
 		*plane = sd->rgb_data;
 	} else if (components & 0x70u) {
 		*plane = sd->yuv_data;
-		if (!*plane && (flags & SCOPE_FUSE_K0)) {
+		if ((!*plane || surface_prefers_fused(ctx, sd)) && ((flags & SCOPE_FUSE_K0) || surface_prefers_fused(ctx, sd))) {
 			*plane = sd->rgb_data;
 			*fuse = 1;
 		}
@@ -395,6 +452,12 @@ int zero_result(scope_ctx *ctx, void *out, size_t bytes, uint32_t flags)
 	return SCOPE_OK;
 }
 
+#define SCOPE_ENTER(ctx)                                                      \
+	if (!(ctx))                                                           \
+		return SCOPE_EINVAL;                                          \
+	std::lock_guard<std::recursive_mutex> scope_lock_((ctx)->mu);         \
+	int st = enter(ctx)
+
 int enter(scope_ctx *ctx)
 {
 	if (!ctx)
@@ -417,7 +480,7 @@ template <typename Launch>
 int display_run(scope_ctx *ctx, const void *table, size_t table_bytes, uint8_t *rgba, size_t out_bytes,
 		       uint32_t flags, Launch launch)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!table || !rgba)
@@ -491,18 +554,18 @@ int scope_ctx_create(int device, scope_ctx **out)
 		return SCOPE_ENODEV;
 	if (hipSetDevice(device) != hipSuccess)
 		return SCOPE_ENODEV;
-	scope_ctx *ctx = (scope_ctx *)calloc(1, sizeof *ctx);
+	scope_ctx *ctx = new (std::nothrow) scope_ctx();
 	if (!ctx)
 		return SCOPE_ENOMEM;
 	ctx->device = device;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
-		free(ctx);
+		delete ctx;
 		return SCOPE_ENODEV;
 	}
 	ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
-		free(ctx);
+		delete ctx;
 		return SCOPE_EIO;
 	}
 	ctx->stream = ctx->own_stream;
@@ -546,16 +609,19 @@ void scope_ctx_destroy(scope_ctx *ctx)
 		(void)hipFree(ctx->stage_out);
 	if (ctx->tickets)
 		(void)hipFree(ctx->tickets);
+	for (int k = 0; k < 2; k++)
+		if (ctx->surf.dev[k])
+			(void)hipFree(ctx->surf.dev[k]);
 	for (uint32_t i = 0; i < 2 * SCOPE_PROFILE_SLOTS; i++)
 		if (ctx->ev[i])
 			(void)hipEventDestroy(ctx->ev[i]);
 	(void)hipStreamDestroy(ctx->own_stream);
-	free(ctx);
+	delete ctx;
 }
 
 int scope_ctx_set_stream(scope_ctx *ctx, void *hip_stream)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -570,7 +636,7 @@ void *scope_ctx_get_stream(scope_ctx *ctx)
 
 int scope_ctx_sync(scope_ctx *ctx)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -579,7 +645,7 @@ int scope_ctx_sync(scope_ctx *ctx)
 
 int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!info)
@@ -601,6 +667,7 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 {
 	if (!ctx || !key)
 		return SCOPE_EINVAL;
+	std::lock_guard<std::recursive_mutex> lock(ctx->mu);
 	if (!strcmp(key, "vss.merge"))
 		ctx->tn.vss_merge = value;
 	else if (!strcmp(key, "vss.unroll"))
@@ -637,7 +704,7 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 int scope_convert_rgb_yuv(scope_ctx *ctx, const uint8_t *rgb, uint32_t rgb_linesize, uint8_t *yuv,
 			  uint32_t yuv_linesize, uint32_t width, uint32_t height, int colorspace, uint32_t flags)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!rgb || !yuv)
@@ -691,7 +758,7 @@ int scope_region_size(uint32_t width, uint32_t height, const struct scope_region
 int scope_stage_region(scope_ctx *ctx, const uint8_t *src, uint32_t src_linesize, uint32_t width, uint32_t height,
 		       const struct scope_region *region, uint8_t *dst, uint32_t dst_linesize, uint32_t flags)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!src || !dst || !region || region->scale == 0)
@@ -732,16 +799,56 @@ int scope_stage_region(scope_ctx *ctx, const uint8_t *src, uint32_t src_linesize
 	return SCOPE_OK;
 }
 
+int scope_surface_begin(scope_ctx *ctx, uint32_t flags)
+{
+	if (!ctx)
+		return SCOPE_EINVAL;
+	ctx->mu.lock(); /* held until scope_surface_end(): the fan-out of one surface is one critical section */
+	int st = enter(ctx);
+	if (!st && ctx->surf.active)
+		st = fail(ctx, SCOPE_EINVAL, "scope_surface_begin without scope_surface_end", hipSuccess);
+	if (!st && (flags & ~(uint32_t)SCOPE_FUSE_K0))
+		st = fail(ctx, SCOPE_EINVAL, "scope_surface_begin takes SCOPE_FUSE_K0 or 0", hipSuccess);
+	if (st) {
+		ctx->mu.unlock();
+		return st;
+	}
+	ctx->surf.active = true;
+	ctx->surf.fuse_k0 = (flags & SCOPE_FUSE_K0) != 0;
+	ctx->surf.host[0] = ctx->surf.host[1] = NULL;
+	ctx->surf.uploads = ctx->surf.hits = 0;
+	return SCOPE_OK;
+}
+
+int scope_surface_end(scope_ctx *ctx, uint32_t *uploads, uint32_t *reuses)
+{
+	if (!ctx)
+		return SCOPE_EINVAL;
+	std::unique_lock<std::recursive_mutex> probe(ctx->mu); /* recursive: succeeds for the owner of a begin */
+	if (!ctx->surf.active)
+		return SCOPE_EINVAL;
+	if (uploads)
+		*uploads = ctx->surf.uploads;
+	if (reuses)
+		*reuses = ctx->surf.hits;
+	ctx->surf.active = false;
+	ctx->surf.host[0] = ctx->surf.host[1] = NULL;
+	/* every call in between was synchronous (host planes), so nothing is in flight on the cached copies */
+	probe.unlock();
+	ctx->mu.unlock(); /* the lock scope_surface_begin() took */
+	return SCOPE_OK;
+}
+
 int scope_vectorscope(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t flags, uint8_t *out)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!sd || !out)
 		return fail(ctx, SCOPE_EINVAL, "NULL argument", hipSuccess);
 	const uint8_t *plane = sd->yuv_data;
 	int fuse = 0;
-	if (!plane && (flags & SCOPE_FUSE_K0)) {
+	if ((!plane && (flags & SCOPE_FUSE_K0)) || surface_prefers_fused(ctx, sd)) {
 		plane = sd->rgb_data;
 		fuse = 1;
 	}
@@ -755,7 +862,7 @@ int scope_vectorscope(scope_ctx *ctx, const struct scope_surface_data *sd, uint3
 
 int scope_vectorscope_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t flags, uint8_t *out)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!b || !out || !b->planes || b->n_frames == 0)
@@ -772,7 +879,7 @@ int scope_vectorscope_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_
 int scope_waveform(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, uint32_t flags,
 		   uint8_t *out)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!sd || !out)
@@ -780,7 +887,7 @@ int scope_waveform(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t
 	const size_t table = (size_t)SCOPE_WV_SIZE * sd->width * 4;
 	const uint8_t *plane = NULL;
 	int fuse = 0;
-	const int sel = pick_plane(sd, components, flags, &plane, &fuse);
+	const int sel = pick_plane(ctx, sd, components, flags, &plane, &fuse);
 	if (sel < 0)
 		return sel; /* wvs_surface_cb returns without drawing, src/waveform.c:276-281 */
 	if (sel == 0 || sd->height == 0 || sd->width == 0)
@@ -793,7 +900,7 @@ int scope_waveform(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t
 int scope_waveform_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
 			 uint8_t *out)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!b || !out || !b->planes || b->n_frames == 0)
@@ -816,14 +923,14 @@ int scope_waveform_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t c
 int scope_histogram_counts(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, uint32_t flags,
 			   uint32_t *counts)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!sd || !counts)
 		return fail(ctx, SCOPE_EINVAL, "NULL argument", hipSuccess);
 	const uint8_t *plane = NULL;
 	int fuse = 0;
-	const int sel = pick_plane(sd, components, flags, &plane, &fuse);
+	const int sel = pick_plane(ctx, sd, components, flags, &plane, &fuse);
 	if (sel < 0)
 		return sel; /* his_surface_cb returns without drawing, src/histogram.c:436-441 */
 	if (sel == 0 || sd->height == 0 || sd->width == 0)
@@ -836,7 +943,7 @@ int scope_histogram_counts(scope_ctx *ctx, const struct scope_surface_data *sd, 
 int scope_histogram_counts_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
 				 uint32_t *counts)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!b || !counts || !b->planes || b->n_frames == 0)
@@ -919,7 +1026,7 @@ int scope_histogram(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_
 
 int scope_table_widen_u8_u32(scope_ctx *ctx, const uint8_t *in, uint32_t *out, uint64_t n)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!in || !out)
@@ -930,7 +1037,7 @@ int scope_table_widen_u8_u32(scope_ctx *ctx, const uint8_t *in, uint32_t *out, u
 
 int scope_table_clamp_u32_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, uint64_t n)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!in || !out)
@@ -941,7 +1048,7 @@ int scope_table_clamp_u32_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, u
 
 int scope_table_pack_u8_u16x2(scope_ctx *ctx, const uint8_t *in, uint32_t *out, uint64_t n_pairs)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!in || !out)
@@ -952,7 +1059,7 @@ int scope_table_pack_u8_u16x2(scope_ctx *ctx, const uint8_t *in, uint32_t *out, 
 
 int scope_table_unpack_clamp_u16x2_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, uint64_t n_pairs)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!in || !out)
@@ -965,6 +1072,7 @@ int scope_ctx_profile(scope_ctx *ctx, int enable)
 {
 	if (!ctx)
 		return SCOPE_EINVAL;
+	std::lock_guard<std::recursive_mutex> lock(ctx->mu);
 	ctx->profile = enable != 0;
 	ctx->timed = 0;
 	return SCOPE_OK;
@@ -972,7 +1080,7 @@ int scope_ctx_profile(scope_ctx *ctx, int enable)
 
 int scope_ctx_kernel_ms(scope_ctx *ctx, uint32_t *launches, float *total_ms)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!launches || !total_ms)
@@ -1113,7 +1221,7 @@ void scope_pipe_destroy(scope_pipe *p)
 
 int scope_pipe_create(scope_ctx *ctx, const struct scope_pipe_config *cfg, scope_pipe **out)
 {
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (!cfg || !out || cfg->width == 0 || cfg->height == 0 || cfg->depth == 0 || cfg->depth > SCOPE_PIPE_MAX_DEPTH)
@@ -1182,7 +1290,7 @@ int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
 	if (!p || !rgb_host)
 		return SCOPE_EINVAL;
 	scope_ctx *ctx = p->ctx;
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if ((uint64_t)p->cfg.width * 4 > linesize)
@@ -1252,7 +1360,7 @@ int scope_pipe_collect(scope_pipe *p, const uint8_t **vectorscope, const uint8_t
 	if (!p)
 		return SCOPE_EINVAL;
 	scope_ctx *ctx = p->ctx;
-	int st = enter(ctx);
+	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
 	if (p->submitted == p->collected)

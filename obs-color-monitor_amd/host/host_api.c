@@ -49,6 +49,16 @@ uint64_t scope_host_frames_dropped(void *source)
 	return scope_host_cm(source)->frames_dropped;
 }
 
+uint64_t scope_host_plane_uploads(void *source)
+{
+	return scope_host_cm(source)->plane_uploads;
+}
+
+uint64_t scope_host_plane_reuses(void *source)
+{
+	return scope_host_cm(source)->plane_reuses;
+}
+
 /* The picture the source's video_render produced (RGBA8, row-major); NULL before the first render. */
 const uint8_t *scope_host_picture(void *source, int kind, uint32_t *width, uint32_t *height)
 {

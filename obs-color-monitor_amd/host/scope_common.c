@@ -58,8 +58,19 @@ static void cm_pipeline_thread_loop(struct cm_source *src, struct cm_surface_que
 	if (item->flags & CM_FLAG_CONVERT_YUV)
 		surface_data.yuv_data = video_data;
 
-	if (item->cb)
+	if (item->cb) {
+		/* one staged surface, possibly several scopes behind the callback (roi_surface_cb fans out, src/roi.c:329-341):
+		 * every plane crosses PCIe once however many of them read it */
+		const bool cached = scope_surface_begin(cm_gpu(), 0) == SCOPE_OK;
 		item->cb(item->cb_data, &surface_data);
+		if (cached) {
+			uint32_t uploads = 0, reuses = 0;
+			if (scope_surface_end(cm_gpu(), &uploads, &reuses) == SCOPE_OK) {
+				src->plane_uploads += uploads;
+				src->plane_reuses += reuses;
+			}
+		}
+	}
 	src->frames_processed++;
 }
 

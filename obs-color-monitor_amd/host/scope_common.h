@@ -77,6 +77,7 @@ struct cm_source {
 	bool bypass;
 
 	uint64_t frames_dropped, frames_processed;
+	uint64_t plane_uploads, plane_reuses; /* host->HBM uploads done / saved by the per-surface cache */
 };
 
 void cm_create(struct cm_source *src, obs_data_t *settings, obs_source_t *source); /* src/common.c:33-52 */

@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "scope_table_pack_u8_u16x2", "scope_table_unpack_clamp_u16x2_u8",
     "scope_ctx_profile", "scope_ctx_kernel_ms",
     "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect", "scope_pipe_size",
-    "scope_region_size", "scope_stage_region",
+    "scope_region_size", "scope_stage_region", "scope_surface_begin", "scope_surface_end",
     "scope_display_vectorscope", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
 )
 
@@ -137,6 +137,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_pipe_submit": (i32, [vp, vp, u32]),
         "scope_pipe_collect": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "scope_pipe_size": (i32, [vp, C.POINTER(u32), C.POINTER(u32)]),
+        "scope_surface_begin": (i32, [vp, u32]),
+        "scope_surface_end": (i32, [vp, C.POINTER(u32), C.POINTER(u32)]),
         "scope_region_size": (i32, [u32, u32, C.POINTER(Region), C.POINTER(u32), C.POINTER(u32)]),
         "scope_stage_region": (i32, [vp, vp, u32, u32, u32, C.POINTER(Region), vp, u32, u32]),
     }
@@ -219,6 +221,16 @@ class ScopeContext:
         self._check(self.L.scope_convert_rgb_yuv(self.h, _hptr(rgb), rgb.shape[1], _hptr(out), out.shape[1], width, h,
                                                  colorspace, 0))
         return out
+
+    def surface_begin(self, fuse_k0=False):
+        """Until surface_end(): host planes handed to the single-surface calls are uploaded once and reused."""
+        self._check(self.L.scope_surface_begin(self.h, FUSE_K0 if fuse_k0 else 0))
+
+    def surface_end(self):
+        """Returns (planes uploaded, uploads saved)."""
+        up, hit = C.c_uint32(), C.c_uint32()
+        self._check(self.L.scope_surface_end(self.h, C.byref(up), C.byref(hit)))
+        return int(up.value), int(hit.value)
 
     def region_size(self, width, height, scale, x=0, y=0, cx=0, cy=0):
         r = Region(scale, x, y, cx, cy)

@@ -58,6 +58,8 @@ class Host:
         L.scope_host_frames_processed.argtypes = [C.c_void_p]
         L.scope_host_frames_dropped.restype = C.c_uint64
         L.scope_host_frames_dropped.argtypes = [C.c_void_p]
+        for f in (L.scope_host_plane_uploads, L.scope_host_plane_reuses):
+            f.restype, f.argtypes = C.c_uint64, [C.c_void_p]
         L.fake_obs_reset()
         assert L.obs_module_load(), "module refused to load (no GPU / no HIP library)"
 
@@ -157,6 +159,8 @@ def run_host_checks(host, oracle, w=96, h=40):
         got_f, got_hi = host.his_table(his)
         assert np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32)) and got_hi == list(want_hi)
     assert winfo.get_width(wvs) == w and winfo.get_height(wvs) == 256
+    # three scopes read each staged surface, but its two planes crossed PCIe once each (scope_surface_begin/end)
+    assert host.L.scope_host_plane_uploads(roi) == 2 * len(frames) and host.L.scope_host_plane_reuses(roi) == len(frames)
     # video_render: the display shaders as GPU post-passes, the picture the plugin would have drawn
     rgb, yuv = frames[-1]
     vinfo.video_render(vss, None)

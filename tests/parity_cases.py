@@ -204,6 +204,42 @@ def check_device_path(ctx, oracle, to_dev, to_host, w, h, linesize, n=2, offset=
     return hy, hr
 
 
+def check_surface_fanout(ctx, oracle, w, h, linesize=None):
+    """scope_surface_begin/end: the dock's three scopes on one staged surface, planes uploaded once."""
+    import obs_color_monitor_amd as ocm
+
+    rgb, yuv = frames(oracle, w, h, 5, linesize=linesize)
+
+    def three(colorspace=2):
+        v, st = ctx.vectorscope(rgb=rgb, yuv=yuv, width=w, colorspace=colorspace)
+        assert st == 0
+        assert_same(v, oracle.vectorscope(yuv, w), "fan-out vectorscope")
+        wv, st = ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x07, colorspace=colorspace)
+        assert_same(wv, oracle.waveform(rgb, yuv, w, 0x07), "fan-out waveform RGB")
+        wl, st = ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x20, colorspace=colorspace)
+        assert_same(wl, oracle.waveform(rgb, yuv, w, 0x20), "fan-out waveform luma")
+        hc, st = ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=0x70, colorspace=colorspace)
+        assert_same(hc, oracle.histogram_counts(rgb, yuv, w, 0x70), "fan-out histogram YUV")
+
+    ctx.surface_begin()
+    three()
+    assert ctx.surface_end() == (2, 2)  # RGB and YUV uploaded once each, two uploads saved
+    ctx.surface_begin(fuse_k0=True)  # YUV never uploaded: converted from the cached RGB plane on the fly
+    three()
+    assert ctx.surface_end() == (1, 3)
+    three()  # outside begin/end nothing is cached
+    with pytest.raises(ocm.ScopeError):
+        ctx.surface_end()
+    ctx.surface_begin()
+    with pytest.raises(ocm.ScopeError):
+        ctx.surface_begin()
+    v, st = ctx.vectorscope(yuv=yuv, width=w)
+    other = oracle.fill_frame(w + 1, h, 1, 3)
+    with pytest.raises(ocm.ScopeError):  # one geometry per surface
+        ctx.histogram_counts(rgb=other, yuv=None, width=w + 1, components=0x07)
+    assert ctx.surface_end() == (1, 0)
+
+
 REGIONS = ((1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (3, 0, 0, 0, 0), (1, 5, 3, 17, 9), (2, 1, 2, 7, 5), (4, 0, 1, 3, 2), (128, 0, 0, 0, 0))
 
 

@@ -147,6 +147,50 @@ def test_device_path_and_unaligned_rows(emul_ctx, oracle, w, h, ls, off):
     pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, w, h, ls, n=2, offset=off)
 
 
+def test_surface_fanout_uploads_each_plane_once(emul_ctx, oracle):
+    pc.check_surface_fanout(emul_ctx, oracle, 70, 20, 4 * 70 + 24)
+    pc.check_surface_fanout(emul_ctx, oracle, 64, 9)
+
+
+def test_context_is_safe_to_share_between_threads(emul_ctx, oracle):
+    """The plugin runs one pipeline thread per stand-alone source plus the render thread on ONE module context."""
+    import threading
+
+    w, h = 66, 30
+    rgb, yuv = pc.frames(oracle, w, h, 1)
+    want_v, want_w = oracle.vectorscope(yuv, w), oracle.waveform(rgb, yuv, w, 0x07)
+    want_h = oracle.histogram_counts(rgb, yuv, w, 0x07)
+    errors = []
+
+    def worker(kind):
+        try:
+            for i in range(25):
+                if kind == 0:
+                    got, _ = emul_ctx.vectorscope(yuv=yuv, width=w)
+                    assert np.array_equal(got, want_v)
+                elif kind == 1:
+                    got, _ = emul_ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x07)
+                    assert np.array_equal(got, want_w)
+                elif kind == 2:
+                    got, _ = emul_ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=0x07)
+                    assert np.array_equal(got, want_h)
+                else:  # a dock fan-out holding the context across several calls
+                    emul_ctx.surface_begin()
+                    a, _ = emul_ctx.vectorscope(rgb=rgb, yuv=yuv, width=w)
+                    b, _ = emul_ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x07)
+                    assert emul_ctx.surface_end() == (2, 0)
+                    assert np.array_equal(a, want_v) and np.array_equal(b, want_w)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 2, 3, 0, 3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_frame_pipeline(emul_ctx, oracle):
     pc.check_pipeline(emul_ctx, oracle, 70, 20, n_frames=5, depth=2, linesize=4 * 70 + 24)
 

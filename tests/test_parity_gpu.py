@@ -321,6 +321,46 @@ def test_properties_full_size(hip_ctx, oracle):
     assert list(rows) == [255 - 204] and (wv[255 - 204, :, 1] == 255).all() and not wv[..., (0, 2, 3)].any()
 
 
+def test_surface_fanout_uploads_each_plane_once(hip_ctx, oracle):
+    """The dock case: three scopes on one staged surface, each plane crossing PCIe once."""
+    pc.check_surface_fanout(hip_ctx, oracle, 1920, 1080)
+    pc.check_surface_fanout(hip_ctx, oracle, 1279, 301, 1279 * 4 + 20)
+
+
+def test_context_is_safe_to_share_between_threads(hip_ctx, oracle):
+    import threading
+
+    w, h = 640, 360
+    rgb, yuv = pc.frames(oracle, w, h, 1)
+    want_v, want_w = oracle.vectorscope(yuv, w), oracle.waveform(rgb, yuv, w, 0x07)
+    errors = []
+
+    def worker(kind):
+        try:
+            for _ in range(20):
+                if kind == 0:
+                    got, _ = hip_ctx.vectorscope(yuv=yuv, width=w)
+                    assert np.array_equal(got, want_v)
+                elif kind == 1:
+                    got, _ = hip_ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x07)
+                    assert np.array_equal(got, want_w)
+                else:
+                    hip_ctx.surface_begin()
+                    a, _ = hip_ctx.vectorscope(rgb=rgb, yuv=yuv, width=w)
+                    b, _ = hip_ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x07)
+                    assert hip_ctx.surface_end() == (2, 0)
+                    assert np.array_equal(a, want_v) and np.array_equal(b, want_w)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 2, 0, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_frame_pipeline_streams(hip_ctx, oracle):
     """BASELINE config 5 in miniature and at full size: frames in flight over upload/compute/download streams."""
     pc.check_pipeline(hip_ctx, oracle, 640, 360, n_frames=9, depth=3)

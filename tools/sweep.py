@@ -233,6 +233,28 @@ def main():
             emit(dict(tag="host_call", scope=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1),
                       gpix=round(W * H / (ms * 1e-3) / 1e9, 2), note="pageable host plane in, table out, synchronous"))
 
+        # the dock: three scopes on ONE staged surface (RGB + YUV planes), per frame
+        def dock():
+            ctx.vectorscope(rgb=host_rgb, yuv=host_yuv, width=W)
+            ctx.waveform(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07)
+            ctx.histogram(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07)
+
+        for name, begin in (("three calls, three uploads", None), ("scope_surface_begin/end: two uploads", False),
+                            ("scope_surface_begin(FUSE_K0): one upload", True)):
+            def run():
+                if begin is not None:
+                    ctx.surface_begin(fuse_k0=begin)
+                dock()
+                if begin is not None:
+                    ctx.surface_end()
+            for _ in range(3):
+                run()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                run()
+            ms = (time.perf_counter() - t0) / 20 * 1e3
+            emit(dict(tag="host_dock", how=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1)))
+
     # ---- H: bytes in flight: loads per lane per batch (two batches in flight) for K1 and K3 -------------------
     if "H" in sec:
         cnt_h = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
