@@ -164,7 +164,7 @@ def test_context_is_safe_to_share_between_threads(emul_ctx, oracle):
 
     def worker(kind):
         try:
-            for i in range(25):
+            for i in range(6):
                 if kind == 0:
                     got, _ = emul_ctx.vectorscope(yuv=yuv, width=w)
                     assert np.array_equal(got, want_v)
@@ -183,7 +183,7 @@ def test_context_is_safe_to_share_between_threads(emul_ctx, oracle):
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
 
-    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 2, 3, 0, 3)]
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 2, 3, 3)]
     for t in threads:
         t.start()
     for t in threads:
