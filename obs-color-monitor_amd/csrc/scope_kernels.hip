@@ -4,7 +4,8 @@
  *
  * Design (DESIGN.md has the full story):
  *   * HBM-bound byte/integer work, no MFMA.  Every pixel is read from HBM exactly once with
- *     coalesced loads (16 B/lane for K0/K1/K3, 4 B/lane = 256 B/wave row segments for K2).
+ *     coalesced streaming loads (16 B/lane for K0/K1/K3, 8 B/lane = two 256-byte row segments per wave for K2),
+ *     about 32-128 KiB of them in flight per CU (fewer is faster: DESIGN.md section 5).
  *   * One 1024-thread workgroup per CU owns a private table in LDS (128 KiB u16-packed
  *     256x256 for K1; 96 KiB lane-replicated 3x256 for K3; 32 KiB per channel column-strip
  *     table for K2) and accumulates with LDS atomics; bank placement is chosen so that the
@@ -12,7 +13,10 @@
  *     for clustered chroma.
  *   * A table leaves the CU once, as a coalesced 16 B/lane store of clamped u8 (K1/K2) or
  *     u32 (K3) partials; partial tables of one frame are combined by a tiny second kernel
- *     (saturating add is exact: min(min(a,255)+min(b,255),255) == min(a+b,255)).
+ *     (saturating add is exact: min(min(a,255)+min(b,255),255) == min(a+b,255)) or, for the histogram's small
+ *     tables, by the last workgroup of the frame.
+ *   * K0 inside the scopes runs in 24-bit fixed point with an exhaustively derived guard band and an fp32 redo
+ *     near a step: bit-exact with the fp32 definition, a third of its instructions.
  *
  * Reference semantics (relative to /root/reference): data/common.effect:23-43,
  * src/vectorscope.c:217-238, src/waveform.c:220-257, src/histogram.c:357-395.
@@ -699,12 +703,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
 /* ------------------------------------------------------------------------------------------
  * K2 waveform
  *
- * A workgroup owns a strip of 64 columns (one wave wide) over a band of rows; lane l owns
- * column strip*64 + l.  Each wave loads whole 256-byte row segments (4 B/lane) and wave w of the
- * workgroup takes rows w, w+16, ...  LDS table per enabled channel: 8192 words, word
- * value*32 + (lane&31), half lane>>5 -- the 32 lanes of an LDS lane group always hit 32
- * different banks and never the same address, so the atomics are conflict-free for any image.
- * A column can receive at most `rows in band` (< 65536) increments, so 16 bits never overflow.
+ * A unit is a strip of 64 columns over a band of rows of one frame.  LDS table per enabled channel: 8192 words =
+ * 16-bit counters [256 values][64 columns]; a column can receive at most `rows in band` (< 65536, the C-ABI cuts
+ * taller frames into bands) increments, so 16 bits never overflow.  One persistent workgroup per CU walks units
+ * g, g + G, ... with one continuous load stream (details at the kernel).
  * ---------------------------------------------------------------------------------------- */
 
 #define WVS_CH_WORDS 8192u
