@@ -12,9 +12,11 @@
  * vss_draw_vectorscope / wvs_draw_waveform / his_draw_histogram).  Here the frame is reduced on
  * the GPU and only the small result tables come back.
  *
- * Threading: a scope_ctx may be used from any thread, one call at a time per context (the
- * reference's pipeline thread is exactly that, src/common.c:375-403).  Every entry point selects
- * the context's device itself; no current-device state is assumed.
+ * Threading: a scope_ctx may be shared by any number of threads: every entry point takes the
+ * context's internal lock, so calls are serialised per context (the reference runs one
+ * "color-monitor" thread per stand-alone source, src/common.c:375-403, plus the render thread).
+ * Asynchronous device-pointer calls (SCOPE_ASYNC) are ordered on the context's stream.  Every
+ * entry point selects the context's device itself; no current-device state is assumed.
  *
  * Errors: every int-returning function returns SCOPE_OK (0) or a negative SCOPE_E* code and
  * leaves the output buffers untouched on failure (the reference's callbacks are void and keep
@@ -99,9 +101,15 @@ int scope_ctx_set_stream(scope_ctx *ctx, void *hip_stream);
 void *scope_ctx_get_stream(scope_ctx *ctx);
 int scope_ctx_sync(scope_ctx *ctx);
 int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
-/* Tunables for A/B measurements: "vss.merge" 0|2|3, "vss.unroll" 1|2|4, "vss.fused_unroll" 1|2|4, "vss.hash" 0|1, "vss.groups" 0..3,
- * "his.unroll" 1|2|4, "wvs.wide" 0|1, "wvs.persist" 0|1, "wvs.per_cu" 0|1|2, "vss.block" / "his.block" 0|64..1024, "fold" 0|1, "nt" 0|1, "slices" (0 = automatic partition of a frame over
- * workgroups).  The defaults are the measured best (profiles/). */
+/* Tunables for A/B measurements (the defaults are the measured best, profiles/):
+ *   "vss.merge" 0|2|3        plain adds | absorb mode always | absorb mode by wave vote
+ *   "vss.unroll" 1|2|4, "vss.fused_unroll" 1|2|4, "his.unroll" 1|2|4   16-byte loads per lane per batch
+ *   "vss.hash" 0|1, "vss.groups" 0..3   bin -> LDS word placement; log2 of lane groups per wave
+ *   "vss.block" / "his.block" 0|64..1024   threads per workgroup (0 = 1024)
+ *   "wvs.wide" 0|1, "wvs.persist" 0|1, "wvs.per_cu" 0|1|2   waveform load shape / persistent walk / workgroups per CU
+ *   "fold" 0|1   histogram partials summed by the last workgroup of a frame
+ *   "nt" 0|1     streaming (non-temporal) loads
+ *   "slices"     workgroups per frame (0 = automatic) */
 int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value);
 const char *scope_strerror(int status);
 const char *scope_last_error(scope_ctx *ctx);
