@@ -42,7 +42,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed run of the same step before the warm-up so the GPU clocks (DVFS) leave idle")
-    ap.add_argument("--frames", type=int, default=32, help="distinct HBM-resident frames per step")
+    ap.add_argument("--frames", type=int, default=0, help="distinct HBM-resident frames per step (default 32 at 4k, 8 at 8k)")
+    ap.add_argument("--size", default="4k", choices=["4k", "8k"],
+                    help="frame size: 3840x2160 (the metric's configuration) or 7680x4320 (BASELINE config 4's frame)")
     ap.add_argument("--workload", default="vectorscope", choices=["vectorscope", "vectorscope_rgb", "waveform", "histogram"])
     ap.add_argument("--components", type=lambda s: int(s, 0), default=0x07)
     ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "ramp", "natural", "screen"])
@@ -84,7 +86,8 @@ def main():
     info = ctx.device_info()
 
     # ---- synthetic input, resident in HBM ------------------------------------------------------
-    n, w, h = args.frames, W4K, H4K
+    w, h = (W4K, H4K) if args.size == "4k" else (2 * W4K, 2 * H4K)
+    n = args.frames or (32 if args.size == "4k" else 8)
     from obs_color_monitor_amd.synth import make_frames
 
     rgb, yuv = make_frames(torch, ctx, n, w, h, args.dist, 0x9E3779B9 + rank)
@@ -225,12 +228,12 @@ def main():
                 "vectorscope_rgb": "vectorscope with fused K0 over RGB planes",
                 "waveform": f"waveform per-column 256-bin (K2), components {args.components:#04x}",
                 "histogram": f"histogram 3x256 u32 (K3), components {args.components:#04x}",
-            }[wl] + f", 3840x2160 BGRA8, {n} distinct HBM-resident frames per step, {args.dist} RGB through K0",
+            }[wl] + f", {w}x{h} BGRA8, {n} distinct HBM-resident frames per step, {args.dist} RGB through K0",
             "frames_per_step": n,
             "width": w,
             "height": h,
             "input_distribution": args.dist,
-            "partition": "one frame batch per GPU" if world == 1 else f"{world} row tiles of 3840x2160 + RCCL sum of tables",
+            "partition": "one frame batch per GPU" if world == 1 else f"{world} row tiles of {w}x{h} + RCCL sum of tables",
             "device": info["name"],
             "compute_units": info["compute_units"],
             "options": args.option,
