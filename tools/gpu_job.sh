@@ -37,8 +37,8 @@ for s in $stages; do
            done; rc=$?
            python tools/pmc_summary.py $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE > $out/pmc_traffic.txt 2>&1; cat $out/pmc_traffic.txt
            python tools/pmc_traffic_json.py $out > $out/pmc_traffic.json 2>> $out/pmc_traffic.txt; cat $out/pmc_traffic.json ;;
-    stream) (timeout 600 python tools/stream_bench.py > $out/stream_max.json 2> $out/stream.err; timeout 600 python tools/stream_bench.py --target-fps 240 --frames 720 > $out/stream_240.json 2>> $out/stream.err); rc=$?; cat $out/stream_max.json $out/stream_240.json; tail -3 $out/stream.err ;;
-    trace) (python tools/lds_trace_gen.py /tmp/lds_traces.bin 2> $out/lds_trace_model.txt && timeout 300 ./tools/lds_trace_bench /tmp/lds_traces.bin > $out/lds_trace.txt 2>&1); rc=$?; paste -d'|' $out/lds_trace_model.txt $out/lds_trace.txt | cut -c1-200 > $out/lds_trace_both.txt ;;
+    stream) (timeout 600 python tests/tools/stream_bench.py > $out/stream_max.json 2> $out/stream.err; timeout 600 python tests/tools/stream_bench.py --target-fps 240 --frames 720 > $out/stream_240.json 2>> $out/stream.err); rc=$?; cat $out/stream_max.json $out/stream_240.json; tail -3 $out/stream.err ;;
+    trace) (python tests/tools/lds_trace_gen.py /tmp/lds_traces.bin 2> $out/lds_trace_model.txt && timeout 300 ./tools/lds_trace_bench /tmp/lds_traces.bin > $out/lds_trace.txt 2>&1); rc=$?; paste -d'|' $out/lds_trace_model.txt $out/lds_trace.txt | cut -c1-200 > $out/lds_trace_both.txt ;;
     *) echo "unknown stage $s"; rc=99 ;;
   esac
   echo "== stage $s rc=$rc $(( $(date +%s) - t0 ))s" | tee -a $out/job.log
