@@ -201,10 +201,14 @@ int scope_histogram_counts_batch(scope_ctx *ctx, const struct scope_batch *b, ui
  * The reference leaves the final FLOAT->UNORM8 rounding to the GPU OBS runs on; here it is pinned
  * to floor(clamp01(x)*255+0.5), like K0. */
 
-/* data/vectorscope.effect:27-33 + src/vectorscope.c:414-439 (zoom 1).  color_type: 0 white, 1 UV
+/* data/vectorscope.effect:27-33 + src/vectorscope.c:414-439.  color_type: 0 white, 1 UV
  * colouring (BT.601 constants when colorspace == 1).  rgba = 256*256*4 bytes. */
 int scope_display_vectorscope(scope_ctx *ctx, const uint8_t *table, int intensity, int color_type, int colorspace,
 			      uint32_t flags, uint8_t *rgba);
+/* The same under the scope's zoom (mouse wheel, src/vectorscope.c:476-482): for zoom > 1.01 the picture is the
+ * sprite scaled about its centre 127.5 (:395-408), point-sampled (data/vectorscope.effect:8-12). */
+int scope_display_vectorscope_zoom(scope_ctx *ctx, const uint8_t *table, int intensity, int color_type, int colorspace,
+				   float zoom, uint32_t flags, uint8_t *rgba);
 /* data/waveform.effect:30-83 + src/waveform.c:334-360.  table = uint8[256][width][4];
  * rgba = out_w*out_h*4 bytes with the sizes scope_display_size(width, 256, ...) returns. */
 int scope_display_waveform(scope_ctx *ctx, const uint8_t *table, uint32_t width, uint32_t components, int display,

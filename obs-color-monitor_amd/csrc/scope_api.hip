@@ -1110,16 +1110,24 @@ void scope_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, i
 		*out_h = display == 1 ? base_h * n : base_h;
 }
 
-int scope_display_vectorscope(scope_ctx *ctx, const uint8_t *table, int intensity, int color_type, int colorspace,
-			      uint32_t flags, uint8_t *rgba)
+int scope_display_vectorscope_zoom(scope_ctx *ctx, const uint8_t *table, int intensity, int color_type, int colorspace,
+				   float zoom, uint32_t flags, uint8_t *rgba)
 {
 	if (!ctx)
 		return SCOPE_EINVAL;
 	if (intensity < 1)
 		intensity = 1; /* src/vectorscope.c:129-131 */
+	if (!(zoom >= 1.0f))
+		zoom = 1.0f; /* :480-481 */
 	return display_run(ctx, table, SCOPE_VSS_BINS, rgba, SCOPE_VSS_BINS * 4, flags, [&](const uint8_t *t, uint8_t *o) {
-		return scope_launch_display_vss(t, o, intensity, color_type, colorspace, ctx->stream);
+		return scope_launch_display_vss(t, o, intensity, color_type, colorspace, zoom, ctx->stream);
 	});
+}
+
+int scope_display_vectorscope(scope_ctx *ctx, const uint8_t *table, int intensity, int color_type, int colorspace,
+			      uint32_t flags, uint8_t *rgba)
+{
+	return scope_display_vectorscope_zoom(ctx, table, intensity, color_type, colorspace, 1.0f, flags, rgba);
 }
 
 int scope_display_waveform(scope_ctx *ctx, const uint8_t *table, uint32_t width, uint32_t components, int display,

@@ -69,13 +69,20 @@ __device__ __forceinline__ DispPick disp_select(float uvx, float uvy, u32 n, int
 
 __global__ __launch_bounds__(256) void scope_display_vss_kernel(const uint8_t *table, u32 *out, float intensity,
 							       float c0, float c1, float c2, float ca, float u0, float u1,
-							       float u2, float v0, float v1, float v2)
+							       float u2, float v0, float v1, float v2, float zoom)
 {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x; /* 65536 pixels */
 	const u32 px = i & 255u, py = i >> 8;
-	const float uvx = __fadd_rn((float)px, 0.5f) / 256.0f, uvy = __fadd_rn((float)py, 0.5f) / 256.0f;
+	float uvx = __fadd_rn((float)px, 0.5f) / 256.0f, uvy = __fadd_rn((float)py, 0.5f) / 256.0f;
+	u32 texel = i;
+	if (zoom > 1.01f) { /* src/vectorscope.c:395-408: the sprite scaled about 127.5; point filter */
+		const float ofst = __fmul_rn(127.5f, __fsub_rn(1.0f, zoom));
+		uvx = __fsub_rn(__fadd_rn((float)px, 0.5f), ofst) / zoom / 256.0f;
+		uvy = __fsub_rn(__fadd_rn((float)py, 0.5f), ofst) / zoom / 256.0f;
+		texel = disp_texel(uvy, 256) * 256u + disp_texel(uvx, 256);
+	}
 	const float s = __fsub_rn(__fmul_rn(uvx, 2.0f), 1.0f), t = __fsub_rn(1.0f, __fmul_rn(uvy, 2.0f));
-	float r = __fmul_rn((float)table[i] / 255.0f, intensity);
+	float r = __fmul_rn((float)table[texel] / 255.0f, intensity);
 	if (r > 1.0f)
 		r = 1.0f;
 	const float col[3] = {c0, c1, c2}, cu[3] = {u0, u1, u2}, cv[3] = {v0, v1, v2};
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void scope_display_his_kernel(const float *tex
 }
 
 hipError_t scope_launch_display_vss(const uint8_t *table, uint8_t *out, int intensity, int color_type, int colorspace,
-				    hipStream_t st)
+				    float zoom, hipStream_t st)
 {
 	/* src/vectorscope.c:418-439 */
 	float c[4] = {1.0f, 1.0f, 1.0f, 1.0f}, cu[3] = {0, 0, 0}, cv[3] = {0, 0, 0};
@@ -162,7 +169,7 @@ hipError_t scope_launch_display_vss(const uint8_t *table, uint8_t *out, int inte
 		}
 	}
 	hipLaunchKernelGGL(scope_display_vss_kernel, dim3(256), dim3(256), 0, st, table, (u32 *)out, (float)intensity, c[0],
-			   c[1], c[2], c[3], cu[0], cu[1], cu[2], cv[0], cv[1], cv[2]);
+			   c[1], c[2], c[3], cu[0], cu[1], cu[2], cv[0], cv[1], cv[2], zoom);
 	return hipGetLastError();
 }
 

@@ -114,7 +114,7 @@ hipError_t scope_launch_unpack16_clamp(const uint32_t *in, uint8_t *out, uint64_
 /* D1-D3: the display pixel shaders (data/vectorscope.effect, waveform.effect, histogram.effect) as
  * output-sized post-passes; out = RGBA8 bytes R,G,B,A.  display: 0 overlay, 1 stack, 2 parade. */
 hipError_t scope_launch_display_vss(const uint8_t *table, uint8_t *out, int intensity, int color_type, int colorspace,
-				    hipStream_t st);
+				    float zoom, hipStream_t st);
 hipError_t scope_launch_display_wvs(const uint8_t *table, uint8_t *out, uint32_t width, uint32_t n_components,
 				    int display, int intensity, uint32_t out_w, uint32_t out_h, hipStream_t st);
 hipError_t scope_launch_display_his(const float *tex, uint8_t *out, float hm0, float hm1, float hm2,

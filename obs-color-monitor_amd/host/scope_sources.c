@@ -8,6 +8,7 @@
  */
 #include "scope_sources.h"
 
+#include <math.h>
 #include <string.h>
 
 /* -- shared -------------------------------------------------------------------------------------- */
@@ -63,6 +64,7 @@ static void *vss_create(obs_data_t *settings, obs_source_t *source)
 	src->cm.flags = CM_FLAG_CONVERT_YUV; /* src/vectorscope.c:79 */
 	cm_create(&src->cm, settings, source);
 	cm_request(&src->cm, vss_surface_cb, src);
+	src->zoom = 1.0f; /* src/vectorscope.c:80 */
 	vss_update(src, settings);
 	return src;
 }
@@ -84,7 +86,17 @@ static void vss_get_defaults(obs_data_t *settings)
 	obs_data_set_default_int(settings, "color_type", 1); /* color_type_uv, :166 */
 }
 
-/* src/vectorscope.c:382-471 minus graticule and zoom: upload + PSDrawBare become one GPU pass */
+void vss_mouse_wheel(void *data, int x_delta, int y_delta)
+{
+	UNUSED_PARAMETER(x_delta);
+	struct vss_source *src = data;
+	src->zoom *= expf((float)y_delta * 5e-4f); /* src/vectorscope.c:479 */
+	if (src->zoom < 1.0f)
+		src->zoom = 1.0f;
+}
+
+/* src/vectorscope.c:382-471 minus the graticule draw (geometry: scope_graticule.h): upload, zoom transform and
+ * PSDrawBare become one GPU pass */
 static void vss_render(void *data, gs_effect_t *effect)
 {
 	UNUSED_PARAMETER(effect);
@@ -96,8 +108,8 @@ static void vss_render(void *data, gs_effect_t *effect)
 	if (!rgba)
 		return;
 	log_failure("scope_display_vectorscope",
-		    scope_display_vectorscope(cm_gpu(), src->tex_buf[r_tex_buf], src->intensity, src->color_type,
-					      src->tex_cs[r_tex_buf], 0, rgba));
+		    scope_display_vectorscope_zoom(cm_gpu(), src->tex_buf[r_tex_buf], src->intensity, src->color_type,
+						   src->tex_cs[r_tex_buf], src->zoom, 0, rgba));
 }
 
 static uint32_t vss_get_width(void *data)

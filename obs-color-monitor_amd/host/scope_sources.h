@@ -34,8 +34,11 @@ struct vss_source {
 	volatile int w_tex_buf;
 	int intensity;  /* src/vectorscope.c:55,129-131 */
 	int color_type; /* 0 white, 1 UV (src/vectorscope.c:36-39) */
+	float zoom;     /* 1.0 on creation (src/vectorscope.c:80); the mouse wheel changes it (:476-482) */
 	struct scope_picture pic;
 };
+/* vss_mouse_wheel (src/vectorscope.c:473-483): zoom *= exp(y_delta * 5e-4), never below 1. */
+void vss_mouse_wheel(void *data, int x_delta, int y_delta);
 
 struct wvs_source {
 	struct cm_source cm;

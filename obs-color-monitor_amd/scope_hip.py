@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "scope_ctx_profile", "scope_ctx_kernel_ms",
     "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect", "scope_pipe_size",
     "scope_region_size", "scope_stage_region", "scope_surface_begin", "scope_surface_end",
-    "scope_display_vectorscope", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
+    "scope_display_vectorscope", "scope_display_vectorscope_zoom", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
 )
 
 
@@ -129,6 +129,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_ctx_profile": (i32, [vp, i32]),
         "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
         "scope_display_vectorscope": (i32, [vp, vp, i32, i32, i32, u32, vp]),
+        "scope_display_vectorscope_zoom": (i32, [vp, vp, i32, i32, i32, C.c_float, u32, vp]),
         "scope_display_waveform": (i32, [vp, vp, u32, u32, i32, i32, u32, vp]),
         "scope_display_histogram": (i32, [vp, vp, vp, u32, i32, u32, u32, vp]),
         "scope_display_size": (None, [u32, u32, u32, i32, C.POINTER(u32), C.POINTER(u32)]),
@@ -360,10 +361,11 @@ class ScopeContext:
         self.L.scope_display_size(base_w, base_h, components, display, C.byref(ow), C.byref(oh))
         return int(ow.value), int(oh.value)
 
-    def display_vectorscope(self, table, intensity=25, color_type=1, colorspace=2):
+    def display_vectorscope(self, table, intensity=25, color_type=1, colorspace=2, zoom=1.0):
         out = np.full((256, 256, 4), 0xEE, dtype=np.uint8)
         t = np.ascontiguousarray(table, dtype=np.uint8)
-        self._check(self.L.scope_display_vectorscope(self.h, _hptr(t), intensity, color_type, colorspace, 0, _hptr(out)))
+        self._check(self.L.scope_display_vectorscope_zoom(self.h, _hptr(t), intensity, color_type, colorspace, zoom, 0,
+                                                         _hptr(out)))
         return out
 
     def display_waveform(self, table, components, display, intensity=25):

@@ -509,7 +509,15 @@ static uint32_t disp_texel(float t, uint32_t size)
 
 void oracle_display_vectorscope(uint8_t *out, const uint8_t *table, int intensity, int color_type, int colorspace)
 {
-	/* src/vectorscope.c:418-439 */
+	oracle_display_vectorscope_zoom(out, table, intensity, color_type, colorspace, 1.0f);
+}
+
+void oracle_display_vectorscope_zoom(uint8_t *out, const uint8_t *table, int intensity, int color_type, int colorspace,
+				     float zoom)
+{
+	/* src/vectorscope.c:418-439; the zoom transform of :395-408 applied to the 256x256 sprite */
+	const int zoomed = zoom > 1.01f;
+	const float ofst = 127.5f * (1.0f - zoom);
 	float color[4] = {1.0f, 1.0f, 1.0f, 1.0f}, cu[3] = {0, 0, 0}, cv[3] = {0, 0, 0};
 	if (color_type == 1) {
 		color[0] = color[1] = color[2] = 0.5f;
@@ -523,9 +531,16 @@ void oracle_display_vectorscope(uint8_t *out, const uint8_t *table, int intensit
 	}
 	for (uint32_t py = 0; py < 256; py++) {
 		for (uint32_t px = 0; px < 256; px++) {
-			const float uvx = ((float)px + 0.5f) / 256.0f, uvy = ((float)py + 0.5f) / 256.0f;
+			float uvx = ((float)px + 0.5f) / 256.0f, uvy = ((float)py + 0.5f) / 256.0f;
+			uint32_t tx = px, ty = py;
+			if (zoomed) { /* the pixel centre taken back through x' = zoom * x + ofst; point filter */
+				uvx = (((float)px + 0.5f) - ofst) / zoom / 256.0f;
+				uvy = (((float)py + 0.5f) - ofst) / zoom / 256.0f;
+				tx = disp_texel(uvx, 256);
+				ty = disp_texel(uvy, 256);
+			}
 			const float s = uvx * 2.0f - 1.0f, t = 1.0f - uvy * 2.0f;
-			float r = ((float)table[py * 256 + px] / 255.0f) * (float)intensity;
+			float r = ((float)table[ty * 256 + tx] / 255.0f) * (float)intensity;
 			if (r > 1.0f)
 				r = 1.0f;
 			uint8_t *o = out + ((size_t)py * 256 + px) * 4;

@@ -73,6 +73,11 @@ void oracle_histogram_level(uint8_t *tex_buf, uint32_t *hi_max, uint32_t width, 
 /* data/vectorscope.effect:27-33 with the uniforms of src/vectorscope.c:414-439.
  * color_type 0 = white, 1 = UV colouring (601 constants when colorspace == 1).  out = 256*256*4 bytes. */
 void oracle_display_vectorscope(uint8_t *out, const uint8_t *table, int intensity, int color_type, int colorspace);
+/* The same under the scope's zoom (src/vectorscope.c:395-408: the sprite is drawn scaled by `zoom` about the centre
+ * 127.5 when zoom > 1.01; mouse wheel, :476-482).  Point sampling (data/vectorscope.effect:8-12); the interpolated
+ * texture coordinate is pinned to ((p + 0.5) - ofst) / zoom / 256 in fp32. */
+void oracle_display_vectorscope_zoom(uint8_t *out, const uint8_t *table, int intensity, int color_type, int colorspace,
+				     float zoom);
 
 /* data/waveform.effect:30-83 with the technique choice of src/waveform.c:334-360.
  * table = uint8[256][width][4].  Output size via oracle_display_size(). */

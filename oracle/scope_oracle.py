@@ -61,6 +61,7 @@ class COracle:
         L.oracle_histogram.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Surface), C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.oracle_histogram_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.oracle_display_vectorscope.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oracle_display_vectorscope_zoom.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
         L.oracle_display_waveform.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         L.oracle_display_histogram.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
         L.oracle_display_size.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -168,10 +169,10 @@ class COracle:
         self.lib.oracle_display_size(base_w, base_h, components, display, C.byref(ow), C.byref(oh))
         return int(ow.value), int(oh.value)
 
-    def display_vectorscope(self, table, intensity=25, color_type=1, colorspace=2):
+    def display_vectorscope(self, table, intensity=25, color_type=1, colorspace=2, zoom=1.0):
         out = np.empty((256, 256, 4), dtype=np.uint8)
         t = np.ascontiguousarray(table, dtype=np.uint8)
-        self.lib.oracle_display_vectorscope(_ptr(out), _ptr(t), intensity, color_type, colorspace)
+        self.lib.oracle_display_vectorscope_zoom(_ptr(out), _ptr(t), intensity, color_type, colorspace, zoom)
         return out
 
     def display_waveform(self, table, components, display, intensity=25):

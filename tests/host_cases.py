@@ -165,6 +165,15 @@ def run_host_checks(host, oracle, w=96, h=40):
     rgb, yuv = frames[-1]
     vinfo.video_render(vss, None)
     assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2))
+    # the mouse wheel zooms the vectorscope about its centre (vss_mouse_wheel, vectorscope.c:473-483)
+    host.L.vss_mouse_wheel.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    host.L.vss_mouse_wheel(vss, 0, 1400)
+    zoom = float(np.float32(1.0) * np.exp(np.float32(1400 * 5e-4)).astype(np.float32))
+    vinfo.video_render(vss, None)
+    assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2, zoom))
+    host.L.vss_mouse_wheel(vss, 0, -100000)  # never below 1
+    vinfo.video_render(vss, None)
+    assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2))
     winfo.video_render(wvs, None)
     assert np.array_equal(host.picture(wvs, 1), oracle.display_waveform(oracle.waveform(rgb, yuv, w, 0x07), 0x07, 0, 51))
     hinfo.video_render(his, None)

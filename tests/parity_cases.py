@@ -310,6 +310,10 @@ def check_display(ctx, oracle, w=70, h=40):
     for color_type, cs, intensity in ((1, 2, 25), (1, 1, 3), (0, 2, 255), (1, 2, 0)):
         want = oracle.display_vectorscope(vss, max(intensity, 1), color_type, cs)
         assert_same(ctx.display_vectorscope(vss, intensity, color_type, cs), want, f"D1 ct{color_type} cs{cs} i{intensity}")
+    for zoom in (1.0, 1.005, 1.02, 1.5, 2.0, 3.7, 40.0):  # mouse-wheel zoom about the centre; <= 1.01 is the identity
+        want = oracle.display_vectorscope(vss, 25, 1, 2, zoom)
+        assert_same(ctx.display_vectorscope(vss, 25, 1, 2, zoom), want, f"D1 zoom {zoom}")
+    assert_same(oracle.display_vectorscope(vss, 25, 1, 2, 1.005), oracle.display_vectorscope(vss, 25, 1, 2), "zoom <= 1.01")
     for comp in (0x07, 0x70, 0x50, 0x20, 0x04):
         wv = oracle.waveform(rgb, yuv, w, comp)
         flt, hi = oracle.histogram(rgb, yuv, w, comp)
