@@ -55,6 +55,13 @@ def main():
     ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C
+    # stdio when a process group exists), so everything else in this process goes to stderr: file descriptor 1 is
+    # pointed at stderr for the run and the JSON line is written to the saved, real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -117,6 +124,11 @@ def main():
 
     def step(i):
         buf = i & 1
+        if wl in ("vectorscope", "vectorscope_rgb") and reducer is not None:
+            # tables go straight into the reducer's wire buffer in its packed format: no packing pass
+            ctx.vectorscope_batch_dev(batch, reducer.wire_buffer(), sync=False, packed16=True)
+            reducer.submit_packed()
+            return
         if wl in ("vectorscope", "vectorscope_rgb"):
             ctx.vectorscope_batch_dev(batch, tables[buf], sync=False)
         elif wl == "waveform":
@@ -320,7 +332,7 @@ def main():
         del plane
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

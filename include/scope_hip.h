@@ -48,6 +48,9 @@ extern "C" {
 #define SCOPE_OUT_DEVICE 0x2u /* result pointers are device pointers; default: host */
 #define SCOPE_ASYNC 0x4u      /* enqueue only; only valid with IN_DEVICE|OUT_DEVICE; scope_ctx_sync() later */
 #define SCOPE_FUSE_K0 0x8u    /* yuv_data is NULL: derive Y'CbCr from rgb_data inside the kernel (K0 fused) */
+#define SCOPE_OUT_PACKED16 0x10u /* scope_vectorscope_batch with SCOPE_OUT_DEVICE: out = uint32[n][32768], two bins per
+			       * word (lo | hi << 16) -- the wire format of the multi-GPU table sum, saving the
+			       * scope_table_pack_u8_u16x2 pass */
 
 /* ---- component masks, identical to the reference ------------------------------------------- */
 #define SCOPE_COMP_RGB 0x07u /* src/waveform.c:26, src/histogram.c:27 */

@@ -308,8 +308,13 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 		st = check_geometry(ctx, linesize, width, height);
 	if (st)
 		return st;
+	/* SCOPE_OUT_PACKED16: tables leave as uint32[32768], two bins per word -- what the multi-GPU sum puts on the wire */
+	const bool packed = (flags & SCOPE_OUT_PACKED16) != 0;
+	if (packed && !(flags & SCOPE_OUT_DEVICE))
+		return fail(ctx, SCOPE_EINVAL, "SCOPE_OUT_PACKED16 needs SCOPE_OUT_DEVICE", hipSuccess);
+	const size_t table = packed ? (size_t)SCOPE_VSS_BINS * 2 : (size_t)SCOPE_VSS_BINS;
 	uint8_t *dev_out = NULL;
-	st = result_begin(ctx, out, (size_t)n * SCOPE_VSS_BINS, flags, &dev_out);
+	st = result_begin(ctx, out, (size_t)n * table, flags, &dev_out);
 	if (st)
 		return st;
 	for (uint32_t f0 = 0; f0 < n; f0 += SCOPE_MAX_FRAMES) {
@@ -318,26 +323,27 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 		st = stage_planes(ctx, planes + f0, nf, linesize, width, height, flags, &fs);
 		if (st)
 			return st;
-		uint8_t *dst = dev_out + (size_t)f0 * SCOPE_VSS_BINS;
+		uint8_t *dst = dev_out + (size_t)f0 * table;
 		uint32_t slices = pick_slices(ctx, nf, 1);
 		const uint32_t min_slices = min_slices_for_span(fs.linesize, height);
 		if (min_slices == 0)
 			return fail(ctx, SCOPE_EINVAL, "pitch * height too large", hipSuccess);
 		if (slices < min_slices)
 			slices = min_slices;
-		if (slices == 1) {
+		if (slices == 1 && !packed) {
 			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, ctx->tn, ctx->stream));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * SCOPE_VSS_BINS);
 			if (st)
 				return st;
 			TIMED_LAUNCH(ctx, scope_launch_vss(fs, slices, fuse, colorspace, ctx->partial, ctx->tn, ctx->stream));
-			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, slices, SCOPE_VSS_BINS, ctx->stream));
+			/* one partial per frame and a packed result: the "reduction" of one table is just the repacking */
+			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, slices, SCOPE_VSS_BINS, packed, ctx->stream));
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* stage_in is reused by the next chunk */
 	}
-	return result_end(ctx, out, (size_t)n * SCOPE_VSS_BINS, flags, dev_out);
+	return result_end(ctx, out, (size_t)n * table, flags, dev_out);
 }
 
 int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
@@ -383,7 +389,7 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 			if (st)
 				return st;
 			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, bands, chmask, fuse, colorspace, ctx->partial, ctx->num_cu, ctx->tn, ctx->stream));
-			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, bands, table, ctx->stream));
+			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, bands, table, 0, ctx->stream));
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -871,7 +877,7 @@ int scope_vectorscope_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_
 		if (!b->planes[i])
 			return SCOPE_ENODATA;
 	if (b->width == 0 || b->height == 0)
-		return zero_result(ctx, out, (size_t)b->n_frames * SCOPE_VSS_BINS, flags);
+		return zero_result(ctx, out, (size_t)b->n_frames * SCOPE_VSS_BINS * ((flags & SCOPE_OUT_PACKED16) ? 2u : 1u), flags);
 	return run_vectorscope(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, b->planes_are_rgb != 0,
 			       b->colorspace, flags, out);
 }

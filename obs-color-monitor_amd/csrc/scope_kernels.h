@@ -95,11 +95,11 @@ hipError_t scope_launch_stage(const uint8_t *src, uint64_t row_pitch, uint32_t c
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
 			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st);
 
-/* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256). */
+/* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
+ * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,
-				   hipStream_t st);
+				   int packed16, hipStream_t st);
 
-/* out[f][i] = sum_s part[f][s][i], i < len. */
 hipError_t scope_launch_sum_reduce(const uint32_t *part, uint32_t *out, uint32_t n_frames, uint32_t slices,
 				   uint32_t len, hipStream_t st);
 

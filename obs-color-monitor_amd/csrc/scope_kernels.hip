@@ -1030,14 +1030,29 @@ __global__ __launch_bounds__(256) void scope_k0_kernel(const uint8_t *src, u32 s
 
 /* out[f][i] = min(sum_s part[f][s][i], 255); 16 bytes per lane; slices <= 256 so the
  * packed 16-bit lanes (max 256*255 = 65280) cannot overflow. */
-__global__ __launch_bounds__(256) void scope_sat_reduce_kernel(const uint8_t *part, uint8_t *out, u32 slices, u64 len16)
+__global__ __launch_bounds__(256) void scope_sat_reduce_kernel(const uint8_t *part, uint8_t *out, u32 slices, u64 len16,
+							      u32 packed16)
 {
 	const u32 frame = blockIdx.y;
 	const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= len16)
 		return;
 	const uint4 *p = (const uint4 *)part + (u64)frame * slices * len16 + g;
-	((uint4 *)out)[(u64)frame * len16 + g] = scope_sat_sum16(p, len16, slices);
+	const uint4 r = scope_sat_sum16(p, len16, slices);
+	if (!packed16) {
+		((uint4 *)out)[(u64)frame * len16 + g] = r;
+		return;
+	}
+	/* the wire format of the multi-GPU sum: two bins per 32-bit word, lo | hi << 16 (scope_table_pack_u8_u16x2) */
+	const u32 w[4] = {r.x, r.y, r.z, r.w};
+	u32 o[8];
+	for (int j = 0; j < 4; j++) {
+		o[2 * j] = (w[j] & 0xffu) | ((w[j] & 0xff00u) << 8);
+		o[2 * j + 1] = ((w[j] >> 16) & 0xffu) | ((w[j] >> 24) << 16);
+	}
+	uint4 *q = (uint4 *)out + ((u64)frame * len16 + g) * 2;
+	q[0] = make_uint4(o[0], o[1], o[2], o[3]);
+	q[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 __global__ __launch_bounds__(256) void scope_sum_reduce_kernel(const u32 *part, u32 *out, u32 slices, u32 len)
@@ -1357,11 +1372,12 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 }
 
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,
-				   hipStream_t st)
+				   int packed16, hipStream_t st)
 {
 	const u64 len16 = len / 16;
 	const u32 blocks = (u32)((len16 + 255) / 256);
-	hipLaunchKernelGGL(scope_sat_reduce_kernel, dim3(blocks, n_frames), dim3(256), 0, st, part, out, slices, len16);
+	hipLaunchKernelGGL(scope_sat_reduce_kernel, dim3(blocks, n_frames), dim3(256), 0, st, part, out, slices, len16,
+			   packed16 ? 1u : 0u);
 	return hipGetLastError();
 }
 

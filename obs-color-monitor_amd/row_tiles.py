@@ -67,6 +67,22 @@ class TableAllReduce:
         self.slot ^= 1
         return done
 
+    def wire_buffer(self):
+        """sat_u8 only: the int32 buffer (two bins per word) the next submit_packed() will reduce.  Let the scope
+        kernels write it directly (vectorscope_batch_dev(..., packed16=True)) and the packing pass disappears."""
+        assert self.kind == "sat_u8"
+        return self.wire[self.slot]
+
+    def submit_packed(self):
+        """Queue the reduction of wire_buffer(), which the caller has just filled on the current stream."""
+        import torch.distributed as dist
+
+        s = self.slot
+        done = self._finish(s ^ 1)
+        self.pending[s] = dist.all_reduce(self.wire[s], group=self.group, async_op=True)
+        self.slot ^= 1
+        return done
+
     def _finish(self, s):
         if self.pending[s] is None:
             return None

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libscope_hip.so")
 
 OK, EINVAL, ENOMEM, ENODEV, EIO, ENODATA, EAGAIN = 0, -22, -12, -19, -5, -61, -11
-IN_DEVICE, OUT_DEVICE, ASYNC, FUSE_K0 = 0x1, 0x2, 0x4, 0x8
+IN_DEVICE, OUT_DEVICE, ASYNC, FUSE_K0, OUT_PACKED16 = 0x1, 0x2, 0x4, 0x8, 0x10
 COMP_RGB, COMP_Y, COMP_UV, COMP_YUV = 0x07, 0x20, 0x50, 0x70
 
 # every symbol include/scope_hip.h declares (tests check the library exports all of them)
@@ -333,8 +333,10 @@ class ScopeContext:
             ptrs = [int(t.data_ptr()) for t in frames_dev]
         return self._batch(ptrs, linesize, width, height, planes_are_rgb, colorspace)
 
-    def vectorscope_batch_dev(self, batch, out_dev, sync=True):
-        self._check(self.L.scope_vectorscope_batch(self.h, C.byref(batch), IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC),
+    def vectorscope_batch_dev(self, batch, out_dev, sync=True, packed16=False):
+        """packed16: out_dev is int32[n][32768], two bins per word (the wire format of TableAllReduce)."""
+        self._check(self.L.scope_vectorscope_batch(self.h, C.byref(batch),
+                                                   IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC) | (OUT_PACKED16 if packed16 else 0),
                                                    _dptr(out_dev)))
 
     def waveform_batch_dev(self, batch, components, out_dev, sync=True):

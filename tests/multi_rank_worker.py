@@ -47,6 +47,25 @@ def main():
             results32.append(done.clone())
     results.append(red.drain().clone())
     results32.append(red32.drain().clone())
+    # the same sum with the tables written straight into the reducer's wire buffer (what bench.py does on the GPUs)
+    redp = TableAllReduce(ctx, 65536, "cpu", "sat_u8")
+    packed_results = []
+    for step, dist_kind in enumerate((3, 2, 1)):
+        rgb = o.fill_frame(w, h, dist_kind, 5 + step)
+        yuv = o.rgb_to_yuv(rgb, w, 2)
+        r0, r1 = tile_rows(h, rank, world)
+        tile = torch.from_numpy(np.ascontiguousarray(yuv[r0:r1])).unsqueeze(0)
+        if step == 1:
+            ctx.set_option("slices", 1)  # a single partial per frame: the "reduction" is only the repacking
+        batch = ctx.make_device_batch(tile, tile.shape[2], w, r1 - r0, planes_are_rgb=False)
+        ctx.vectorscope_batch_dev(batch, redp.wire_buffer(), packed16=True)
+        ctx.set_option("slices", 0)
+        done = redp.submit_packed()
+        if done is not None:
+            packed_results.append(done.clone())
+    packed_results.append(redp.drain().clone())
+    for got, want in zip(packed_results, wants):
+        assert np.array_equal(got.numpy().reshape(256, 256), want), "packed-wire row-tiled vectorscope != whole frame"
     assert len(results) == 3 and len(results32) == 3
     for got, want in zip(results, wants):
         assert np.array_equal(got.numpy().reshape(256, 256), want), "row-tiled vectorscope != whole frame"

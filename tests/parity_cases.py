@@ -186,6 +186,15 @@ def check_device_path(ctx, oracle, to_dev, to_host, w, h, linesize, n=2, offset=
     for i in range(n):
         assert_same(got[i], oracle.vectorscope(yuvs[i], w), f"device vectorscope fused frame {i}")
 
+    # the multi-GPU wire format straight from the kernels: two bins per 32-bit word, lo | hi << 16
+    pk_h, pk_a = to_dev(np.full(n * 65536 * 2, 0xEE, np.uint8))
+    for batch, what in ((by, "packed"), (br, "packed fused")):
+        ctx.vectorscope_batch_dev(batch, pk_a, packed16=True)
+        got = to_host(pk_h).view(np.uint32).reshape(n, 32768)
+        for i in range(n):
+            t = oracle.vectorscope(yuvs[i], w).reshape(-1).astype(np.uint32)
+            assert_same(got[i], t[0::2] | (t[1::2] << 16), f"device vectorscope {what} frame {i}")
+
     out_h, out_a = to_dev(np.full(n * 256 * w * 4, 0xEE, np.uint8))
     ctx.waveform_batch_dev(br, 0x07, out_a)
     got = to_host(out_h).reshape(n, 256, w, 4)
