@@ -216,7 +216,7 @@ def test_stage_region_rejects_bad_arguments(emul_ctx, oracle):
 
 
 def test_display_post_passes(emul_ctx, oracle):
-    pc.check_display(emul_ctx, oracle, 35, 20)
+    pc.check_display(emul_ctx, oracle, 35, 20, quick=True)
 
 
 @pytest.mark.parametrize("fold", [0, 1])
