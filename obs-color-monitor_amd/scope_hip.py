@@ -161,7 +161,9 @@ def _dptr(t):
 
 
 class ScopeContext:
-    """One scope_ctx.  ``lib_path`` lets the CPU-emulation test build be driven by the same code."""
+    """One scope_ctx of libscope_hip.so (the default, and the only library the product ships: without it, or without a
+    HIP device, construction raises -- there is no CPU fallback).  ``lib_path`` exists for tests/ only: they point the same
+    binding at tests/emul/libscope_emul.so, the kernel sources compiled against a CPU stand-in of the HIP runtime."""
 
     def __init__(self, device: int = 0, lib_path: str | None = None):
         self.L = load_library(lib_path)
