@@ -115,8 +115,7 @@ def main():
         table_bytes = 4096
     tables = [torch.empty((n, table_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)]
     reducer = None
-    if use_dist:
-        assert wl != "waveform", "multi-GPU waveform shards by column strip without a reduction; bench covers K1/K3"
+    if use_dist and wl != "waveform":  # the waveform shards by column strip: every rank's slab is final, no collective
         from obs_color_monitor_amd.row_tiles import TableAllReduce
 
         reducer = TableAllReduce(ctx, n * table_bytes, "cuda", "sum_u32" if wl == "histogram" else "sat_u8")
@@ -194,7 +193,7 @@ def main():
             mine = o.histogram_counts(host_planes[f], o.rgb_to_yuv(host_planes[f], w, 2), w, args.components)
             mine = mine.astype(np.int64)
         want = torch.from_numpy(mine.reshape(-1).astype(np.int64)).cuda()
-        if use_dist:
+        if reducer is not None:
             dist.all_reduce(want)
         if wl != "histogram":
             want = want.clamp(max=255)
@@ -202,6 +201,11 @@ def main():
         else:
             got = final[f].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
         parity = parity and bool(torch.equal(got, want))
+
+    if use_dist:  # the line rank 0 prints speaks for every rank
+        ok = torch.tensor([1 if parity else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        parity = bool(ok.item())
 
     # ---- the numbers ------------------------------------------------------------------------------
     pix_per_step = world * n * w * h
@@ -245,7 +249,9 @@ def main():
             "width": w,
             "height": h,
             "input_distribution": args.dist,
-            "partition": "one frame batch per GPU" if world == 1 else f"{world} row tiles of {w}x{h} + RCCL sum of tables",
+            "partition": "one frame batch per GPU" if world == 1 else
+                         (f"{world} column slabs of {w}x{h}, no collective" if wl == "waveform" else
+                          f"{world} row tiles of {w}x{h} + RCCL sum of tables"),
             "device": info["name"],
             "compute_units": info["compute_units"],
             "options": args.option,
