@@ -118,7 +118,8 @@ def main():
     if use_dist and wl != "waveform":  # the waveform shards by column strip: every rank's slab is final, no collective
         from obs_color_monitor_amd.row_tiles import TableAllReduce
 
-        reducer = TableAllReduce(ctx, n * table_bytes, "cuda", "sum_u32" if wl == "histogram" else "sat_u8")
+        # one collective per 8 steps: a collective per step costs more host time than a step takes on the GPU
+        reducer = TableAllReduce(ctx, n * table_bytes, "cuda", "sum_u32" if wl == "histogram" else "sat_u8", bucket=8)
     result_tables = [None]
 
     def step(i):

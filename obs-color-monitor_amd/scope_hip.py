@@ -166,6 +166,7 @@ class ScopeContext:
     binding at tests/emul/libscope_emul.so, the kernel sources compiled against a CPU stand-in of the HIP runtime."""
 
     def __init__(self, device: int = 0, lib_path: str | None = None):
+        self.device, self.lib_path = device, lib_path
         self.L = load_library(lib_path)
         h = C.c_void_p()
         st = self.L.scope_ctx_create(device, C.byref(h))

@@ -4,6 +4,8 @@ Small cases mirror tests/test_parity_emul.py; the rest are BASELINE.json's full 
 (1280x720 histogram, 3840x2160 vectorscope / waveform / histogram, 7680x4320 row-tiled vectorscope),
 an exhaustive K0 check over all 2^24 colours, and size-independent properties.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -401,3 +403,61 @@ def test_display_post_passes(hip_ctx, oracle):
     """tables -> scope pictures on the GPU, every display technique."""
     pc.check_display(hip_ctx, oracle, 70, 40)
     pc.check_display(hip_ctx, oracle, 1280, 72)
+
+
+def test_table_all_reduce_side_stream_buckets(hip_ctx, oracle):
+    """The reducer bench.py uses for N > 1, on a one-rank RCCL group: tables written straight into the wire buffer,
+    several steps per collective, collective + unpack on a side stream, a partly filled bucket flushed by drain()."""
+    import torch
+    import torch.distributed as dist
+
+    from obs_color_monitor_amd.row_tiles import TableAllReduce
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29591")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        w, h, n = 320, 180, 2
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            hip_ctx.set_stream(stream.cuda_stream)
+            red = TableAllReduce(hip_ctx, n * 65536, "cuda", "sat_u8", bucket=3)
+            red32 = TableAllReduce(hip_ctx, n * 4096, "cuda", "sum_u32", bucket=3)
+            wants, wants32, keep = [], [], []
+            cnt = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+            for step in range(7):
+                planes_y, planes_r = [], []
+                for f in range(n):
+                    rgb = oracle.fill_frame(w, h, 1 + (step + f) % 5, 300 + 10 * step + f)
+                    planes_r.append(rgb)
+                    planes_y.append(oracle.rgb_to_yuv(rgb, w, 2))
+                wants.append(np.stack([oracle.vectorscope(y, w) for y in planes_y]))
+                wants32.append(np.stack([oracle.histogram_counts(r, None, w, 0x07) for r in planes_r]))
+                ty = torch.from_numpy(np.stack(planes_y)).cuda()
+                tr = torch.from_numpy(np.stack(planes_r)).cuda()
+                keep += [ty, tr]
+                by = hip_ctx.make_device_batch(ty, 4 * w, w, h, planes_are_rgb=False)
+                br = hip_ctx.make_device_batch(tr, 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+                hip_ctx.vectorscope_batch_dev(by, red.wire_buffer(), sync=False, packed16=True)
+                red.submit_packed()
+                hip_ctx.histogram_counts_batch_dev(br, 0x07, cnt, sync=False)
+                red32.submit(cnt.view(torch.uint8))
+            last = red.drain()
+            last32 = red32.drain()
+            torch.cuda.current_stream().synchronize()
+            assert np.array_equal(last.cpu().numpy().reshape(n, 256, 256), wants[6])
+            assert np.array_equal(last32.cpu().numpy().view(np.uint32).reshape(n, 256, 4), wants32[6])
+            # the buckets still hold the other steps: 3,4,5 in the second bucket; 1,2 behind step 6 in the first
+            for step, (s, k) in {3: (1, 0), 4: (1, 1), 5: (1, 2), 1: (0, 1), 2: (0, 2)}.items():
+                got = red._final_slice(s, k).cpu().numpy().reshape(n, 256, 256)
+                assert np.array_equal(got, wants[step]), f"step {step}"
+                got32 = red32._final_slice(s, k).cpu().numpy().view(np.uint32).reshape(n, 256, 4)
+                assert np.array_equal(got32, wants32[step]), f"histogram step {step}"
+        hip_ctx.set_stream(None)
+    finally:
+        hip_ctx.set_stream(None)
+        if created:
+            dist.destroy_process_group()
