@@ -364,15 +364,16 @@ __device__ __forceinline__ u32 vss_rev5(u32 row)
 
 template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u32 n)
 {
-	const u32 t = ~key; /* bits 16..23 = row = 255 - v */
+	/* The LDS table is stored by v, not by the output row 255 - v (the flush reads it upside down), which saves the
+	 * complement here: bits 16..23 of the key are the table row as they are. */
 	u32 byte, shift;
 	if (HASH == 1) {
-		/* word row*128 + ((u & 127) ^ rev5(row)), half u >> 7 */
-		byte = ((t >> 7) & 0x1fe00u) ^ ((key & 127u) << 2) ^ ((__brev(t >> 16) >> 27) << 2);
+		/* word v*128 + ((u & 127) ^ rev5(v)), half u >> 7 */
+		byte = ((key >> 7) & 0x1fe00u) ^ ((key & 127u) << 2) ^ ((__brev(key >> 16) >> 27) << 2);
 		shift = (key >> 3) & 16u;
 	} else {
-		/* word row*128 + ((u >> 1) ^ ((row & 3) << 3)), half u & 1; the three terms use disjoint bits */
-		byte = ((t >> 7) & 0x1fe00u) ^ ((t >> 11) & 0x60u) ^ ((key << 1) & 0x1fcu);
+		/* word v*128 + ((u >> 1) ^ ((v & 3) << 3)), half u & 1; the three terms use disjoint bits */
+		byte = ((key >> 7) & 0x1fe00u) ^ ((key >> 11) & 0x60u) ^ ((key << 1) & 0x1fcu);
 		shift = (key & 1u) << 4;
 	}
 	atomicAdd((u32 *)((uint8_t *)tab + byte), n << shift);
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	/* flush: 16 consecutive bins of one row per lane per step, one coalesced 16-byte store */
 	uint4 *out = (uint4 *)(dst + (size_t)unit * SCOPE_VSS_BINS);
 	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x) {
-		const u32 row = g >> 4, u0 = (g & 15u) << 4, x5 = vss_rev5(row);
+		const u32 row = 255u - (g >> 4) /* table row v of output row g >> 4 */, u0 = (g & 15u) << 4, x5 = vss_rev5(row);
 		u32 o[4];
 #pragma unroll
 		for (u32 j = 0; j < 4; j++)
