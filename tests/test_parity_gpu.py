@@ -250,6 +250,7 @@ def test_config4_vectorscope_8k_row_tiles(hip_ctx, oracle):
     pc.assert_same(got, want, "8K vectorscope, one call")
 
     acc = torch.zeros(32768, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     for t in range(tiles):
         tile = yuv[t * h // tiles:(t + 1) * h // tiles]
         part, st = hip_ctx.vectorscope(yuv=tile, width=w)
@@ -260,6 +261,7 @@ def test_config4_vectorscope_8k_row_tiles(hip_ctx, oracle):
         hip_ctx.sync()
         acc += packed
     out = torch.empty(65536, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the sums ran on torch's stream, the context has its own
     hip_ctx.unpack16_clamp_dev(acc, out, 32768)
     hip_ctx.sync()
     pc.assert_same(out.cpu().numpy().reshape(256, 256), want, "8K vectorscope, 8 row tiles + packed sum + clamp")
@@ -393,6 +395,7 @@ def test_stage_region_device_planes(hip_ctx, oracle):
     for region in ((2, 0, 0, 0, 0), (5, 3, 2, 100, 60), (1, 11, 7, 640, 360)):
         want = oracle.stage_region(plane, w, *region)
         dst = torch.full((want.shape[0], want.shape[1] + 16), 0xA5, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the context runs on its own stream: the fill above must have landed first
         hip_ctx.stage_region_dev(src, w * 4, w, h, region, dst, dst.shape[1])
         got = dst.cpu().numpy()
         pc.assert_same(got[:, :want.shape[1]], want, f"device stage_region {region}")
