@@ -346,8 +346,9 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
  * K1 vectorscope
  *
  * LDS table: 32768 words, two u16 counters per word.  Bin (u, row) with row = 255 - v lives in
- *   HASH 1: word row*128 + ((u & 127) ^ rev5(row)), half u >> 7
- *   HASH 0: word row*128 + ((u >> 1) ^ ((row & 3) << 3)), half u & 1        (first version, kept for A/B)
+ *   HASH 1: word row*128 + ((u & 127) ^ rev5(row)), half u >> 7                  (kept for A/B)
+ *   HASH 0: word row*128 + (((u >> 1) + 8 row) & 127), half u & 1               (default)
+ * where row is the TABLE row = v (the flush turns the table upside down into output rows 255 - v).
  * rev5 = the low five bits of the row, bit-reversed.  With HASH 1 neighbouring u share neither a
  * word nor a bank, and 2^k consecutive rows are offset by multiples of 32/2^k banks, so a chroma
  * cluster of up to 32 (u, row) cells in any aligned w x h = 32 box lands on 32 different banks.
@@ -383,8 +384,11 @@ template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u
 		byte = ((key >> 7) & 0x1fe00u) ^ ((key & 127u) << 2) ^ ((__brev(key >> 16) >> 27) << 2);
 		shift = (key >> 3) & 16u;
 	} else {
-		/* word v*128 + ((u >> 1) ^ ((v & 3) << 3)), half u & 1; the three terms use disjoint bits */
-		byte = ((key >> 7) & 0x1fe00u) ^ ((key >> 11) & 0x60u) ^ ((key << 1) & 0x1fcu);
+		/* word v*128 + (((u >> 1) + 8 v) & 127), half u & 1: every table row is rotated by eight words against the
+		 * one before, so the rows of a chroma cluster start on different banks.  Five operations: bits above 8 of
+		 * the sum cannot reach the masked bits 2..8, so whatever else the register holds does not matter. */
+		const u32 v = (key >> 16) & 0xffu;
+		byte = (v << 9) | (((key << 1) + (v << 5)) & 0x1fcu);
 		shift = (key & 1u) << 4;
 	}
 	atomicAdd((u32 *)((uint8_t *)tab + byte), n << shift);
@@ -397,7 +401,7 @@ template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, 
 	if (HASH == 1) {
 		w = tab[(row << 7) + ((u & 127u) ^ x5)] >> ((u >> 3) & 16u);
 	} else {
-		w = tab[(row << 7) + ((u >> 1) ^ ((row & 3u) << 3))] >> ((u & 1u) << 4);
+		w = tab[(row << 7) + (((u >> 1) + (row << 3)) & 127u)] >> ((u & 1u) << 4);
 	}
 	return min(w & 0xffffu, 255u);
 }

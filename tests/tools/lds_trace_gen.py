@@ -39,7 +39,8 @@ def rev5(r):
 
 
 HASHES = {
-    "h0:(u>>1)^((row&3)<<3)": lambda u, r: (r << 7) + ((u >> 1) ^ ((r & 3) << 3)),
+    "h0:((u>>1)+8row)&127": lambda u, r: (r << 7) + (((u >> 1) + (r << 3)) & 127),
+    "hx:(u>>1)^((row&3)<<3)": lambda u, r: (r << 7) + ((u >> 1) ^ ((r & 3) << 3)),
     "h1:(u&127)^rev5(row)": lambda u, r: (r << 7) + ((u & 127) ^ rev5(r)),
     "h2:(u&127)+9*row": lambda u, r: (r << 7) + (((u & 127) + 9 * r) & 127),
     "h3:plain u>>1": lambda u, r: (r << 7) + (u >> 1),

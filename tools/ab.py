@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Same-process A/B of two builds of libscope_hip.so on the SAME HBM-resident frames.
+
+Between processes the streaming kernels land in one of two placement modes 3 % apart, which
+drowns the 1-2 % effects kernel tuning is about; here both libraries read the very same buffers, alternately.
+
+    python tools/ab.py /path/to/libA.so /path/to/libB.so [--workload vectorscope|vectorscope_rgb|histogram|waveform]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import torch  # noqa: E402
+
+import obs_color_monitor_amd as ocm  # noqa: E402
+from sweep import W, H, timed  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs=2)
+    ap.add_argument("--workload", default="vectorscope")
+    ap.add_argument("--dists", default="uniform,natural,screen")
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    n = 32
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctxs = []
+    for p in args.libs:
+        c = ocm.ScopeContext(0, os.path.abspath(p))
+        c.set_stream(stream.cuda_stream)
+        ctxs.append(c)
+    from obs_color_monitor_amd.synth import make_frames
+
+    wl = args.workload
+    table = {"vectorscope": 65536, "vectorscope_rgb": 65536, "histogram": 4096, "waveform": 256 * W * 4}[wl]
+    out = torch.empty((n, table), dtype=torch.uint8, device="cuda")
+    for d in args.dists.split(","):
+        rgb, yuv = make_frames(torch, ctxs[0], n, W, H, d, 7)
+        res = [[], []]
+        for r in range(args.rounds):
+            for i, c in enumerate(ctxs):
+                if wl == "vectorscope":
+                    b = c.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
+                    fn = lambda: c.vectorscope_batch_dev(b, out, sync=False)  # noqa: E731
+                elif wl == "vectorscope_rgb":
+                    b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+                    fn = lambda: c.vectorscope_batch_dev(b, out, sync=False)  # noqa: E731
+                elif wl == "histogram":
+                    b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+                    fn = lambda: c.histogram_counts_batch_dev(b, 0x07, out, sync=False)  # noqa: E731
+                else:
+                    b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+                    fn = lambda: c.waveform_batch_dev(b, 0x07, out, sync=False)  # noqa: E731
+                if r == 0:
+                    t_end = time.perf_counter() + 0.5
+                    while time.perf_counter() < t_end:
+                        fn()
+                        c.sync()
+                k, wall, _ = timed(c, fn, reps=30)
+                res[i].append(n * (4 * W * H + (table if wl != "histogram" else 4096)) / (k * 1e-3) / 1e9)
+        for i, p in enumerate(args.libs):
+            r = sorted(res[i])
+            print(f"{wl:16s} {d:12s} {os.path.basename(p):24s} median {r[len(r) // 2]:7.1f} GB/s   all " +
+                  " ".join(f"{x:.0f}" for x in res[i]), flush=True)
+        del rgb, yuv
+
+
+if __name__ == "__main__":
+    main()
