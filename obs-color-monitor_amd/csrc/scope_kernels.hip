@@ -419,13 +419,18 @@ struct VssLane {
 
 template <int HASH> __device__ __forceinline__ void vss_absorb4(u32 *tab, VssLane &st, u32 k0, u32 k1, u32 k2, u32 k3)
 {
-	const bool any = (k0 == st.colour) | (k1 == st.colour) | (k2 == st.colour) | (k3 == st.colour);
-	if (!any && st.count)
-		vss_add<HASH>(tab, st.colour, st.count); /* the colour changed: hand in the old one (rare) */
-	const u32 colour = any ? st.colour : k0;        /* ... and start counting the new one */
-	const bool e0 = k0 == colour, e1 = k1 == colour, e2 = k2 == colour, e3 = k3 == colour;
-	st.colour = colour;
-	st.count = (any ? st.count : 0u) + (u32)e0 + (u32)e1 + (u32)e2 + (u32)e3;
+	bool e0 = k0 == st.colour, e1 = k1 == st.colour, e2 = k2 == st.colour, e3 = k3 == st.colour;
+	if (!(e0 | e1 | e2 | e3)) { /* none of the four is the lane's colour: it changed (rare; divergent) */
+		if (st.count)
+			vss_add<HASH>(tab, st.colour, st.count); /* hand in the old one ... */
+		st.colour = k0;                                /* ... and start counting the new one */
+		st.count = 0;
+		e0 = true;
+		e1 = k1 == k0;
+		e2 = k2 == k0;
+		e3 = k3 == k0;
+	}
+	st.count += (u32)e0 + (u32)e1 + (u32)e2 + (u32)e3;
 	if (!(e0 & e1 & e2 & e3)) { /* one exec test skips all four when the whole wave was absorbed */
 		if (!e0)
 			vss_add<HASH>(tab, k0, 1);
