@@ -116,21 +116,22 @@ __device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool nee
 }
 
 /* N texels of one lane, in place.  The votes are wave-wide: a cell is redone in fp32 by the whole wave when any
- * lane holds a texel near a step (identical results for the other lanes, that is what the exhaustive test says). */
+ * lane holds a texel near a step (identical results for the other lanes, that is what the exhaustive test says).
+ * Cells that are black throughout are exempt (black is an exact tie both paths agree on); a black texel next to
+ * other colours just sends its cell to the fp32 path, which is as right as the fast one. */
 template <int N> __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, bool need_uv, bool need_y)
 {
-	u32 t[N], slack[N], worst = 0xffffffffu;
+	u32 t[N], worst = 0xffffffffu, any = 0;
 #pragma unroll
 	for (int j = 0; j < N; j++) {
-		t[j] = scope_k0_fixed(p[j], k, need_uv, need_y, slack[j]);
-		worst = min(worst, slack[j]);
+		u32 slack;
+		t[j] = scope_k0_fixed(p[j], k, need_uv, need_y, slack);
+		worst = min(worst, slack);
+		any |= p[j];
 	}
-	if (__ballot(worst < 2u * SCOPE_K0_FX_GUARD) != 0) {
-		bool redo = false;
-#pragma unroll
-		for (int j = 0; j < N; j++)
-			redo |= slack[j] < 2u * SCOPE_K0_FX_GUARD && (p[j] & 0x00ffffffu) != 0;
-		if (__ballot(redo) != 0) {
+	const bool near_step = worst < 2u * SCOPE_K0_FX_GUARD;
+	if (__ballot(near_step) != 0) {
+		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
 #pragma unroll
 			for (int j = 0; j < N; j++)
 				p[j] = scope_k0_texel(p[j], k, need_uv, need_y);
