@@ -39,12 +39,12 @@ struct ScopeK0 {
 	float ug, vg;
 	float ub, vb;
 	float yr, yg, yb;
-	/* The same rows in fixed point (coefficient * 2^23, last entry = the constant term): the fast path of the
+	/* The same rows in fixed point (coefficient * 2^24, last entry = the constant term): the fast path of the
 	 * fused kernels, see scope_k0_fixed in scope_kernels.hip. */
 	int fu[4], fy[4], fv[4];
 };
-#define SCOPE_K0_FX_SHIFT 23
-#define SCOPE_K0_FX_GUARD 256 /* results closer than this (in 2^-23 of an output step) to a step are recomputed in fp32 */
+#define SCOPE_K0_FX_SHIFT 24  /* the output byte is byte 3 of the sum */
+#define SCOPE_K0_FX_GUARD 512 /* results closer than this (in 2^-24 of an output step) to a step are recomputed in fp32 */
 
 /* Tunables the host may flip for A/B runs (scope_ctx_set_option). */
 struct ScopeTuning {

@@ -82,35 +82,43 @@ __device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool nee
 /* ---- the fast path ------------------------------------------------------------------------------
  * The fp32 chain above costs ~33 VALU instructions per texel and makes every fused kernel VALU-bound.
  * The value it approximates is T = c_r R + c_g G + c_b B + 255 off + 0.5 with output floor(T) (no clamp is
- * ever active for 8-bit inputs), which three 24-bit integer multiply-adds give directly in 2^-23 fixed
- * point: E = C_r R + C_g G + C_b B + K, output E >> 23.  The two disagree only where T is within ~2.5e-5 of
- * an integer, i.e. where fp32 rounding decides: an exhaustive run over all 2^24 colours, both matrices and
- * all three rows finds every such colour within 211 units (2^-23) of a step.  So K carries a guard of 256
- * units, `slack` = min over the rows of (E & (2^23 - 1)), and a texel with slack < 512 is "near a step":
- * it is recomputed with the fp32 chain (a wave votes per cell; 6e-5 .. 1e-3 of all colours).  Black is an
- * exact tie (V = 128.0) on which both paths agree, and common (letterbox bars): it is exempt.
+ * ever active for 8-bit inputs), which three 24-bit integer multiply-adds give directly in 2^-24 fixed
+ * point: E = C_r R + C_g G + C_b B + K, the output is byte 3 of E (chroma |c| < 0.5 fits v_mul_i32_i24, luma
+ * 0 <= c < 1 fits v_mul_u32_u24; the sum is taken mod 2^32 and ends below 256 * 2^24).  The two disagree only where T is within ~2.5e-5 of an integer, i.e.
+ * where fp32 rounding decides: an exhaustive run over all 2^24 colours, both matrices and all three rows finds every
+ * such colour within 422 units (2^-24) of a step.  So K carries a guard of 512 units and a value whose fraction is
+ * below 1024 -- bytes 1..2 of E, read as a number, below 4 -- is "near a step": its cell is recomputed with the fp32
+ * chain (a wave votes per cell; 6e-5 .. 1e-3 of all colours).  Two rows' fractions travel as the halves of one
+ * register (v_perm_b32) and the running minimum over a cell is a v_pk_min_u16.  Black is an exact tie (V = 128.0) on
+ * which both paths agree, and common (letterbox bars): it is exempt.
  * tests/test_parity_gpu.py runs all 2^24 colours through this code against the oracle. */
 __device__ __forceinline__ int scope_mad24(int a, int b, int c)
 {
 	return __mul24(a, b) + c; /* v_mad_i32_i24 */
 }
 
-__device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool need_uv, bool need_y, u32 &slack)
+__device__ __forceinline__ u32 scope_umad24(u32 a, u32 b, u32 c)
+{
+	return __umul24(a, b) + c; /* v_mad_u32_u24: the luma coefficients are positive and may exceed 0.5 */
+}
+
+#define SCOPE_K0_NEAR 4u /* 2 * SCOPE_K0_FX_GUARD >> 8 */
+
+/* worst: running per-half minimum of the fractions' upper 16 bits. */
+__device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool need_uv, bool need_y, u32 &worst)
 {
 	const int b = (int)(px & 0xffu), g = (int)((px >> 8) & 0xffu), r = (int)((px >> 16) & 0xffu);
-	const u32 mask = (1u << SCOPE_K0_FX_SHIFT) - 1u;
 	u32 out = 0xff000000u;
-	slack = 0xffffffffu;
 	if (need_uv) {
 		const u32 eu = (u32)scope_mad24(k.fu[0], r, scope_mad24(k.fu[1], g, scope_mad24(k.fu[2], b, k.fu[3])));
 		const u32 ev = (u32)scope_mad24(k.fv[0], r, scope_mad24(k.fv[1], g, scope_mad24(k.fv[2], b, k.fv[3])));
-		slack = min(eu & mask, ev & mask);
-		out |= (eu >> SCOPE_K0_FX_SHIFT) | ((ev >> (SCOPE_K0_FX_SHIFT - 16)) & 0x00ff0000u);
+		worst = scope_pk_min_u16(worst, scope_perm(ev, eu, 0x06050201u));
+		out = scope_perm(ev, eu, 0x0d070c03u); /* U, 0, V, 255 */
 	}
 	if (need_y) {
-		const u32 ey = (u32)scope_mad24(k.fy[0], r, scope_mad24(k.fy[1], g, scope_mad24(k.fy[2], b, k.fy[3])));
-		slack = min(slack, ey & mask);
-		out |= (ey >> (SCOPE_K0_FX_SHIFT - 8)) & 0x0000ff00u;
+		const u32 ey = scope_umad24((u32)k.fy[0], (u32)r, scope_umad24((u32)k.fy[1], (u32)g, scope_umad24((u32)k.fy[2], (u32)b, (u32)k.fy[3])));
+		worst = scope_pk_min_u16(worst, scope_perm(ey, ey, 0x06050201u));
+		out = scope_perm(ey, out, 0x03020700u);
 	}
 	return out;
 }
@@ -124,12 +132,10 @@ template <int N> __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], cons
 	u32 t[N], worst = 0xffffffffu, any = 0;
 #pragma unroll
 	for (int j = 0; j < N; j++) {
-		u32 slack;
-		t[j] = scope_k0_fixed(p[j], k, need_uv, need_y, slack);
-		worst = min(worst, slack);
+		t[j] = scope_k0_fixed(p[j], k, need_uv, need_y, worst);
 		any |= p[j];
 	}
-	const bool near_step = worst < 2u * SCOPE_K0_FX_GUARD;
+	const bool near_step = min(worst & 0xffffu, worst >> 16) < SCOPE_K0_NEAR;
 	if (__ballot(near_step) != 0) {
 		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
 #pragma unroll
@@ -146,8 +152,8 @@ template <int N> __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], cons
 static void k0_fixed_row(const float c[3], double offset, int out[4])
 {
 	for (int i = 0; i < 3; i++)
-		out[i] = (int)lrint((double)c[i] * (double)(1 << SCOPE_K0_FX_SHIFT));
-	out[3] = (int)llrint((255.0 * offset + 0.5) * (double)(1 << SCOPE_K0_FX_SHIFT)) + SCOPE_K0_FX_GUARD;
+		out[i] = (int)lrint((double)c[i] * (double)(1 << SCOPE_K0_FX_SHIFT)); /* 24 bits: signed (U, V) or unsigned (Y) */
+	out[3] = (int)(uint32_t)(llrint((255.0 * offset + 0.5) * (double)(1 << SCOPE_K0_FX_SHIFT)) + SCOPE_K0_FX_GUARD);
 }
 
 ScopeK0 scope_k0_matrix(int colorspace)

@@ -65,6 +65,20 @@ __device__ __forceinline__ scope_u2 scope_load_row2_nt(const unsigned char *row,
 	return __builtin_nontemporal_load((const __attribute__((address_space(1))) scope_u2 *)(base + lane_off));
 }
 
+/* v_perm_b32: byte i of the result is byte sel[i] of the 8 bytes {hi (4..7), lo (0..3)}; 0x0c gives 0x00, 0x0d gives 0xff. */
+__device__ __forceinline__ unsigned scope_perm(unsigned hi, unsigned lo, unsigned sel)
+{
+	return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+/* v_pk_min_u16: the two 16-bit halves independently. */
+__device__ __forceinline__ unsigned scope_pk_min_u16(unsigned a, unsigned b)
+{
+	typedef unsigned short scope_us2 __attribute__((ext_vector_type(2)));
+	const scope_us2 r = __builtin_elementwise_min(__builtin_bit_cast(scope_us2, a), __builtin_bit_cast(scope_us2, b));
+	return __builtin_bit_cast(unsigned, r);
+}
+
 /* Sum over the 64 lanes of a wave; every lane must be active (uniform control flow). */
 __device__ __forceinline__ unsigned scope_wave_sum(unsigned x)
 {

@@ -169,6 +169,11 @@ static inline void __threadfence()
 {
 	__sync_synchronize();
 }
+static inline unsigned __umul24(unsigned a, unsigned b)
+{
+	return (a & 0xffffffu) * (b & 0xffffffu);
+}
+
 static inline int __mul24(int a, int b)
 {
 	/* v_mul_i32_i24: operands are the sign-extended low 24 bits, result the low 32 bits of the product */

@@ -46,6 +46,31 @@ static inline scope_u2 scope_load_row2_nt(const unsigned char *row, unsigned lan
 	return scope_u2{p[0], p[1]};
 }
 
+static inline unsigned scope_perm(unsigned hi, unsigned lo, unsigned sel)
+{
+	const unsigned long long src = ((unsigned long long)hi << 32) | lo;
+	unsigned out = 0;
+	for (int i = 0; i < 4; i++) {
+		const unsigned c = (sel >> (8 * i)) & 0xffu;
+		unsigned byte;
+		if (c <= 7)
+			byte = (unsigned)(src >> (8 * c)) & 0xffu;
+		else if (c <= 11)
+			byte = ((src >> (16 * (c - 8) + 15)) & 1u) ? 0xffu : 0u;
+		else
+			byte = c == 12 ? 0u : 0xffu;
+		out |= byte << (8 * i);
+	}
+	return out;
+}
+
+static inline unsigned scope_pk_min_u16(unsigned a, unsigned b)
+{
+	const unsigned lo = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu);
+	const unsigned hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+	return lo | (hi << 16);
+}
+
 static inline unsigned scope_wave_sum(unsigned x)
 {
 	return x;

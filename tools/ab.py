@@ -4,7 +4,8 @@
 Between processes the streaming kernels land in one of two placement modes 3 % apart, which
 drowns the 1-2 % effects kernel tuning is about; here both libraries read the very same buffers, alternately.
 
-    python tools/ab.py /path/to/libA.so /path/to/libB.so [--workload vectorscope|vectorscope_rgb|histogram|waveform]
+    python tools/ab.py /path/to/libA.so /path/to/libB.so [--workload vectorscope|vectorscope_rgb|histogram|histogram_yuv|waveform|waveform_yuv]
+(the *_rgb / *_yuv forms read RGB planes and convert in the kernel: the fused-K0 path)
 """
 import argparse
 import os
@@ -39,7 +40,9 @@ def main():
     from obs_color_monitor_amd.synth import make_frames
 
     wl = args.workload
-    table = {"vectorscope": 65536, "vectorscope_rgb": 65536, "histogram": 4096, "waveform": 256 * W * 4}[wl]
+    table = {"vectorscope": 65536, "vectorscope_rgb": 65536, "histogram": 4096, "histogram_yuv": 4096,
+             "waveform": 256 * W * 4, "waveform_yuv": 256 * W * 4}[wl]
+    comp = 0x70 if wl.endswith("_yuv") else 0x07
     out = torch.empty((n, table), dtype=torch.uint8, device="cuda")
     for d in args.dists.split(","):
         rgb, yuv = make_frames(torch, ctxs[0], n, W, H, d, 7)
@@ -52,19 +55,19 @@ def main():
                 elif wl == "vectorscope_rgb":
                     b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
                     fn = lambda: c.vectorscope_batch_dev(b, out, sync=False)  # noqa: E731
-                elif wl == "histogram":
+                elif wl.startswith("histogram"):
                     b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-                    fn = lambda: c.histogram_counts_batch_dev(b, 0x07, out, sync=False)  # noqa: E731
+                    fn = lambda: c.histogram_counts_batch_dev(b, comp, out, sync=False)  # noqa: E731
                 else:
                     b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-                    fn = lambda: c.waveform_batch_dev(b, 0x07, out, sync=False)  # noqa: E731
+                    fn = lambda: c.waveform_batch_dev(b, comp, out, sync=False)  # noqa: E731
                 if r == 0:
                     t_end = time.perf_counter() + 0.5
                     while time.perf_counter() < t_end:
                         fn()
                         c.sync()
                 k, wall, _ = timed(c, fn, reps=30)
-                res[i].append(n * (4 * W * H + (table if wl != "histogram" else 4096)) / (k * 1e-3) / 1e9)
+                res[i].append(n * (4 * W * H + table) / (k * 1e-3) / 1e9)
         for i, p in enumerate(args.libs):
             r = sorted(res[i])
             print(f"{wl:16s} {d:12s} {os.path.basename(p):24s} median {r[len(r) // 2]:7.1f} GB/s   all " +
