@@ -104,7 +104,15 @@ __device__ __forceinline__ u32 scope_umad24(u32 a, u32 b, u32 c)
 
 #define SCOPE_K0_NEAR 4u /* 2 * SCOPE_K0_FX_GUARD >> 8 */
 
-/* worst: running per-half minimum of the fractions' upper 16 bits. */
+/* The vectorscope's bin key of a Y'CbCr texel: U in byte 1, V in byte 2, bytes 0 and 3 zero (see vss_add). */
+__device__ __forceinline__ u32 vss_bin(u32 px)
+{
+	return scope_perm(0u, px, 0x0c02000cu);
+}
+
+/* worst: running per-half minimum of the fractions' upper 16 bits.  VSSKEY: the result is the vectorscope's bin key
+ * (0, U, V, 0) instead of the texel (U, Y, V, 255) -- the same single v_perm_b32 with another selector. */
+template <bool VSSKEY>
 __device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool need_uv, bool need_y, u32 &worst)
 {
 	const int b = (int)(px & 0xffu), g = (int)((px >> 8) & 0xffu), r = (int)((px >> 16) & 0xffu);
@@ -113,7 +121,7 @@ __device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool nee
 		const u32 eu = (u32)scope_mad24(k.fu[0], r, scope_mad24(k.fu[1], g, scope_mad24(k.fu[2], b, k.fu[3])));
 		const u32 ev = (u32)scope_mad24(k.fv[0], r, scope_mad24(k.fv[1], g, scope_mad24(k.fv[2], b, k.fv[3])));
 		worst = scope_pk_min_u16(worst, scope_perm(ev, eu, 0x06050201u));
-		out = scope_perm(ev, eu, 0x0d070c03u); /* U, 0, V, 255 */
+		out = scope_perm(ev, eu, VSSKEY ? 0x0c07030cu : 0x0d070c03u); /* 0, U, V, 0 or U, 0, V, 255 */
 	}
 	if (need_y) {
 		const u32 ey = scope_umad24((u32)k.fy[0], (u32)r, scope_umad24((u32)k.fy[1], (u32)g, scope_umad24((u32)k.fy[2], (u32)b, (u32)k.fy[3])));
@@ -127,20 +135,24 @@ __device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool nee
  * lane holds a texel near a step (identical results for the other lanes, that is what the exhaustive test says).
  * Cells that are black throughout are exempt (black is an exact tie both paths agree on); a black texel next to
  * other colours just sends its cell to the fp32 path, which is as right as the fast one. */
-template <int N> __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, bool need_uv, bool need_y)
+template <int N, bool VSSKEY = false>
+__device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, bool need_uv, bool need_y)
 {
 	u32 t[N], worst = 0xffffffffu, any = 0;
 #pragma unroll
 	for (int j = 0; j < N; j++) {
-		t[j] = scope_k0_fixed(p[j], k, need_uv, need_y, worst);
+		t[j] = scope_k0_fixed<VSSKEY>(p[j], k, need_uv, need_y, worst);
 		any |= p[j];
 	}
 	const bool near_step = min(worst & 0xffffu, worst >> 16) < SCOPE_K0_NEAR;
 	if (__ballot(near_step) != 0) {
 		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
 #pragma unroll
-			for (int j = 0; j < N; j++)
+			for (int j = 0; j < N; j++) {
 				p[j] = scope_k0_texel(p[j], k, need_uv, need_y);
+				if (VSSKEY)
+					p[j] = vss_bin(p[j]);
+			}
 			return;
 		}
 	}
@@ -352,13 +364,20 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 /* ------------------------------------------------------------------------------------------
  * K1 vectorscope
  *
- * LDS table: 32768 words, two u16 counters per word.  Bin (u, row) with row = 255 - v lives in
- *   HASH 1: word row*128 + ((u & 127) ^ rev5(row)), half u >> 7                  (kept for A/B)
- *   HASH 0: word row*128 + (((u >> 1) + 8 row) & 127), half u & 1               (default)
- * where row is the TABLE row = v (the flush turns the table upside down into output rows 255 - v).
- * rev5 = the low five bits of the row, bit-reversed.  With HASH 1 neighbouring u share neither a
- * word nor a bank, and 2^k consecutive rows are offset by multiples of 32/2^k banks, so a chroma
- * cluster of up to 32 (u, row) cells in any aligned w x h = 32 box lands on 32 different banks.
+ * LDS table: 32768 words, two u16 counters per word.  Bin (u, v) lives in table row v (the flush turns the
+ * table upside down into output rows 255 - v), half u & 1 of
+ *   HASH 0: word v*128 + ((u >> 1) ^ 8 (v & 15))     (default)
+ *   HASH 1: word v*128 + (u >> 1)                     (kept for A/B: two instructions fewer, but the rows of a
+ *                                                      chroma cluster then share their banks: -17 % on
+ *                                                      concentrated chroma, +1..5 % elsewhere)
+ * With HASH 0 sixteen consecutive rows start on sixteen different multiples of eight words, so a chroma cluster
+ * of 16 x 16 bins is spread over all banks.
+ *
+ * A pixel's bin travels as a KEY = u << 8 | v << 16 (vss_bin: one v_perm_b32 from the texel, or straight from the
+ * fixed-point sums when K0 is fused).  Equal keys <=> equal bins; the bin index u + 256*(255 - v) is never
+ * materialised, the LDS byte address comes straight from the key's bits: key >> 7 = v << 9 | u << 1 is already
+ * "row base + 4 * (u >> 1)" up to bit 1 (each VALU instruction occupies a SIMD for a quad-cycle here, so
+ * instructions are what counts).
  *
  * Counters are 16 bit: between two clamp passes a workgroup adds at most 65280 pixels, and
  * every counter is <= 255 after a pass, so no counter can exceed 65535.  The clamp is exact
@@ -368,48 +387,23 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 #define VSS_WORDS 32768u
 #define VSS_EPOCH_PIXELS 65280u
 
-/* A pixel's bin as a key: byte0 = U, byte2 = V (src/vectorscope.c:228-232).  Equal keys <=> equal bins;
- * the bin index u + 256*(255 - v) is never materialised: the LDS byte address comes straight from the
- * key's bits (each VALU instruction occupies a SIMD for a quad-cycle here, so instructions are what counts). */
-__device__ __forceinline__ u32 vss_bin(u32 px)
-{
-	return px & 0x00ff00ffu;
-}
-
-__device__ __forceinline__ u32 vss_rev5(u32 row)
-{
-	return __brev(row) >> 27;
-}
-
 template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u32 n)
 {
-	/* The LDS table is stored by v, not by the output row 255 - v (the flush reads it upside down), which saves the
-	 * complement here: bits 16..23 of the key are the table row as they are. */
-	u32 byte, shift;
-	if (HASH == 1) {
-		/* word v*128 + ((u & 127) ^ rev5(v)), half u >> 7 */
-		byte = ((key >> 7) & 0x1fe00u) ^ ((key & 127u) << 2) ^ ((__brev(key >> 16) >> 27) << 2);
-		shift = (key >> 3) & 16u;
-	} else {
-		/* word v*128 + (((u >> 1) + 8 v) & 127), half u & 1: every table row is rotated by eight words against the
-		 * one before, so the rows of a chroma cluster start on different banks.  Five operations: bits above 8 of
-		 * the sum cannot reach the masked bits 2..8, so whatever else the register holds does not matter. */
-		const u32 v = (key >> 16) & 0xffu;
-		byte = (v << 9) | (((key << 1) + (v << 5)) & 0x1fcu);
-		shift = (key & 1u) << 4;
-	}
-	atomicAdd((u32 *)((uint8_t *)tab + byte), n << shift);
+	const u32 t = key >> 7; /* v << 9 | u << 1 */
+	u32 byte;
+	if (HASH == 1)
+		byte = t & 0x1fffcu;
+	else
+		byte = scope_bitop3<0x78>(t, key >> 11, 0x1e0u) & 0x1fffcu; /* t ^ (v << 5 & 0x1e0); key >> 11 = v << 5 | u >> 3 */
+	/* half u & 1 = bit 8 of the key; bits 4..7 are zero, so the shift count is 0 or 16 */
+	atomicAdd((u32 *)((uint8_t *)tab + byte), n << ((key >> 4) & 31u));
 }
 
 /* one clamped bin out of the table */
-template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, u32 row, u32 u, u32 x5)
+template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, u32 row, u32 u)
 {
-	u32 w;
-	if (HASH == 1) {
-		w = tab[(row << 7) + ((u & 127u) ^ x5)] >> ((u >> 3) & 16u);
-	} else {
-		w = tab[(row << 7) + (((u >> 1) + (row << 3)) & 127u)] >> ((u & 1u) << 4);
-	}
+	const u32 col = HASH == 1 ? (u >> 1) : ((u >> 1) ^ ((row & 15u) << 3));
+	const u32 w = tab[(row << 7) + col] >> ((u & 1u) << 4);
 	return min(w & 0xffffu, 255u);
 }
 
@@ -420,7 +414,7 @@ template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, 
  * only sends the others to LDS; the pair is added when the colour changes, before every clamp pass and
  * at the end of the slice.  Whether a batch runs in absorb mode is one wave vote (vss_region). */
 struct VssLane {
-	u32 colour; /* key of the pending pixels; 0xffffffff = none (no key has bits in bytes 1 and 3) */
+	u32 colour; /* key of the pending pixels; 0xffffffff = none (no key has bits in bytes 0 and 3) */
 	u32 count;
 };
 
@@ -519,10 +513,10 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 					       for (int k = 0; k < U; k++) {
 						       u32 p[4] = {q[k][0], q[k][1], q[k][2], q[k][3]};
 						       if (FUSE)
-							       scope_k0_cell<4>(p, k0, true, false);
+							       scope_k0_cell<4, true>(p, k0, true, false); /* keys come out */
 #pragma unroll
 						       for (int j = 0; j < 4; j++)
-							       idx[k][j] = vss_bin(p[j]);
+							       idx[k][j] = FUSE ? p[j] : vss_bin(p[j]);
 					       }
 					       /* MERGE 3: a wave vote -- does at least a quarter of the wave hold nothing but
 						* single-colour cells in this batch (16 pixels per lane)?  Then it sits on flat content
@@ -569,9 +563,9 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 					       for (int k = 0; k < U; k++) {
 						       u32 p0[1] = {q[k]};
 						       if (FUSE)
-							       scope_k0_cell<1>(p0, k0, true, false);
+							       scope_k0_cell<1, true>(p0, k0, true, false);
 						       if (ok[k])
-							       vss_add<HASH>(tab, vss_bin(p0[0]), 1);
+							       vss_add<HASH>(tab, FUSE ? p0[0] : vss_bin(p0[0]), 1);
 					       }
 				       });
 	}
@@ -607,13 +601,12 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	/* flush: 16 consecutive bins of one row per lane per step, one coalesced 16-byte store */
 	uint4 *out = (uint4 *)(dst + (size_t)unit * SCOPE_VSS_BINS);
 	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x) {
-		const u32 row = 255u - (g >> 4) /* table row v of output row g >> 4 */, u0 = (g & 15u) << 4, x5 = vss_rev5(row);
+		const u32 row = 255u - (g >> 4) /* table row v of output row g >> 4 */, u0 = (g & 15u) << 4;
 		u32 o[4];
 #pragma unroll
 		for (u32 j = 0; j < 4; j++)
-			o[j] = vss_read_bin<HASH>(tab, row, u0 + 4 * j, x5) | (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 1, x5) << 8) |
-			       (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 2, x5) << 16) |
-			       (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 3, x5) << 24);
+			o[j] = vss_read_bin<HASH>(tab, row, u0 + 4 * j) | (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 1) << 8) |
+			       (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 2) << 16) | (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 3) << 24);
 		out[g] = make_uint4(o[0], o[1], o[2], o[3]);
 	}
 }

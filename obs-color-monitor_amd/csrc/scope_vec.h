@@ -79,6 +79,12 @@ __device__ __forceinline__ unsigned scope_pk_min_u16(unsigned a, unsigned b)
 	return __builtin_bit_cast(unsigned, r);
 }
 
+/* v_bitop3_b32: any bitwise function of three operands; bit (a << 2 | b << 1 | c) of TT is the result for the bits a, b, c. */
+template <unsigned TT> __device__ __forceinline__ unsigned scope_bitop3(unsigned a, unsigned b, unsigned c)
+{
+	return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+
 /* Sum over the 64 lanes of a wave; every lane must be active (uniform control flow). */
 __device__ __forceinline__ unsigned scope_wave_sum(unsigned x)
 {

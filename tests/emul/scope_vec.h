@@ -71,6 +71,16 @@ static inline unsigned scope_pk_min_u16(unsigned a, unsigned b)
 	return lo | (hi << 16);
 }
 
+template <unsigned TT> static inline unsigned scope_bitop3(unsigned a, unsigned b, unsigned c)
+{
+	unsigned out = 0;
+	for (int i = 0; i < 32; i++) {
+		const unsigned idx = (((a >> i) & 1u) << 2) | (((b >> i) & 1u) << 1) | ((c >> i) & 1u);
+		out |= ((TT >> idx) & 1u) << i;
+	}
+	return out;
+}
+
 static inline unsigned scope_wave_sum(unsigned x)
 {
 	return x;

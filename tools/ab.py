@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--workload", default="vectorscope")
     ap.add_argument("--dists", default="uniform,natural,screen")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--opt-a", action="append", default=[], help="key=value for the first library's context")
+    ap.add_argument("--opt-b", action="append", default=[], help="key=value for the second (the same .so twice compares options)")
     args = ap.parse_args()
     n = 32
     stream = torch.cuda.Stream()
@@ -36,6 +38,9 @@ def main():
     for p in args.libs:
         c = ocm.ScopeContext(0, os.path.abspath(p))
         c.set_stream(stream.cuda_stream)
+        for kv in (args.opt_a if not ctxs else args.opt_b):
+            k, v = kv.split("=")
+            c.set_option(k, int(v))
         ctxs.append(c)
     from obs_color_monitor_amd.synth import make_frames
 
@@ -70,7 +75,7 @@ def main():
                 res[i].append(n * (4 * W * H + table) / (k * 1e-3) / 1e9)
         for i, p in enumerate(args.libs):
             r = sorted(res[i])
-            print(f"{wl:16s} {d:12s} {os.path.basename(p):24s} median {r[len(r) // 2]:7.1f} GB/s   all " +
+            print(f"{wl:16s} {d:12s} {os.path.basename(p) + ' ' + ','.join(args.opt_a if i == 0 else args.opt_b):28s} median {r[len(r) // 2]:7.1f} GB/s   all " +
                   " ".join(f"{x:.0f}" for x in res[i]), flush=True)
         del rgb, yuv
 
