@@ -138,14 +138,16 @@ __device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool nee
 template <int N, bool VSSKEY = false>
 __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, bool need_uv, bool need_y)
 {
-	u32 t[N], worst = 0xffffffffu, any = 0;
+	u32 t[N], worst = 0xffffffffu;
 #pragma unroll
-	for (int j = 0; j < N; j++) {
+	for (int j = 0; j < N; j++)
 		t[j] = scope_k0_fixed<VSSKEY>(p[j], k, need_uv, need_y, worst);
-		any |= p[j];
-	}
 	const bool near_step = min(worst & 0xffffu, worst >> 16) < SCOPE_K0_NEAR;
-	if (__ballot(near_step) != 0) {
+	if (__ballot(near_step) != 0) { /* rare, except on black */
+		u32 any = 0;
+#pragma unroll
+		for (int j = 0; j < N; j++)
+			any |= p[j];
 		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
 #pragma unroll
 			for (int j = 0; j < N; j++) {
