@@ -623,10 +623,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 
 #define HIS_WORDS (3u * 256u * 32u)
 
-__device__ __forceinline__ void his_add(u32 *tab, u32 px, u32 chmask, u32 rep)
+template <bool FUSE> __device__ __forceinline__ void his_add(u32 *tab, u32 px, u32 chmask, u32 rep)
 {
-	if ((px >> 24) == 0)
-		return; /* src/histogram.c:386-387 */
+	if (!FUSE && (px >> 24) == 0)
+		return; /* src/histogram.c:386-387; the K0 pass writes alpha 255 whatever the source holds */
 	if (chmask & 1u)
 		atomicAdd(&tab[((0u * 256u + (px & 0xffu)) << 5) + rep], 1u);
 	if (chmask & 2u)
@@ -657,7 +657,7 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 #pragma unroll
 						       for (int j = 0; j < 4; j++)
 							       if (ok[k])
-								       his_add(tab, p[j], chmask, rep);
+								       his_add<FUSE>(tab, p[j], chmask, rep);
 					       }
 		};
 		if (linesize == ncols * 16u) /* uniform: rows without padding */
@@ -673,7 +673,7 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 						       if (FUSE)
 							       scope_k0_cell<1>(p0, k0, need_uv, need_y);
 						       if (ok[k])
-							       his_add(tab, p0[0], chmask, rep);
+							       his_add<FUSE>(tab, p0[0], chmask, rep);
 					       }
 				       });
 	}
@@ -876,9 +876,9 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 			if (FUSE)                                                                             \
 				scope_k0_cell<2>(pp_, k0, need_uv, need_y);                                   \
 			const u32 p0 = pp_[0], p1 = pp_[1];                                                   \
-			if (live0 && (p0 >> 24) != 0) /* src/waveform.c:247-248 */                            \
+			if (live0 && (FUSE || (p0 >> 24) != 0)) /* src/waveform.c:247-248; K0 writes alpha 255 */ \
 				wvs_count<CH>(tab, p0, wbyte, 1u);                                            \
-			if (live1 && (p1 >> 24) != 0)                                                         \
+			if (live1 && (FUSE || (p1 >> 24) != 0))                                               \
 				wvs_count<CH>(tab, p1, wbyte, 65536u);                                        \
 		}                                                                                             \
 	} while (0)
@@ -923,9 +923,9 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
 				p1 = scope_k0_texel(p1, k0, need_uv, need_y);
 			}
-			if (live0 && (p0 >> 24) != 0)
+			if (live0 && (FUSE || (p0 >> 24) != 0))
 				wvs_count<CH>(tab, p0, wbyte, 1u);
-			if (live1 && (p1 >> 24) != 0)
+			if (live1 && (FUSE || (p1 >> 24) != 0))
 				wvs_count<CH>(tab, p1, wbyte, 65536u);
 		}
 		__syncthreads();
