@@ -314,9 +314,9 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	const u32 d_off = dq * linesize + dr * cell_bytes;
 	const u32 wrap_off = linesize - ncols * cell_bytes; /* what a column wrap adds on top: the pitch padding */
 	/* CONTIG: the rows follow each other without padding (linesize == ncols * cell_bytes, the usual case), so a
-	 * cell's offset is its index times the cell size: no column bookkeeping, three operations per load.  Used where
-	 * it was measured to pay: the histogram (+1 %) and the fused-K0 vectorscope (+4 %), both short of VALU slots;
-	 * the plain vectorscope lost 3 % on uniform content with it and keeps the general form. */
+	 * cell's offset is its index times the cell size: no column bookkeeping, three operations per load instead of
+	 * eleven.  Same-process A/B: histogram +1 %, fused-K0 vectorscope +4 %, plain vectorscope +0.6 % on noise and
+	 * +3.7 % on screen content (once its per-pixel arithmetic had been trimmed; before that it lost 3 % there). */
 	const u32 end_off = (s1 - row0 * ncols) * cell_bytes;
 	vec_t va[U], vb[U];
 	bool oka[U], okb[U];
@@ -554,8 +554,8 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 							       }
 					       }
 		};
-		if (FUSE && linesize == ncols * 16u) /* uniform: RGB planes whose rows carry no padding */
-			scope_stream<4, U, NT, FUSE>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, bin_cells);
+		if (linesize == ncols * 16u) /* uniform: planes whose rows carry no padding */
+			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, bin_cells);
 		else
 			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, bin_cells);
 	} else {
