@@ -528,7 +528,7 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 						* and a vote per cell or even per batch costs more than it saves). */
 					       bool absorb = MERGE == 1 || MERGE == 2;
 					       if (MERGE == 3) {
-						       if ((vote_clock++ & 3u) == 0) {
+						       if ((vote_clock++ & (16u / U - 1u)) == 0) { /* every 64 pixels per lane */
 							       bool flat = true;
 #pragma unroll
 							       for (int k = 0; k < U; k++)
