@@ -107,7 +107,7 @@ int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
 /* Tunables for A/B measurements (the defaults are the measured best, profiles/):
  *   "vss.merge" 0|2|3        plain adds | absorb mode always | absorb mode by wave vote
  *   "vss.unroll" 1|2|4, "vss.fused_unroll" 1|2|4, "his.unroll" 1|2|4   16-byte loads per lane per batch
- *   "vss.hash" 0|1, "vss.groups" 0..3   bin -> LDS word placement; log2 of lane groups per wave
+ *   "vss.hash" 0|1, "vss.groups" 0..3   table rows XOR-swizzled across the LDS banks (0) or not (1); log2 of lane groups per wave
  *   "vss.block" / "his.block" 0|64..1024   threads per workgroup (0 = 1024)
  *   "wvs.wide" 0|1, "wvs.persist" 0|1, "wvs.per_cu" 0|1|2   waveform load shape / persistent walk / workgroups per CU
  *   "fold" 0|1   histogram partials summed by the last workgroup of a frame
