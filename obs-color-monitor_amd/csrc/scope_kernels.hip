@@ -83,14 +83,15 @@ __device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool nee
  * The fp32 chain above costs ~33 VALU instructions per texel and makes every fused kernel VALU-bound.
  * The value it approximates is T = c_r R + c_g G + c_b B + 255 off + 0.5 with output floor(T) (no clamp is
  * ever active for 8-bit inputs), which three 24-bit integer multiply-adds give directly in 2^-24 fixed
- * point: E = C_r R + C_g G + C_b B + K, the output is byte 3 of E (chroma |c| < 0.5 fits v_mul_i32_i24, luma
- * 0 <= c < 1 fits v_mul_u32_u24; the sum is taken mod 2^32 and ends below 256 * 2^24).  The two disagree only where T is within ~2.5e-5 of an integer, i.e.
- * where fp32 rounding decides: an exhaustive run over all 2^24 colours, both matrices and all three rows finds every
- * such colour within 422 units (2^-24) of a step.  So K carries a guard of 512 units and a value whose fraction is
- * below 1024 -- bytes 1..2 of E, read as a number, below 4 -- is "near a step": its cell is recomputed with the fp32
- * chain (a wave votes per cell; 6e-5 .. 1e-3 of all colours).  Two rows' fractions travel as the halves of one
- * register (v_perm_b32) and the running minimum over a cell is a v_pk_min_u16.  Black is an exact tie (V = 128.0) on
- * which both paths agree, and common (letterbox bars): it is exempt.
+ * point: E = C_r R + C_g G + C_b B + K, and the output is byte 3 of E (chroma |c| < 0.5 fits v_mul_i32_i24,
+ * luma 0 <= c < 1 fits v_mul_u32_u24; the sum is taken mod 2^32 and ends below 256 * 2^24).  The two disagree
+ * only where T is within ~2.5e-5 of an integer, i.e. where fp32 rounding decides: an exhaustive run over all
+ * 2^24 colours, both matrices and all three rows finds every such colour within 422 units (2^-24) of a step.
+ * So K carries a guard of 512 units and a value whose fraction is below 1024 -- bytes 1..2 of E, read as a
+ * number, below 4 -- is "near a step": its cell is recomputed with the fp32 chain (a wave votes per cell;
+ * 6e-5 .. 1e-3 of all colours).  Two rows' fractions travel as the halves of one register (v_perm_b32) and the
+ * running minimum over a cell is a v_pk_min_u16.  Black is an exact tie (V = 128.0) on which both paths agree,
+ * and common (letterbox bars): cells that are black throughout are exempt.
  * tests/test_parity_gpu.py runs all 2^24 colours through this code against the oracle. */
 __device__ __forceinline__ int scope_mad24(int a, int b, int c)
 {
@@ -124,7 +125,8 @@ __device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool nee
 		out = scope_perm(ev, eu, VSSKEY ? 0x0c07030cu : 0x0d070c03u); /* 0, U, V, 0 or U, 0, V, 255 */
 	}
 	if (need_y) {
-		const u32 ey = scope_umad24((u32)k.fy[0], (u32)r, scope_umad24((u32)k.fy[1], (u32)g, scope_umad24((u32)k.fy[2], (u32)b, (u32)k.fy[3])));
+		const u32 ey = scope_umad24((u32)k.fy[0], (u32)r,
+					    scope_umad24((u32)k.fy[1], (u32)g, scope_umad24((u32)k.fy[2], (u32)b, (u32)k.fy[3])));
 		worst = scope_pk_min_u16(worst, scope_perm(ey, ey, 0x06050201u));
 		out = scope_perm(ey, out, 0x03020700u);
 	}
