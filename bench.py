@@ -4,9 +4,10 @@
   python bench.py --gpus N --steps K --warmup W         (N > 1: launched under torch.distributed.run)
 
 A *step* is one pass of the hot path over one batch of synthetic input: by default the 256x256
-CbCr vectorscope scatter (BASELINE configs[1]) over `--frames` (32) distinct 3840x2160 BGRA8 frames
-that are already resident in HBM (32 x 33 MB > the 256 MB Infinity Cache, so every step streams
-from HBM).  Frames are uniform-random RGB pushed through the K0 kernel, i.e. the staged Y'CbCr
+CbCr vectorscope scatter (BASELINE configs[1]) over `--frames` (64, the most one launch takes) distinct
+3840x2160 BGRA8 frames that are already resident in HBM (64 x 33 MB = 2.1 GB, far beyond the 256 MB
+Infinity Cache, so every step streams from HBM; a launch costs ~20 us on top of its streaming time,
+which is why the batch is deep: 32 frames read 6-7 % slower, 128 and 256 -- two and four launches -- no faster).  Frames are uniform-random RGB pushed through the K0 kernel, i.e. the staged Y'CbCr
 planes the reference's vss_draw_vectorscope reads.  Every step goes through the C-ABI of
 libscope_hip.so (no CPU path exists in the product).
 
@@ -42,7 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed run of the same step before the warm-up so the GPU clocks (DVFS) leave idle")
-    ap.add_argument("--frames", type=int, default=0, help="distinct HBM-resident frames per step (default 32 at 4k, 8 at 8k)")
+    ap.add_argument("--frames", type=int, default=0, help="distinct HBM-resident frames per step (default 64 at 4k, 16 at 8k)")
     ap.add_argument("--size", default="4k", choices=["4k", "8k"],
                     help="frame size: 3840x2160 (the metric's configuration) or 7680x4320 (BASELINE config 4's frame)")
     ap.add_argument("--workload", default="vectorscope", choices=["vectorscope", "vectorscope_rgb", "waveform", "histogram"])
@@ -94,7 +95,7 @@ def main():
 
     # ---- synthetic input, resident in HBM ------------------------------------------------------
     w, h = (W4K, H4K) if args.size == "4k" else (2 * W4K, 2 * H4K)
-    n = args.frames or (32 if args.size == "4k" else 8)
+    n = args.frames or (64 if args.size == "4k" else 16)
     from obs_color_monitor_amd.synth import make_frames
 
     rgb, yuv = make_frames(torch, ctx, n, w, h, args.dist, 0x9E3779B9 + rank)

@@ -403,14 +403,6 @@ template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u
 	atomicAdd((u32 *)((uint8_t *)tab + byte), n << ((key >> 4) & 31u));
 }
 
-/* one clamped bin out of the table */
-template <int HASH> __device__ __forceinline__ u32 vss_read_bin(const u32 *tab, u32 row, u32 u)
-{
-	const u32 col = HASH == 1 ? (u >> 1) : ((u >> 1) ^ ((row & 15u) << 3));
-	const u32 w = tab[(row << 7) + col] >> ((u & 1u) << 4);
-	return min(w & 0xffffu, 255u);
-}
-
 /* Flat content (screen capture, graphics, letterbox, a paused scene): almost every pixel of a lane's
  * stream has the colour the lane saw last.  Same-address LDS atomics serialise at ~4 clk per lane
  * (profiles/round1/lds_atomic_microbench.txt) -- a flat frame costs 127 clk per wave instruction --
@@ -472,6 +464,12 @@ __device__ __forceinline__ u32 vss_clamp_word(u32 w)
 	const u32 lo = min(w & 0xffffu, 255u);
 	const u32 hi = min(w >> 16, 255u);
 	return lo | (hi << 16);
+}
+
+/* two table words = four consecutive bins -> four clamped bytes */
+__device__ __forceinline__ u32 vss_clamp_pair(u32 w0, u32 w1)
+{
+	return min(w0 & 0xffffu, 255u) | (min(w0 >> 16, 255u) << 8) | (min(w1 & 0xffffu, 255u) << 16) | (min(w1 >> 16, 255u) << 24);
 }
 
 __device__ __forceinline__ void vss_clamp_pass(u32 *tab)
@@ -602,16 +600,15 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	vss_flush_lane<HASH>(tab, st);
 	__syncthreads();
 
-	/* flush: 16 consecutive bins of one row per lane per step, one coalesced 16-byte store */
+	/* flush: 16 consecutive bins of one row per lane per step = 8 table words, which the swizzle (a multiple of eight
+	 * words) leaves contiguous: two 16-byte LDS reads, one coalesced 16-byte store */
 	uint4 *out = (uint4 *)(dst + (size_t)unit * SCOPE_VSS_BINS);
 	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x) {
-		const u32 row = 255u - (g >> 4) /* table row v of output row g >> 4 */, u0 = (g & 15u) << 4;
-		u32 o[4];
-#pragma unroll
-		for (u32 j = 0; j < 4; j++)
-			o[j] = vss_read_bin<HASH>(tab, row, u0 + 4 * j) | (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 1) << 8) |
-			       (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 2) << 16) | (vss_read_bin<HASH>(tab, row, u0 + 4 * j + 3) << 24);
-		out[g] = make_uint4(o[0], o[1], o[2], o[3]);
+		const u32 row = 255u - (g >> 4); /* table row v of output row g >> 4 */
+		const u32 w0 = (row << 7) + (((g & 15u) << 3) ^ (HASH == 1 ? 0u : ((row & 15u) << 3)));
+		const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
+		out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
+				    vss_clamp_pair(hi.z, hi.w));
 	}
 }
 
