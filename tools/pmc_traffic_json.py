@@ -14,7 +14,8 @@ import sys
 
 KERNEL = {"vectorscope": "scope_vss_kernel", "vectorscope_rgb": "scope_vss_kernel", "waveform": "scope_wvs_kernel",
           "histogram": "scope_his_kernel"}
-W, H, FRAMES = 3840, 2160, 32
+W, H = 3840, 2160
+FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 64  # frames per launch of the profiled bench.py runs (its default)
 
 
 def mean_counter(d, kernel, counter):
