@@ -32,6 +32,16 @@ typedef uint64_t u64;
 
 /* All LDS scratch lives in the dynamic region so its base stays 16-byte aligned. */
 extern __shared__ __attribute__((aligned(16))) u32 scope_lds[];
+#ifdef SCOPE_TRACE_WG
+__device__ unsigned long long scope_dbg_times[1024 * 4];
+extern "C" int scope_debug_read(unsigned long long *out)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scope_dbg_times), sizeof(unsigned long long) * 1024 * 4);
+}
+#define SCOPE_STAMP(k) do { if (threadIdx.x == 0) scope_dbg_times[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define SCOPE_STAMP(k) do { } while (0)
+#endif
 
 /* ------------------------------------------------------------------------------------------
  * K0: per-texel RGB -> Y'CbCr, bit-exact with oracle/scope_oracle.c:k0_texel
@@ -591,6 +601,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 		*(uint4 *)&tab[i] = zero;
 	__syncthreads();
 
+	SCOPE_STAMP(0);
 	u32 since_clamp = 0;
 	VssLane st = {0xffffffffu, 0};
 	vss_region<4, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, glog2, k0,
@@ -599,6 +610,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 						 k0, since_clamp, st);
 	vss_flush_lane<HASH>(tab, st);
 	__syncthreads();
+	SCOPE_STAMP(1);
 
 	/* flush: 16 consecutive bins of one row per lane per step = 8 table words, which the swizzle (a multiple of eight
 	 * words) leaves contiguous: two 16-byte LDS reads, one coalesced 16-byte store */
@@ -610,6 +622,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 		out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
 				    vss_clamp_pair(hi.z, hi.w));
 	}
+	SCOPE_STAMP(2);
 }
 
 /* ------------------------------------------------------------------------------------------
