@@ -28,6 +28,10 @@ for n in (8, 64):
         t0 = t[:, 0].min()
         us = (t - t0) / 100.0   # 100 MHz
         res.append((us[:, 0].max(), np.median(us[:, 1]), us[:, 1].min(), us[:, 1].max(), us[:, 2].max(), np.percentile(us[:, 1], 10), np.percentile(us[:, 1], 90)))
+    ends = us[:, 1]  # last launch: when each workgroup left its pixel loop
+    print("   by XCD (workgroup id mod 8), mean end [us]:", " ".join(f"{ends[x::8].mean():.1f}" for x in range(8)))
+    sl = max(1, 256 // n)
+    print(f"   by slice of its frame (id mod {sl}), mean end [us]:", " ".join(f"{ends[x::sl].mean():.1f}" for x in range(min(sl, 8))))
     r = np.median(np.array(res), axis=0)
     print(f"n={n}: last start +{r[0]:.1f} us; main loop ends median {r[1]:.1f} (min {r[2]:.1f}, p10 {r[5]:.1f}, p90 {r[6]:.1f}, max {r[3]:.1f}); last flush done {r[4]:.1f} us")
     del rgb, yuv, out
