@@ -28,10 +28,11 @@ def main():
     ap.add_argument("--workload", default="vectorscope")
     ap.add_argument("--dists", default="uniform,natural,screen")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=32, help="frames per launch (bench.py's default is 64)")
     ap.add_argument("--opt-a", action="append", default=[], help="key=value for the first library's context")
     ap.add_argument("--opt-b", action="append", default=[], help="key=value for the second (the same .so twice compares options)")
     args = ap.parse_args()
-    n = 32
+    n = args.frames
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctxs = []
