@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef uint32_t v4 __attribute__((vector_size(16)));
 
@@ -202,8 +203,47 @@ __global__ void fill_kernel(uint32_t *p, uint64_t n)
 		p[i] = (uint32_t)(i * 2654435761u) | 1u;
 }
 
-int main()
+// Round 2: why does the same kernel read 3-4 % slower from some allocations ("two placement modes")?
+// Ten 1 GiB allocations of one process, each read (a) as chunks interleaved over the workgroups -- the chip sweeps memory
+// linearly and touches few pages at a time -- and (b) as one contiguous share per workgroup walked in 8 lane-group
+// streams, which is what the vectorscope kernel does: 2048 streams that are 0.5 MB apart.  If only (b) depends on the
+// allocation, the address translation (page fragment size of the allocation) is the suspect, not the DRAM.
+static int placement_main()
 {
+	const uint64_t bytes = 32ull * 3840 * 2160 * 4;
+	const uint64_t n16 = bytes / 16;
+	const int NB = 10;
+	uint32_t *buf[NB], *sink;
+	hipMalloc((void **)&sink, 64);
+	for (int i = 0; i < NB; i++) {
+		if (hipMalloc((void **)&buf[i], bytes) != hipSuccess) {
+			fprintf(stderr, "hipMalloc failed\n");
+			return 1;
+		}
+		hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf[i], bytes / 4);
+	}
+	hipDeviceSynchronize();
+	for (int i = 0; i < 300; i++)
+		hipLaunchKernelGGL((read_kernel<4, true>), dim3(256), dim3(1024), 0, 0, (const v4 *)buf[0], n16, sink);
+	hipDeviceSynchronize();
+	for (int round = 0; round < 2; round++)
+		for (int i = 0; i < NB; i++) {
+			const float a = run_pp<4, true, 0>((const v4 *)buf[i], n16, sink, 256, 1024, 30);
+			const float b = run_pp<4, true, 2>((const v4 *)buf[i], n16, sink, 256, 1024, 30);
+			const float c = run_pp<4, true, 1>((const v4 *)buf[i], n16, sink, 256, 1024, 30);
+			printf("round %d buffer %d at %p (mod 2MiB = %#llx, mod 1GiB = %#llx): interleaved %7.1f  contiguous+8 streams %7.1f  contiguous %7.1f GB/s\n",
+			       round, i, (void *)buf[i], (unsigned long long)((uintptr_t)buf[i] & 0x1fffff),
+			       (unsigned long long)((uintptr_t)buf[i] & 0x3fffffff), bytes / (a * 1e-3) / 1e9, bytes / (b * 1e-3) / 1e9,
+			       bytes / (c * 1e-3) / 1e9);
+			fflush(stdout);
+		}
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc > 1 && !strcmp(argv[1], "placement"))
+		return placement_main();
 	const uint64_t bytes = 32ull * 3840 * 2160 * 4;
 	const uint64_t n16 = bytes / 16;
 	uint32_t *buf, *sink;

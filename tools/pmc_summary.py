@@ -18,7 +18,7 @@ for d in sys.argv[1:]:
             acc[name][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
     print("==", d)
     for name, ctrs in acc.items():
-        if "scope_" not in name:
+        if "scope_" not in name and "flush_" not in name:
             continue
         print("  ", name)
         for c, vals in sorted(ctrs.items()):
