@@ -106,11 +106,13 @@ int scope_ctx_sync(scope_ctx *ctx);
 int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
 /* Tunables for A/B measurements (the defaults are the measured best, profiles/):
  *   "vss.merge" 0|2|3        plain adds | absorb mode always | absorb mode by wave vote
- *   "vss.unroll" 1|2|4, "vss.fused_unroll" 1|2|4, "his.unroll" 1|2|4   16-byte loads per lane per batch
- *   "vss.hash" 0|1, "vss.groups" 0..3   table rows XOR-swizzled across the LDS banks (0) or not (1); log2 of lane groups per wave
+ *   "vss.unroll" 0|1|2|4, "vss.fused_unroll" 1|2|4, "his.unroll" 1|2|4   16-byte loads per lane per batch (0: by launch size)
+ *   "vss.hash" 0|1, "vss.groups" -1|0..3   table rows XOR-swizzled across the LDS banks (0) or not (1); log2 of lane groups per
+ *                wave (-1: 8 groups for batches, 1 for launches of a few frames)
  *   "vss.block" / "his.block" 0|64..1024   threads per workgroup (0 = 1024)
  *   "wvs.wide" 0|1, "wvs.persist" 0|1, "wvs.per_cu" 0|1|2   waveform load shape / persistent walk / workgroups per CU
- *   "fold" 0|1   histogram partials summed by the last workgroup of a frame
+ *   "fold" 0|1   the slices of a histogram frame meet inside the launch (atomics + last arrival) | partial tables + a second kernel
+ *   "vss.sparse" 0|1   vectorscope partial tables hold only the 16-bin groups that are not empty
  *   "nt" 0|1     streaming (non-temporal) loads
  *   "slices"     workgroups per frame (0 = automatic) */
 int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value);
@@ -175,6 +177,20 @@ int scope_waveform(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t
  * counts = uint32[256][4], slots R,G,B,unused. */
 int scope_histogram_counts(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t components, uint32_t flags,
 			   uint32_t *counts);
+
+/* ---- K2 + K3 in one pass over the plane ------------------------------------------------------
+ * The dock hands ONE staged surface to every registered scope (roi_surface_cb, src/roi.c:329-341) and the reference
+ * then walks it once per scope.  A waveform strip's table is a histogram per column, so the waveform kernel's flush can
+ * add the columns up: the K3 counts of the same plane come out of the K2 pass without a second read and without a
+ * single extra LDS atomic per pixel.  Results are exactly those of scope_waveform + scope_histogram_counts.  The pass is
+ * shared when both masks select the same plane (both RGB, or both Y'CbCr) and the histogram counts no channel the
+ * waveform does not (e.g. 0x07 + 0x07, 0x70 + 0x20); otherwise the two scopes run one after the other.  wvs_out and
+ * his_counts are both host or both device.  Inside scope_surface_begin/end a plain scope_waveform call does the same
+ * on the side and a following scope_histogram* call on that surface is served from it (counted as a reuse). */
+int scope_waveform_histogram(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t wvs_components,
+			     uint32_t his_components, uint32_t flags, uint8_t *wvs_out, uint32_t *his_counts);
+int scope_waveform_histogram_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t wvs_components,
+				   uint32_t his_components, uint32_t flags, uint8_t *wvs_out, uint32_t *his_counts);
 
 /* ---- K3 + K3b: the whole of his_draw_histogram ---------------------------------------------
  * Replaces his_draw_histogram(src, tex_buf, hi_max, surface_data) (src/histogram.c:357-418):
@@ -253,10 +269,13 @@ int scope_pipe_size(const scope_pipe *pipe, uint32_t *width, uint32_t *height);
 void scope_pipe_destroy(scope_pipe *pipe);
 /* Enqueue one RGB frame (bytes B,G,R,A).  SCOPE_EAGAIN when `depth` frames are already in flight. */
 int scope_pipe_submit(scope_pipe *pipe, const uint8_t *rgb_host, uint32_t linesize);
-/* Wait for the OLDEST frame in flight and hand out its tables (pinned host memory owned by the
- * pipe, valid until `depth` more frames have been submitted).  Pointers for scopes that were not
+/* Wait for the OLDEST frame in flight and hand out its tables: pinned host memory owned by the pipe, which rotates
+ * depth + 1 table buffers, so the pointers stay valid until the NEXT scope_pipe_collect, however many frames are
+ * submitted in between -- also when the ring was full and the next submit re-uses the collected frame's slot at once.  Pointers for scopes that were not
  * configured come back NULL.  his_counts is uint32[256][4] (apply scope_histogram_level for K3b).
- * SCOPE_EAGAIN when nothing is in flight. */
+ * SCOPE_EAGAIN when nothing is in flight.
+ * A scope_pipe_submit that fails half-way drains what it had queued and does NOT take a ring slot: the frame is simply
+ * not in the pipe, the next submit starts clean. */
 int scope_pipe_collect(scope_pipe *pipe, const uint8_t **vectorscope, const uint8_t **waveform,
 		       const uint32_t **his_counts);
 
@@ -270,6 +289,20 @@ int scope_table_clamp_u32_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, u
  * (257 * 255 < 65536, so the halves never carry).  n_pairs = number of bins / 2. */
 int scope_table_pack_u8_u16x2(scope_ctx *ctx, const uint8_t *in, uint32_t *out, uint64_t n_pairs);
 int scope_table_unpack_clamp_u16x2_u8(scope_ctx *ctx, const uint32_t *in, uint8_t *out, uint64_t n_pairs);
+
+/* The sum itself, callable from C: an in-place ncclAllReduce(sum, uint32) over RCCL / xGMI of `n_words` packed
+ * (scope_table_pack_u8_u16x2, or SCOPE_OUT_PACKED16 straight from scope_vectorscope_batch) or plain uint32
+ * (histogram counts) words on the context's stream, i.e. ordered behind the kernels that filled `words` and before
+ * scope_table_unpack_clamp_u16x2_u8.  The communicator is the host's own ncclComm_t handed in as is (one rank per
+ * GPU, created on the context's device); hosts that have none can make one with the three helpers below: rank 0
+ * calls scope_rccl_unique_id and passes the 128 bytes to the other ranks by its own means (a file, a socket, MPI,
+ * torch.distributed), then every rank calls scope_rccl_comm_create.  RCCL is loaded on first use (dlopen): a
+ * single-GPU host never touches it.  The reference has no multi-GPU path; this replaces nothing in it. */
+#define SCOPE_RCCL_ID_BYTES 128
+int scope_rccl_unique_id(uint8_t id[SCOPE_RCCL_ID_BYTES]);
+int scope_rccl_comm_create(scope_ctx *ctx, const uint8_t id[SCOPE_RCCL_ID_BYTES], int n_ranks, int rank, void **rccl_comm);
+int scope_rccl_comm_destroy(void *rccl_comm);
+int scope_table_allreduce(scope_ctx *ctx, void *rccl_comm, uint32_t *words, uint64_t n_words);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * With profiling on, every accumulation launch (the dominant kernel of a call, not the small

@@ -10,6 +10,7 @@
 #include "../../include/scope_hip.h"
 #include "scope_kernels.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <mutex>
@@ -18,7 +19,6 @@
 #include <string.h>
 
 #define SCOPE_PROFILE_SLOTS 512u
-#define SCOPE_FOLD_MAX_SLICES 16u /* more partials than this: one workgroup summing them is slower than a kernel */
 
 struct scope_ctx {
 	int device;
@@ -27,6 +27,9 @@ struct scope_ctx {
 	hipStream_t stream;
 	uint8_t *partial; /* partial tables of one launch */
 	size_t partial_bytes;
+	uint8_t *pmask; /* which 16-bin groups of the vectorscope's sparse partials were written */
+	size_t pmask_bytes;
+	uint32_t *his_acc; /* SCOPE_MAX_FRAMES x 1024 accumulators of the histogram's in-launch combine; zero between launches */
 	uint8_t *stage_in; /* host planes uploaded here */
 	size_t stage_in_bytes;
 	uint8_t *stage_out; /* tables on their way to a host buffer */
@@ -45,8 +48,15 @@ struct scope_ctx {
 		uint32_t linesize, width, height; /* geometry of the cached planes */
 		uint32_t pitch;                   /* of the device copies */
 		uint32_t uploads, hits;
+		/* the histogram the waveform pass of this surface produced on the side (scope_waveform inside begin/end):
+		 * a later scope_histogram* call for the same plane and a subset of its channels is served from here */
+		bool his_valid;
+		const uint8_t *his_plane;
+		int his_fuse;
+		uint32_t his_chmask;
+		uint32_t his_counts[SCOPE_HIS_WORDS];
 	} surf;
-	uint32_t *tickets; /* SCOPE_MAX_FRAMES arrival counters of the in-kernel reduction; zero between launches */
+	uint32_t *tickets; /* SCOPE_MAX_FRAMES arrival counters of the in-launch combine; zero between launches */
 	ScopeTuning tn;
 	int slices_override;
 	int profile;
@@ -330,15 +340,23 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 			return fail(ctx, SCOPE_EINVAL, "pitch * height too large", hipSuccess);
 		if (slices < min_slices)
 			slices = min_slices;
+		const uint32_t mask_block = ctx->tn.vss_sparse ? scope_vss_mask_block(ctx->tn) : 0u;
 		if (slices == 1 && !packed) {
-			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, NULL, ctx->tn, ctx->stream));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * SCOPE_VSS_BINS);
+			if (!st && mask_block)
+				st = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)nf * slices * mask_block);
 			if (st)
 				return st;
-			TIMED_LAUNCH(ctx, scope_launch_vss(fs, slices, fuse, colorspace, ctx->partial, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_vss(fs, slices, fuse, colorspace, ctx->partial, mask_block ? ctx->pmask : NULL,
+							   ctx->tn, ctx->stream));
 			/* one partial per frame and a packed result: the "reduction" of one table is just the repacking */
-			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, slices, SCOPE_VSS_BINS, packed, ctx->stream));
+			if (mask_block)
+				HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, dst, nf, slices, mask_block, packed,
+									    ctx->stream));
+			else
+				HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, slices, SCOPE_VSS_BINS, packed, ctx->stream));
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* stage_in is reused by the next chunk */
@@ -346,8 +364,11 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 	return result_end(ctx, out, (size_t)n * table, flags, dev_out);
 }
 
+/* his_counts != NULL: the same pass over the planes also leaves their K3 count tables (uint32[n][256][4], host or
+ * device like `out`) for the channels of his_chmask that chmask covers -- the caller checks that it covers them all. */
 int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
-		 uint32_t height, uint32_t chmask, int fuse, int colorspace, uint32_t flags, uint8_t *out)
+		 uint32_t height, uint32_t chmask, int fuse, int colorspace, uint32_t flags, uint8_t *out,
+		 uint32_t *his_counts = NULL, uint32_t his_chmask = 0)
 {
 	int st = check_flags(ctx, flags);
 	if (!st)
@@ -357,10 +378,16 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 	if (width == 0)
 		return SCOPE_OK; /* empty table */
 	const size_t table = (size_t)SCOPE_WV_SIZE * width * 4;
-	uint8_t *dev_out = NULL;
-	st = result_begin(ctx, out, (size_t)n * table, flags, &dev_out);
-	if (st)
-		return st;
+	const size_t his_table = SCOPE_HIS_WORDS * sizeof(uint32_t);
+	uint8_t *dev_out = out, *dev_his = (uint8_t *)his_counts;
+	if (!(flags & SCOPE_OUT_DEVICE)) {
+		const size_t his_at = round_up((size_t)n * table, 256);
+		st = grow(ctx, &ctx->stage_out, &ctx->stage_out_bytes, his_at + (his_counts ? round_up((size_t)n * his_table, 256) : 0));
+		if (st)
+			return st;
+		dev_out = ctx->stage_out;
+		dev_his = his_counts ? ctx->stage_out + his_at : NULL;
+	}
 	const uint32_t strips = (width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
 	for (uint32_t f0 = 0; f0 < n; f0 += SCOPE_MAX_FRAMES) {
 		const uint32_t nf = (n - f0 < SCOPE_MAX_FRAMES) ? n - f0 : SCOPE_MAX_FRAMES;
@@ -369,6 +396,9 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 		if (st)
 			return st;
 		uint8_t *dst = dev_out + (size_t)f0 * table;
+		const ScopeHisSink sink = {ctx->his_acc, ctx->tickets, (uint32_t *)(dev_his ? dev_his + (size_t)f0 * his_table : NULL),
+					   his_chmask};
+		const ScopeHisSink *his = dev_his ? &sink : NULL;
 		uint32_t bands = pick_slices(ctx, nf, strips);
 		if (bands > 16)
 			bands = 16;
@@ -377,24 +407,35 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 			bands = 1;
 		/* the kernel counts in 16 bits per column and band: a band holds at most 65535 rows */
 		const uint32_t min_bands = (height + 65534u) / 65535u;
+		if (min_bands > 256)
+			return fail(ctx, SCOPE_EINVAL, "frame taller than 256 * 65535 rows", hipSuccess); /* the reduction sums <= 256 partials */
 		if (bands < min_bands) {
 			if (((uintptr_t)dst) & 15u)
 				return fail(ctx, SCOPE_EINVAL, "frames taller than 65535 rows need a 16-byte aligned table", hipSuccess);
-			bands = min_bands; /* <= 256 partials, the reduction's limit: width * height < 2^31 */
+			bands = min_bands;
 		}
 		if (bands == 1) {
-			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->num_cu, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->num_cu, ctx->tn, ctx->stream, his));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * bands * table);
 			if (st)
 				return st;
-			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, bands, chmask, fuse, colorspace, ctx->partial, ctx->num_cu, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, bands, chmask, fuse, colorspace, ctx->partial, ctx->num_cu, ctx->tn, ctx->stream,
+							   his));
 			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, bands, table, 0, ctx->stream));
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	return result_end(ctx, out, (size_t)n * table, flags, dev_out);
+	if (!(flags & SCOPE_OUT_DEVICE)) {
+		HIP_TRY(ctx, hipMemcpyAsync(out, dev_out, (size_t)n * table, hipMemcpyDeviceToHost, ctx->stream));
+		if (his_counts)
+			HIP_TRY(ctx, hipMemcpyAsync(his_counts, dev_his, (size_t)n * his_table, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	} else if (!(flags & SCOPE_ASYNC)) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return SCOPE_OK;
 }
 
 int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
@@ -425,19 +466,18 @@ int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint
 			slices = min_slices;
 		if (slices == 1) {
 			TIMED_LAUNCH(ctx, scope_launch_his(fs, 1, chmask, fuse, colorspace, dst, NULL, NULL, ctx->tn, ctx->stream));
+		} else if (ctx->tn.fold) {
+			/* the slices of a frame meet in ctx->his_acc inside the launch; no partial tables, no second kernel */
+			TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, dst, ctx->his_acc, ctx->tickets, ctx->tn,
+							   ctx->stream));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * table);
 			if (st)
 				return st;
-			if (ctx->tn.fold && slices <= SCOPE_FOLD_MAX_SLICES) {
-				TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, (uint32_t *)ctx->partial, dst,
-							      ctx->tickets, ctx->tn, ctx->stream));
-			} else {
-				TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, (uint32_t *)ctx->partial, NULL,
-							      NULL, ctx->tn, ctx->stream));
-				HIP_TRY(ctx, scope_launch_sum_reduce((const uint32_t *)ctx->partial, dst, nf, slices, SCOPE_HIS_WORDS,
-								     ctx->stream));
-			}
+			TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, (uint32_t *)ctx->partial, NULL, NULL,
+							   ctx->tn, ctx->stream));
+			HIP_TRY(ctx, scope_launch_sum_reduce((const uint32_t *)ctx->partial, dst, nf, slices, SCOPE_HIS_WORDS,
+							     ctx->stream));
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
 			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -576,8 +616,11 @@ int scope_ctx_create(int device, scope_ctx **out)
 	}
 	ctx->stream = ctx->own_stream;
 	bool ok = scope_kernels_init() == hipSuccess;
+	const size_t acc_bytes = (size_t)SCOPE_MAX_FRAMES * SCOPE_HIS_WORDS * sizeof(uint32_t);
 	ok = ok && hipMalloc((void **)&ctx->tickets, SCOPE_MAX_FRAMES * sizeof(uint32_t)) == hipSuccess &&
 	     hipMemsetAsync(ctx->tickets, 0, SCOPE_MAX_FRAMES * sizeof(uint32_t), ctx->stream) == hipSuccess &&
+	     hipMalloc((void **)&ctx->his_acc, acc_bytes) == hipSuccess &&
+	     hipMemsetAsync(ctx->his_acc, 0, acc_bytes, ctx->stream) == hipSuccess &&
 	     hipStreamSynchronize(ctx->stream) == hipSuccess;
 	for (uint32_t i = 0; ok && i < 2 * SCOPE_PROFILE_SLOTS; i++)
 		ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
@@ -586,15 +629,16 @@ int scope_ctx_create(int device, scope_ctx **out)
 		return SCOPE_EIO;
 	}
 	ctx->tn.vss_merge = 3;
-	ctx->tn.vss_unroll = 4;
+	ctx->tn.vss_unroll = 0;       /* auto: 4 loads per lane per batch for batches, 2 for launches of a few frames */
 	ctx->tn.vss_fused_unroll = 2;
 	ctx->tn.vss_hash = 0;
-	ctx->tn.vss_groups_log2 = 3;
+	ctx->tn.vss_groups_log2 = -1; /* auto: 8 lane-group streams for batches, one stream for launches of a few frames */
 	ctx->tn.his_unroll = 1;
 	ctx->tn.wvs_wide = 1;
 	ctx->tn.wvs_persist = 1;
 	ctx->tn.wvs_per_cu = 1;
 	ctx->tn.fold = 1;
+	ctx->tn.vss_sparse = 1;
 	ctx->tn.nt_loads = 1;
 	ctx->err[0] = 0;
 	*out = ctx;
@@ -615,6 +659,10 @@ void scope_ctx_destroy(scope_ctx *ctx)
 		(void)hipFree(ctx->stage_out);
 	if (ctx->tickets)
 		(void)hipFree(ctx->tickets);
+	if (ctx->his_acc)
+		(void)hipFree(ctx->his_acc);
+	if (ctx->pmask)
+		(void)hipFree(ctx->pmask);
 	for (int k = 0; k < 2; k++)
 		if (ctx->surf.dev[k])
 			(void)hipFree(ctx->surf.dev[k]);
@@ -694,6 +742,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.his_unroll = value;
 	else if (!strcmp(key, "fold"))
 		ctx->tn.fold = value != 0;
+	else if (!strcmp(key, "vss.sparse"))
+		ctx->tn.vss_sparse = value != 0;
 	else if (!strcmp(key, "wvs.per_cu"))
 		ctx->tn.wvs_per_cu = value;
 	else if (!strcmp(key, "wvs.persist"))
@@ -823,6 +873,7 @@ int scope_surface_begin(scope_ctx *ctx, uint32_t flags)
 	ctx->surf.fuse_k0 = (flags & SCOPE_FUSE_K0) != 0;
 	ctx->surf.host[0] = ctx->surf.host[1] = NULL;
 	ctx->surf.uploads = ctx->surf.hits = 0;
+	ctx->surf.his_valid = false;
 	return SCOPE_OK;
 }
 
@@ -838,6 +889,7 @@ int scope_surface_end(scope_ctx *ctx, uint32_t *uploads, uint32_t *reuses)
 	if (reuses)
 		*reuses = ctx->surf.hits;
 	ctx->surf.active = false;
+	ctx->surf.his_valid = false;
 	ctx->surf.host[0] = ctx->surf.host[1] = NULL;
 	/* every call in between was synchronous (host planes), so nothing is in flight on the cached copies */
 	probe.unlock();
@@ -899,6 +951,19 @@ int scope_waveform(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t
 	if (sel == 0 || sd->height == 0 || sd->width == 0)
 		return table ? zero_result(ctx, out, table, flags) : SCOPE_OK; /* src/waveform.c:225-234 */
 	const uint8_t *one[1] = {plane};
+	if (ctx->surf.active && !(flags & (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE))) {
+		/* the dock: the same surface goes to the histogram next (src/roi.c:329-341); its counts cost this pass nothing */
+		ctx->surf.his_valid = false;
+		st = run_waveform(ctx, one, 1, sd->linesize, sd->width, sd->height, channel_mask(components), fuse, sd->colorspace,
+				  flags, out, ctx->surf.his_counts, channel_mask(components));
+		if (st == SCOPE_OK) {
+			ctx->surf.his_valid = true;
+			ctx->surf.his_plane = plane;
+			ctx->surf.his_fuse = fuse;
+			ctx->surf.his_chmask = channel_mask(components);
+		}
+		return st;
+	}
 	return run_waveform(ctx, one, 1, sd->linesize, sd->width, sd->height, channel_mask(components), fuse,
 			    sd->colorspace, flags, out);
 }
@@ -941,9 +1006,18 @@ int scope_histogram_counts(scope_ctx *ctx, const struct scope_surface_data *sd, 
 		return sel; /* his_surface_cb returns without drawing, src/histogram.c:436-441 */
 	if (sel == 0 || sd->height == 0 || sd->width == 0)
 		return zero_result(ctx, counts, SCOPE_HIS_WORDS * 4, flags); /* src/histogram.c:363-373 */
+	const uint32_t chmask = channel_mask(components);
+	if (ctx->surf.active && ctx->surf.his_valid && !(flags & (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE)) &&
+	    ctx->surf.his_plane == plane && ctx->surf.his_fuse == fuse && (chmask & ~ctx->surf.his_chmask) == 0) {
+		for (uint32_t t = 0; t < SCOPE_HIS_WORDS; t++) {
+			const uint32_t slot = t & 3u; /* slot 0 = R = byte 2, 1 = G, 2 = B */
+			counts[t] = (slot < 3 && ((chmask >> (2u - slot)) & 1u)) ? ctx->surf.his_counts[t] : 0u;
+		}
+		ctx->surf.hits++;
+		return SCOPE_OK;
+	}
 	const uint8_t *one[1] = {plane};
-	return run_histogram(ctx, one, 1, sd->linesize, sd->width, sd->height, channel_mask(components), fuse,
-			     sd->colorspace, flags, counts);
+	return run_histogram(ctx, one, 1, sd->linesize, sd->width, sd->height, chmask, fuse, sd->colorspace, flags, counts);
 }
 
 int scope_histogram_counts_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t components, uint32_t flags,
@@ -965,6 +1039,55 @@ int scope_histogram_counts_batch(scope_ctx *ctx, const struct scope_batch *b, ui
 	const int fuse = want_yuv && b->planes_are_rgb;
 	return run_histogram(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, channel_mask(components), fuse,
 			     b->colorspace, flags, counts);
+}
+
+int scope_waveform_histogram(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t wvs_components,
+			     uint32_t his_components, uint32_t flags, uint8_t *wvs_out, uint32_t *his_counts)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if (!sd || !wvs_out || !his_counts)
+		return fail(ctx, SCOPE_EINVAL, "NULL argument", hipSuccess);
+	const uint8_t *pw = NULL, *ph = NULL;
+	int fw = 0, fh = 0;
+	const int sw = pick_plane(ctx, sd, wvs_components, flags, &pw, &fw);
+	const int sh = pick_plane(ctx, sd, his_components, flags, &ph, &fh);
+	const uint32_t cw = channel_mask(wvs_components), ch = channel_mask(his_components);
+	if (sw == 1 && sh == 1 && pw == ph && fw == fh && (ch & ~cw) == 0 && sd->width && sd->height) {
+		const uint8_t *one[1] = {pw};
+		return run_waveform(ctx, one, 1, sd->linesize, sd->width, sd->height, cw, fw, sd->colorspace, flags, wvs_out,
+				    his_counts, ch);
+	}
+	/* different planes or channels the waveform does not count: two passes, same results */
+	st = scope_waveform(ctx, sd, wvs_components, flags, wvs_out);
+	if (st)
+		return st;
+	return scope_histogram_counts(ctx, sd, his_components, flags, his_counts);
+}
+
+int scope_waveform_histogram_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t wvs_components,
+				   uint32_t his_components, uint32_t flags, uint8_t *wvs_out, uint32_t *his_counts)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if (!b || !wvs_out || !his_counts || !b->planes || b->n_frames == 0)
+		return fail(ctx, SCOPE_EINVAL, "NULL or empty batch", hipSuccess);
+	for (uint32_t i = 0; i < b->n_frames; i++)
+		if (!b->planes[i])
+			return SCOPE_ENODATA;
+	const bool w_rgb = (wvs_components & 0x07u) != 0, w_yuv = !w_rgb && (wvs_components & 0x70u) != 0;
+	const bool h_rgb = (his_components & 0x07u) != 0, h_yuv = !h_rgb && (his_components & 0x70u) != 0;
+	const uint32_t cw = channel_mask(wvs_components), ch = channel_mask(his_components);
+	const bool same_kind = (w_rgb && h_rgb && b->planes_are_rgb) || (w_yuv && h_yuv);
+	if (same_kind && (ch & ~cw) == 0 && b->width && b->height)
+		return run_waveform(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, cw, w_yuv && b->planes_are_rgb,
+				    b->colorspace, flags, wvs_out, his_counts, ch);
+	st = scope_waveform_batch(ctx, b, wvs_components, flags, wvs_out);
+	if (st)
+		return st;
+	return scope_histogram_counts_batch(ctx, b, his_components, flags, his_counts);
 }
 
 void scope_histogram_level(uint8_t *tex_buf, uint32_t *hi_max, uint32_t width, uint32_t height, uint32_t components,
@@ -1179,7 +1302,7 @@ struct scope_pipe_slot {
 	uint8_t *dev_stage; /* the scaled / cropped plane (NULL when the region is the whole frame at scale 1) */
 	uint8_t *dev_vss, *dev_wvs;
 	uint32_t *dev_his;
-	uint8_t *host_tables; /* pinned: vss | wvs | his back to back */
+	uint32_t host_index;  /* which of the pipe's pinned table buffers this frame's download goes to */
 	hipEvent_t uploaded, computed, downloaded;
 };
 
@@ -1192,6 +1315,10 @@ struct scope_pipe {
 	bool staged;
 	hipStream_t up, down;
 	scope_pipe_slot slot[SCOPE_PIPE_MAX_DEPTH];
+	/* depth + 1 pinned buffers (vss | wvs | his back to back), used round robin: the tables handed out by
+	 * scope_pipe_collect stay untouched until the next collect, also when the ring was full (at most `depth` frames can
+	 * be submitted between two collects, and they go to the other `depth` buffers) */
+	uint8_t *host_tables[SCOPE_PIPE_MAX_DEPTH + 1];
 	uint64_t submitted, collected;
 };
 
@@ -1217,8 +1344,6 @@ void scope_pipe_destroy(scope_pipe *p)
 			(void)hipFree(s->dev_wvs);
 		if (s->dev_his)
 			(void)hipFree(s->dev_his);
-		if (s->host_tables)
-			(void)hipHostFree(s->host_tables);
 		if (s->uploaded)
 			(void)hipEventDestroy(s->uploaded);
 		if (s->computed)
@@ -1226,6 +1351,9 @@ void scope_pipe_destroy(scope_pipe *p)
 		if (s->downloaded)
 			(void)hipEventDestroy(s->downloaded);
 	}
+	for (uint32_t i = 0; i <= p->cfg.depth && i <= SCOPE_PIPE_MAX_DEPTH; i++)
+		if (p->host_tables[i])
+			(void)hipHostFree(p->host_tables[i]);
 	if (p->up)
 		(void)hipStreamDestroy(p->up);
 	if (p->down)
@@ -1276,12 +1404,11 @@ int scope_pipe_create(scope_ctx *ctx, const struct scope_pipe_config *cfg, scope
 			ok = hipMalloc((void **)&s->dev_wvs, p->wvs_bytes) == hipSuccess;
 		if (ok && p->his_bytes)
 			ok = hipMalloc((void **)&s->dev_his, p->his_bytes) == hipSuccess;
-		if (ok)
-			ok = hipHostMalloc((void **)&s->host_tables, p->vss_bytes + p->wvs_bytes + p->his_bytes + 64, 0) ==
-			     hipSuccess;
 		ok = ok && hipEventCreate(&s->uploaded) == hipSuccess && hipEventCreate(&s->computed) == hipSuccess &&
 		     hipEventCreate(&s->downloaded) == hipSuccess;
 	}
+	for (uint32_t i = 0; ok && i <= cfg->depth; i++)
+		ok = hipHostMalloc((void **)&p->host_tables[i], p->vss_bytes + p->wvs_bytes + p->his_bytes + 64, 0) == hipSuccess;
 	if (!ok) {
 		scope_pipe_destroy(p);
 		return fail(ctx, SCOPE_ENOMEM, "pipeline allocation", hipSuccess);
@@ -1299,19 +1426,13 @@ int scope_pipe_size(const scope_pipe *p, uint32_t *width, uint32_t *height)
 	return SCOPE_OK;
 }
 
-int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
+namespace {
+
+/* Everything scope_pipe_submit enqueues for one frame.  A failure half-way leaves work queued on up to three streams. */
+int pipe_enqueue(scope_pipe *p, scope_pipe_slot *s, const uint8_t *rgb_host, uint32_t linesize)
 {
-	if (!p || !rgb_host)
-		return SCOPE_EINVAL;
 	scope_ctx *ctx = p->ctx;
-	SCOPE_ENTER(ctx);
-	if (st)
-		return st;
-	if ((uint64_t)p->cfg.width * 4 > linesize)
-		return fail(ctx, SCOPE_EINVAL, "linesize < 4*width", hipSuccess);
-	if (p->submitted - p->collected >= p->cfg.depth)
-		return SCOPE_EAGAIN;
-	scope_pipe_slot *s = &p->slot[p->submitted % p->cfg.depth];
+	int st = SCOPE_OK;
 	const uint32_t w = p->rw, h = p->rh;
 	const uint32_t dev_flags = SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE | SCOPE_ASYNC;
 
@@ -1323,7 +1444,8 @@ int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
 				      hipMemcpyHostToDevice, p->up));
 	HIP_TRY(ctx, hipEventRecord(s->uploaded, p->up));
 
-	/* compute stream: three reductions of the same HBM-resident plane, K0 fused where YUV is needed */
+	/* compute stream: the scopes of the same HBM-resident plane, K0 fused where Y'CbCr is needed: the vectorscope
+	 * reads it once, waveform and histogram share a second read (the histogram rides on the waveform's pass) */
 	HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->uploaded, 0));
 	const uint8_t *plane[1] = {s->dev_rgb};
 	uint32_t pitch = (uint32_t)p->pitch;
@@ -1338,14 +1460,17 @@ int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
 		if (st)
 			return st;
 	}
+	bool his_done = false;
 	if (p->wvs_bytes) {
-		const uint32_t c = p->cfg.wvs_components;
-		st = run_waveform(ctx, plane, 1, pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace,
-				  dev_flags, s->dev_wvs);
+		const uint32_t c = p->cfg.wvs_components, hc = p->cfg.his_components;
+		/* the histogram rides on the waveform's pass when it counts the same kind of plane and no other channels */
+		his_done = p->his_bytes && ((c & 0x07u) != 0) == ((hc & 0x07u) != 0) && (channel_mask(hc) & ~channel_mask(c)) == 0;
+		st = run_waveform(ctx, plane, 1, pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace, dev_flags, s->dev_wvs,
+				  his_done ? s->dev_his : NULL, channel_mask(hc));
 		if (st)
 			return st;
 	}
-	if (p->his_bytes) {
+	if (p->his_bytes && !his_done) {
 		const uint32_t c = p->cfg.his_components;
 		st = run_histogram(ctx, plane, 1, pitch, w, h, channel_mask(c), !(c & 0x07u), p->cfg.colorspace,
 				   dev_flags, s->dev_his);
@@ -1356,7 +1481,7 @@ int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
 
 	/* download stream: the small tables into pinned memory */
 	HIP_TRY(ctx, hipStreamWaitEvent(p->down, s->computed, 0));
-	uint8_t *dst = s->host_tables;
+	uint8_t *dst = p->host_tables[s->host_index];
 	if (p->vss_bytes)
 		HIP_TRY(ctx, hipMemcpyAsync(dst, s->dev_vss, p->vss_bytes, hipMemcpyDeviceToHost, p->down));
 	if (p->wvs_bytes)
@@ -1365,6 +1490,37 @@ int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
 		HIP_TRY(ctx, hipMemcpyAsync(dst + p->vss_bytes + p->wvs_bytes, s->dev_his, p->his_bytes, hipMemcpyDeviceToHost,
 					    p->down));
 	HIP_TRY(ctx, hipEventRecord(s->downloaded, p->down));
+	return SCOPE_OK;
+}
+
+} // namespace
+
+extern "C" int scope_pipe_submit(scope_pipe *p, const uint8_t *rgb_host, uint32_t linesize)
+{
+	if (!p || !rgb_host)
+		return SCOPE_EINVAL;
+	scope_ctx *ctx = p->ctx;
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if ((uint64_t)p->cfg.width * 4 > linesize)
+		return fail(ctx, SCOPE_EINVAL, "linesize < 4*width", hipSuccess);
+	if (p->submitted - p->collected >= p->cfg.depth)
+		return SCOPE_EAGAIN;
+	scope_pipe_slot *s = &p->slot[p->submitted % p->cfg.depth];
+	s->host_index = (uint32_t)(p->submitted % (p->cfg.depth + 1));
+	st = pipe_enqueue(p, s, rgb_host, linesize);
+	if (st) {
+		/* roll back: whatever was queued for this frame drains (its events may be half recorded, its buffers half
+		 * written), and the slot is NOT taken -- the next submit starts it from scratch and collect never sees it */
+		char keep[sizeof ctx->err];
+		memcpy(keep, ctx->err, sizeof keep);
+		(void)hipStreamSynchronize(p->up);
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipStreamSynchronize(p->down);
+		memcpy(ctx->err, keep, sizeof keep);
+		return st;
+	}
 	p->submitted++;
 	return SCOPE_OK;
 }
@@ -1381,14 +1537,130 @@ int scope_pipe_collect(scope_pipe *p, const uint8_t **vectorscope, const uint8_t
 		return SCOPE_EAGAIN;
 	scope_pipe_slot *s = &p->slot[p->collected % p->cfg.depth];
 	HIP_TRY(ctx, hipEventSynchronize(s->downloaded));
+	const uint8_t *tables = p->host_tables[s->host_index];
 	if (vectorscope)
-		*vectorscope = p->vss_bytes ? s->host_tables : NULL;
+		*vectorscope = p->vss_bytes ? tables : NULL;
 	if (waveform)
-		*waveform = p->wvs_bytes ? s->host_tables + p->vss_bytes : NULL;
+		*waveform = p->wvs_bytes ? tables + p->vss_bytes : NULL;
 	if (his_counts)
-		*his_counts = p->his_bytes ? (const uint32_t *)(s->host_tables + p->vss_bytes + p->wvs_bytes) : NULL;
+		*his_counts = p->his_bytes ? (const uint32_t *)(tables + p->vss_bytes + p->wvs_bytes) : NULL;
 	p->collected++;
 	return SCOPE_OK;
+}
+
+} /* extern "C" */
+
+/* ---- multi-GPU: the table sum as a C call -------------------------------------------------------------------------
+ * RCCL is bound at run time (dlopen of the librccl already in the process, else the ROCm one), so a host that never
+ * sums tables across GPUs does not load it and the library has no link-time dependency on it.  The five entry points
+ * are declared here exactly as <rccl/rccl.h> does (ncclUniqueId is a 128-byte struct passed by value). */
+namespace {
+
+struct rccl_id {
+	char internal[128];
+};
+struct rccl_api {
+	void *handle;
+	int (*get_unique_id)(rccl_id *);
+	int (*comm_init_rank)(void **comm, int nranks, rccl_id id, int rank);
+	int (*comm_destroy)(void *comm);
+	int (*all_reduce)(const void *send, void *recv, size_t count, int datatype, int op, void *comm, hipStream_t stream);
+	const char *(*error_string)(int);
+};
+
+const rccl_api *rccl()
+{
+	static std::mutex mu;
+	static rccl_api api;
+	static bool tried = false;
+	std::lock_guard<std::mutex> lock(mu);
+	if (!tried) {
+		tried = true;
+		const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+		for (const char *n : names) {
+			api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+			if (api.handle)
+				break;
+		}
+		if (api.handle) {
+			api.get_unique_id = (int (*)(rccl_id *))dlsym(api.handle, "ncclGetUniqueId");
+			api.comm_init_rank = (int (*)(void **, int, rccl_id, int))dlsym(api.handle, "ncclCommInitRank");
+			api.comm_destroy = (int (*)(void *))dlsym(api.handle, "ncclCommDestroy");
+			api.all_reduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.handle, "ncclAllReduce");
+			api.error_string = (const char *(*)(int))dlsym(api.handle, "ncclGetErrorString");
+			if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_reduce)
+				api.handle = NULL;
+		}
+	}
+	return api.handle ? &api : NULL;
+}
+
+int rccl_fail(scope_ctx *ctx, const char *what, int rc)
+{
+	const rccl_api *r = rccl();
+	if (ctx)
+		snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, (r && r->error_string) ? r->error_string(rc) : "RCCL not loadable");
+	return SCOPE_EIO;
+}
+
+} // namespace
+
+extern "C" {
+
+int scope_rccl_unique_id(uint8_t id[SCOPE_RCCL_ID_BYTES])
+{
+	const rccl_api *r = rccl();
+	if (!r || !id)
+		return r ? SCOPE_EINVAL : SCOPE_ENODEV;
+	rccl_id u;
+	if (r->get_unique_id(&u) != 0)
+		return SCOPE_EIO;
+	memcpy(id, u.internal, sizeof u.internal);
+	return SCOPE_OK;
+}
+
+int scope_rccl_comm_create(scope_ctx *ctx, const uint8_t id[SCOPE_RCCL_ID_BYTES], int n_ranks, int rank, void **comm)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if (!id || !comm || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+		return fail(ctx, SCOPE_EINVAL, "scope_rccl_comm_create", hipSuccess);
+	if (n_ranks > 257)
+		return fail(ctx, SCOPE_EINVAL, "more than 257 ranks: the packed 16-bit halves of the table sum could carry", hipSuccess);
+	const rccl_api *r = rccl();
+	if (!r)
+		return rccl_fail(ctx, "dlopen(librccl)", 0);
+	rccl_id u;
+	memcpy(u.internal, id, sizeof u.internal);
+	*comm = NULL;
+	const int rc = r->comm_init_rank(comm, n_ranks, u, rank); /* binds to the current device = the context's */
+	return rc ? rccl_fail(ctx, "ncclCommInitRank", rc) : SCOPE_OK;
+}
+
+int scope_rccl_comm_destroy(void *comm)
+{
+	const rccl_api *r = rccl();
+	if (!r || !comm)
+		return SCOPE_EINVAL;
+	return r->comm_destroy(comm) ? SCOPE_EIO : SCOPE_OK;
+}
+
+int scope_table_allreduce(scope_ctx *ctx, void *rccl_comm, uint32_t *words, uint64_t n_words)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if (!rccl_comm || !words)
+		return fail(ctx, SCOPE_EINVAL, "scope_table_allreduce: NULL argument", hipSuccess);
+	if (n_words == 0)
+		return SCOPE_OK;
+	const rccl_api *r = rccl();
+	if (!r)
+		return rccl_fail(ctx, "dlopen(librccl)", 0);
+	/* ncclUint32 = 3, ncclSum = 0; in place, on the context's stream (ordered behind the kernels that filled the table) */
+	const int rc = r->all_reduce(words, words, (size_t)n_words, 3, 0, rccl_comm, ctx->stream);
+	return rc ? rccl_fail(ctx, "ncclAllReduce", rc) : SCOPE_OK;
 }
 
 } /* extern "C" */

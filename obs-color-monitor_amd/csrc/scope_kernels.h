@@ -49,13 +49,15 @@ struct ScopeK0 {
 /* Tunables the host may flip for A/B runs (scope_ctx_set_option). */
 struct ScopeTuning {
 	int vss_merge;       /* 0 plain adds, 1|2 absorb mode always, 3 absorb mode by wave vote (default) */
-	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 1, 2 or 4 */
+	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 1, 2 or 4; 0 = by launch size */
 	int vss_fused_unroll; /* the same for the fused-K0 form (VALU-bound: a shallower pipeline is enough) */
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
-	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3 */
+	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3; -1 = by launch size */
 	int his_unroll;      /* 1, 2 or 4; more bytes in flight than ~32 KiB per CU LOWER the achieved bandwidth */
 	int vss_block, his_block; /* threads per workgroup (0 = SCOPE_BLOCK) */
-	int fold;            /* 1: histogram partials are summed by the last workgroup of a frame when they are few */
+	int fold;            /* 1: the slices of a histogram frame are combined inside the launch (atomics + last arrival); 0: partial
+			      * tables + scope_launch_sum_reduce */
+	int vss_sparse;      /* 1: vectorscope partials are written sparse (flagged 16-bin groups only) */
 	int wvs_per_cu;      /* cap on persistent waveform workgroups per CU (0 = as many as fit); 1 keeps ~32 KiB of
 			      * loads in flight per CU, which is what the HBM likes best (+5 % for 1-2 channels) */
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
@@ -73,17 +75,22 @@ hipError_t scope_kernels_init(void);
 hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *dst, uint32_t dst_linesize,
 			   uint32_t width, uint32_t height, int colorspace, hipStream_t st);
 
-/* K1.  dst = uint8[n_frames][slices][65536]; with slices > 1 the tables are clamped partials to
- * be combined by scope_launch_sat_reduce.  fuse_k0: planes are RGB, U/V computed in-kernel. */
+/* K1.  dst = uint8[n_frames][slices][65536].  pmask == NULL: complete clamped tables (final when slices == 1, else
+ * partials for scope_launch_sat_reduce).  pmask = uint8[n_frames][slices][scope_vss_mask_block(tn)]: SPARSE partials
+ * -- only the 16-bin groups holding a count are written and flagged -- for scope_launch_sat_reduce_sparse.
+ * fuse_k0: planes are RGB, U/V computed in-kernel. */
 hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
-			    const ScopeTuning &tn, hipStream_t st);
+			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st);
+/* Threads per workgroup of the vectorscope launch = bytes per sparse-partial mask; 0: this tuning cannot write masks. */
+uint32_t scope_vss_mask_block(const ScopeTuning &tn);
 
-/* K3.  dst = uint32[n_frames][slices][1024]; with slices > 1 the partials are summed either by the kernel itself
- * -- folded = uint32[n_frames][1024] and tickets = uint32[n_frames], zero before the first launch and left zero by
- * every launch: the last workgroup of a frame does it -- or, with folded == NULL, by scope_launch_sum_reduce.
+/* K3.  With acc == NULL (or slices == 1) dst = uint32[n_frames][slices][1024]: partials for scope_launch_sum_reduce,
+ * or the final tables when slices == 1.  With acc = uint32[n_frames][1024] and tickets = uint32[n_frames] -- both zero
+ * before the first launch and left zero by every launch -- the slices of a frame are combined inside the launch
+ * (device-scope atomic adds, the last workgroup of a frame moves the sums out) and dst = uint32[n_frames][1024].
  * chmask bit c = count byte c of the texel (bit0 -> slot 2, bit1 -> slot 1, bit2 -> slot 0). */
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint32_t *dst, uint32_t *folded, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st);
+			    uint32_t *dst, uint32_t *acc, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st);
 
 /* Capture pre-steps: dst(i, j) = texel at src + j*row_pitch + i*col_step*4, i < cx, j < cy (the caller folds
  * scale and ROI origin into src / row_pitch / col_step).  All pointers and pitches 4-byte aligned. */
@@ -91,14 +98,27 @@ hipError_t scope_launch_stage(const uint8_t *src, uint64_t row_pitch, uint32_t c
 			      uint8_t *dst, uint32_t dst_linesize, hipStream_t st);
 
 /* K2.  dst = uint8[n_frames][bands][256][width][4]; combine with scope_launch_sat_reduce when
- * bands > 1.  chmask as above (bit c -> byte c of the output texel). */
+ * bands > 1.  chmask as above (bit c -> byte c of the output texel).
+ * his != NULL: the same pass also leaves the K3 count tables of the frames in his->out (uint32[n_frames][256][4], the
+ * layout scope_launch_his writes), for the channels his->chmask selects among those of chmask -- no second read of
+ * the planes.  acc = uint32[SCOPE_MAX_FRAMES][1024] and tickets = uint32[SCOPE_MAX_FRAMES] are zero before the first
+ * launch and left zero by every launch. */
+struct ScopeHisSink {
+	uint32_t *acc, *tickets, *out;
+	uint32_t chmask;
+};
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st);
+			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st,
+			    const ScopeHisSink *his = NULL);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
  * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,
 				   int packed16, hipStream_t st);
+
+/* The same over sparse partials: part / pmask as scope_launch_vss wrote them with `mask_block` threads per workgroup. */
+hipError_t scope_launch_sat_reduce_sparse(const uint8_t *part, const uint8_t *pmask, uint8_t *out, uint32_t n_frames,
+					  uint32_t slices, uint32_t mask_block, int packed16, hipStream_t st);
 
 hipError_t scope_launch_sum_reduce(const uint32_t *part, uint32_t *out, uint32_t n_frames, uint32_t slices,
 				   uint32_t len, hipStream_t st);

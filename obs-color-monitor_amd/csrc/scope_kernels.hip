@@ -215,7 +215,9 @@ ScopeK0 scope_k0_matrix(int colorspace)
  *
  * Loads are double-buffered: the U loads of batch b+1 are in flight while batch b is binned, and
  * `before_batch` (uniform; may contain barriers) runs between issue and use, so the vectorscope's
- * clamp passes do not drain the memory pipeline.  `fn(v, ok)` gets a whole batch: U cells per lane
+ * clamp passes do not drain the memory pipeline.  `after_first_issue` (uniform; may contain barriers) runs once, with
+ * the first batch in flight: the kernels zero their LDS table there, under the HBM latency of the first loads instead
+ * of in front of it (0.7 us of a one-frame launch).  `fn(v, ok)` gets a whole batch: U cells per lane
  * and which of them are real.  Row pitch is honoured.
  * ---------------------------------------------------------------------------------------- */
 
@@ -236,21 +238,21 @@ template <bool NT, typename V> __device__ __forceinline__ V scope_load(const V *
 	return *p;
 }
 
-/* "Last workgroup reduces": every workgroup of a group (the slices of one frame) calls this after writing its
- * partial table to global memory; it returns true, in every thread, for the workgroup that arrives last, which
- * may then read all the partials.  The caller resets the ticket when done, so a zero-initialised ticket array
- * serves every launch on the stream.
+/* "Last workgroup finishes the frame": every workgroup of a group (the slices of one frame) calls this after it has
+ * added its table to the frame's accumulator with agent-scope atomics; it returns true, in every thread, for the
+ * workgroup that arrives last, which may then read (exchange) the accumulator.  The caller resets the ticket when
+ * done, so a zero-initialised ticket array serves every launch on the stream.
  *
- * No fences: an agent-scope release/acquire pair costs a write-back plus an invalidate of the XCD's whole L2
- * (buffer_wbl2 / buffer_inv) per workgroup, which doubled the run time of the vectorscope kernel when tried.
- * Instead the partial tables are written and read with agent-scope accesses (sc1: they go through to the
- * device-coherent level, nothing stays dirty or stale in a per-XCD L2), the writer waits for its stores to be
- * acknowledged (vmcnt(0)) before it takes a ticket, and the ticket is an agent-scope atomic.  Such accesses are
- * slow, so this only pays for small tables and few partials: the histogram's 4 KiB tables (+2.4 % on the batch);
- * the vectorscope's 64 KiB tables lost 7 % this way and keep their reduce kernel. */
+ * This is the "agent atomics on both sides" hand-off of MI355X_MICROARCH.md (Workgroup dispatch, XCD placement &
+ * inter-workgroup visibility): the payload is written AND read with device-scope atomic read-modify-writes, which are
+ * performed at the memory side, below the per-XCD L2s, so no cache can hold a stale or an unwritten copy and no
+ * L2 write-back / invalidate (buffer_wbl2 / buffer_inv, ~1.7 us each) is needed.  Every wave waits until its atomics
+ * have been acknowledged (the asm wait: hipcc may drop a builtin one) before the barrier, and one lane then takes an
+ * agent-scope ticket.  Round 1 handed over sc1-stored partial tables here; that form is gone.
+ * tests: test_histogram_in_kernel_combine_stress (thousands of launches, every count checked). */
 __device__ __forceinline__ bool scope_last_arrival(u32 *ticket, u32 group_size, u32 *lds_flag)
 {
-	__builtin_amdgcn_s_waitcnt(0); /* this thread's partial-table stores have been acknowledged */
+	scope_drain_vmem(); /* this wave's atomics have been performed */
 	__syncthreads();
 	if (threadIdx.x == 0)
 		*lds_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == group_size - 1u;
@@ -287,9 +289,9 @@ __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
 	return (u32)(((u64)total * s) / S);
 }
 
-template <int VECW, int U, bool NT, bool CONTIG, typename Hook, typename F>
+template <int VECW, int U, bool NT, bool CONTIG, typename Pro, typename Hook, typename F>
 __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 c0, u32 c1,
-					     u32 glog2, Hook &&before_batch, F &&fn)
+					     u32 glog2, Pro &&after_first_issue, Hook &&before_batch, F &&fn)
 {
 	typedef typename ScopeVec<VECW>::type vec_t;
 	if (c0 >= c1)
@@ -364,6 +366,7 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	 * so on every path exactly U younger loads are outstanding when a batch is binned and the
 	 * compiler can wait with vmcnt(U) instead of draining the queue. */
 	SCOPE_ISSUE(va, oka);
+	after_first_issue();
 	for (u32 b = 0; b < batches; b += 2) {
 		SCOPE_ISSUE(vb, okb);
 		SCOPE_BIN(va, oka);
@@ -496,9 +499,10 @@ __device__ __forceinline__ void vss_clamp_pass(u32 *tab)
 	}
 }
 
-template <int VECW, int U, bool NT, int MERGE, bool FUSE, int HASH>
+template <int VECW, int U, bool NT, int MERGE, bool FUSE, int HASH, typename Pro>
 __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
-					   u32 slice, u32 slices, u32 glog2, const ScopeK0 &k0, u32 &since_clamp, VssLane &st)
+					   u32 slice, u32 slices, u32 glog2, const ScopeK0 &k0, u32 &since_clamp, VssLane &st,
+					   Pro &&prologue)
 {
 	if (ncols == 0)
 		return;
@@ -565,11 +569,11 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 					       }
 		};
 		if (linesize == ncols * 16u) /* uniform: planes whose rows carry no padding */
-			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, bin_cells);
+			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_cells);
 		else
-			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch, bin_cells);
+			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_cells);
 	} else {
-		scope_stream<1, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, epoch,
+		scope_stream<1, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch,
 				       [&](const u32(&q)[U], const bool(&ok)[U]) {
 #pragma unroll
 					       for (int k = 0; k < U; k++) {
@@ -585,10 +589,19 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 
 /* grid = n_frames * slices workgroups; unit = frame * slices + slice.
  * Region A: ncols_a cells of 4 pixels from byte 0 of each row (16-byte aligned rows only);
- * region B: ncols_b single pixels from byte xbyte_b (row tails, or whole rows when unaligned). */
+ * region B: ncols_b single pixels from byte xbyte_b (row tails, or whole rows when unaligned).
+ *
+ * pmask == NULL: dst[unit] is a complete clamped table (the final one when slices == 1).
+ * pmask != NULL: a SPARSE partial -- only the 16-bin groups that hold a count are written, and thread t records which
+ * of its groups g = t + k * blockDim.x (k < 8: blockDim.x >= 512) it wrote as bit k of its mask byte (layout below).
+ * The slices of a one-frame launch see 1/256 of the picture each: on real video most of a slice's table is empty, and
+ * even uniform noise reaches only the 57 % of the CbCr square that RGB maps to (scope_sat_reduce_sparse_kernel
+ * reads back only what was written).  Measured alternatives -- every workgroup adding its table to one accumulator
+ * with device-scope atomics (35 us for 256 dense tables: memory-side atomics run at ~7.5 G cache lines/s and count
+ * twice the partials' bytes) -- are in profiles/round2/flush_microbench_r2a.txt. */
 template <int U, bool NT, int MERGE, bool FUSE, int HASH>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
-							       u32 xbyte_b, u32 glog2, ScopeK0 k0, uint8_t *dst)
+							       u32 xbyte_b, u32 glog2, ScopeK0 k0, uint8_t *dst, uint8_t *pmask)
 {
 	u32 *tab = scope_lds;
 	const u32 unit = blockIdx.x;
@@ -596,18 +609,26 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	const u32 slice = unit - frame * slices;
 	const uint8_t *plane = fs.plane[frame];
 
-	const uint4 zero = make_uint4(0, 0, 0, 0);
-	for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4)
-		*(uint4 *)&tab[i] = zero;
-	__syncthreads();
+	/* the table is zeroed with the first batch of loads already in flight (scope_stream) */
+	bool zeroed = false; /* uniform */
+	auto zero_table = [&]() {
+		if (zeroed)
+			return;
+		zeroed = true;
+		const uint4 zero = make_uint4(0, 0, 0, 0);
+		for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4)
+			*(uint4 *)&tab[i] = zero;
+		__syncthreads();
+	};
 
 	SCOPE_STAMP(0);
 	u32 since_clamp = 0;
 	VssLane st = {0xffffffffu, 0};
 	vss_region<4, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, glog2, k0,
-						 since_clamp, st);
+						 since_clamp, st, zero_table);
 	vss_region<1, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, glog2,
-						 k0, since_clamp, st);
+						 k0, since_clamp, st, zero_table);
+	zero_table(); /* a slice without pixels */
 	vss_flush_lane<HASH>(tab, st);
 	__syncthreads();
 	SCOPE_STAMP(1);
@@ -615,13 +636,31 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	/* flush: 16 consecutive bins of one row per lane per step = 8 table words, which the swizzle (a multiple of eight
 	 * words) leaves contiguous: two 16-byte LDS reads, one coalesced 16-byte store */
 	uint4 *out = (uint4 *)(dst + (size_t)unit * SCOPE_VSS_BINS);
-	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x) {
+	/* sparse partials are stored by block of 16 groups (256 bins = one table row), the slices of a frame side by side:
+	 * group g of slice s is cell ((frame * 256 + g / 16) * slices + s) * 16 + g % 16, so that what one workgroup of
+	 * the reduction reads -- a row of every slice -- is one contiguous run instead of 256 B out of every 64 KiB */
+	uint4 *outs = (uint4 *)dst + ((size_t)frame * 256u * slices + slice) * 16u;
+	u32 wrote = 0, k = 0;
+	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
 		const u32 row = 255u - (g >> 4); /* table row v of output row g >> 4 */
 		const u32 w0 = (row << 7) + (((g & 15u) << 3) ^ (HASH == 1 ? 0u : ((row & 15u) << 3)));
 		const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
-		out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
-				    vss_clamp_pair(hi.z, hi.w));
+		if (!pmask) {
+			out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
+					    vss_clamp_pair(hi.z, hi.w));
+		} else if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0) {
+			/* streaming store: a partial is read once, by other CUs; leaving it dirty in this XCD's L2 only
+			 * moves the write-back to the end of the kernel */
+			const scope_v4 t = {vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
+					    vss_clamp_pair(hi.z, hi.w)};
+			__builtin_nontemporal_store(t, (scope_v4 *)outs + ((size_t)(g >> 4) * slices * 16u + (g & 15u)));
+			wrote |= 1u << k;
+		}
 	}
+	/* the masks likewise: byte t of slice s is ((frame * blockDim / 16 + t / 16) * slices + s) * 16 + t % 16 */
+	if (pmask)
+		pmask[(((size_t)frame * (blockDim.x >> 4) + (threadIdx.x >> 4)) * slices + slice) * 16u + (threadIdx.x & 15u)] =
+			(uint8_t)wrote;
 	SCOPE_STAMP(2);
 }
 
@@ -647,9 +686,9 @@ template <bool FUSE> __device__ __forceinline__ void his_add(u32 *tab, u32 px, u
 		atomicAdd(&tab[((2u * 256u + ((px >> 16) & 0xffu)) << 5) + rep], 1u);
 }
 
-template <int VECW, int U, bool NT, bool FUSE>
+template <int VECW, int U, bool NT, bool FUSE, typename Pro>
 __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
-					   u32 slice, u32 slices, u32 chmask, const ScopeK0 &k0)
+					   u32 slice, u32 slices, u32 chmask, const ScopeK0 &k0, Pro &&prologue)
 {
 	if (ncols == 0)
 		return;
@@ -673,11 +712,11 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 					       }
 		};
 		if (linesize == ncols * 16u) /* uniform: rows without padding */
-			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing, bin_cells);
+			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
 		else
-			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing, bin_cells);
+			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
 	} else {
-		scope_stream<1, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, 0, nothing,
+		scope_stream<1, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing,
 				       [&](const u32(&q)[U], const bool(&ok)[U]) {
 #pragma unroll
 					       for (int k = 0; k < U; k++) {
@@ -691,9 +730,15 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 	}
 }
 
+/* acc == NULL: dst[unit] receives this workgroup's counts (the final table when slices == 1, else a partial for
+ * scope_sum_reduce_kernel).  acc != NULL (slices > 1): the slices of a frame are combined inside the launch -- every
+ * workgroup adds its non-zero counts to acc[frame] with device-scope atomics (at most 768 per workgroup: 12 wave
+ * instructions, 0.2 us for a whole one-frame launch of 256 workgroups), and the one that arrives last moves the sums
+ * to dst[frame] with atomic exchanges, which also leaves the accumulator zero for the next launch
+ * (scope_last_arrival).  One launch, no partial tables, whatever the number of slices. */
 template <int U, bool NT, bool FUSE>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
-							       u32 xbyte_b, u32 chmask, ScopeK0 k0, u32 *dst, u32 *folded, u32 *tickets)
+							       u32 xbyte_b, u32 chmask, ScopeK0 k0, u32 *dst, u32 *acc, u32 *tickets)
 {
 	u32 *tab = scope_lds;
 	const u32 unit = blockIdx.x;
@@ -701,17 +746,24 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
 	const u32 slice = unit - frame * slices;
 	const uint8_t *plane = fs.plane[frame];
 
-	const uint4 zero = make_uint4(0, 0, 0, 0);
-	for (u32 i = threadIdx.x * 4; i < HIS_WORDS; i += blockDim.x * 4)
-		*(uint4 *)&tab[i] = zero;
-	__syncthreads();
+	bool zeroed = false; /* uniform */
+	auto zero_table = [&]() {
+		if (zeroed)
+			return;
+		zeroed = true;
+		const uint4 zero = make_uint4(0, 0, 0, 0);
+		for (u32 i = threadIdx.x * 4; i < HIS_WORDS; i += blockDim.x * 4)
+			*(uint4 *)&tab[i] = zero;
+		__syncthreads();
+	};
 
-	his_region<4, U, NT, FUSE>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, chmask, k0);
-	his_region<1, U, NT, FUSE>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, chmask, k0);
+	his_region<4, U, NT, FUSE>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, chmask, k0, zero_table);
+	his_region<1, U, NT, FUSE>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, chmask, k0, zero_table);
+	zero_table();
 	__syncthreads();
 
 	/* fold the 32 replicas; lane t starts at replica t so a lane group reads 32 banks */
-	u32 *out = dst + (size_t)unit * SCOPE_HIS_WORDS;
+	u32 *out = acc ? acc + (size_t)frame * SCOPE_HIS_WORDS : dst + (size_t)unit * SCOPE_HIS_WORDS;
 	for (u32 t = threadIdx.x; t < SCOPE_HIS_WORDS; t += blockDim.x) {
 		const u32 value = t >> 2, slot = t & 3u;
 		u32 sum = 0;
@@ -721,23 +773,18 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
 			for (u32 j = 0; j < 32; j++)
 				sum += tab[base + ((j + value) & 31u)];
 		}
-		if (folded)
-			__hip_atomic_store(&out[t], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		else
+		if (!acc)
 			out[t] = sum;
+		else if (sum)
+			__hip_atomic_fetch_add(&out[t], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 
-	/* folded != NULL: the last workgroup of a frame sums the frame's partial count tables */
-	if (folded && scope_last_arrival(&tickets[frame], slices, &tab[0])) {
-		const u32 *part = dst + (size_t)frame * slices * SCOPE_HIS_WORDS;
-		for (u32 t = threadIdx.x; t < SCOPE_HIS_WORDS; t += blockDim.x) {
-			u32 sum = 0;
-			for (u32 sl = 0; sl < slices; sl++)
-				sum += __hip_atomic_load(&part[(size_t)sl * SCOPE_HIS_WORDS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			folded[(size_t)frame * SCOPE_HIS_WORDS + t] = sum;
-		}
+	if (acc && scope_last_arrival(&tickets[frame], slices, &tab[0])) {
+		for (u32 t = threadIdx.x; t < SCOPE_HIS_WORDS; t += blockDim.x)
+			dst[(size_t)frame * SCOPE_HIS_WORDS + t] =
+				__hip_atomic_exchange(&out[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (threadIdx.x == 0)
-			tickets[frame] = 0;
+			__hip_atomic_store(&tickets[frame], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
@@ -817,9 +864,24 @@ __device__ __forceinline__ WvsUnit wvs_unit(const ScopeFrameSet &fs, u32 unit, u
  * table is flushed and stay in flight across the flush and the zero-fill -- so the memory pipeline does
  * not drain at every unit boundary (a unit is only ~0.5 MB).  Batch n of a unit = row pairs 4n..4n+3;
  * wave w takes batches w, w + nwaves, ... */
-template <int CH, bool FUSE, bool WIDE>
+/* HIS: the histogram of the same channels comes out of this pass for nothing.  A strip's table IS a histogram per
+ * column -- exact 16-bit counts until the flush clamps them -- so the flush, which reads every counter anyway, also
+ * adds up each value's 64 columns (the same texels pass the same alpha test in both loops, src/waveform.c:247-248 and
+ * src/histogram.c:386-387), a 16-lane row sum hands the totals to LDS, and 12 wave instructions per unit add them to
+ * the frame's accumulator his.acc[frame][slot][value] with device-scope atomics.  The workgroup that finishes a
+ * frame's last unit (ticket) moves the sums to his.out[frame][value][slot] and leaves accumulator and ticket zero.
+ * No LDS atomic per pixel is added: the dock's waveform + histogram cost one read of the plane (src/roi.c:329-341
+ * hands one staged surface to every scope). */
+struct ScopeWvsHis {
+	u32 *acc;     /* [SCOPE_MAX_FRAMES][4][256], zero between launches */
+	u32 *tickets; /* [SCOPE_MAX_FRAMES], zero between launches */
+	u32 *out;     /* [n_frames][256][4]: slots R,G,B,unused as scope_his_kernel writes them */
+	u32 chmask;   /* channels the caller wants counted (a subset of CH); the others stay zero */
+};
+
+template <int CH, bool FUSE, bool WIDE, bool HIS>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, ScopeK0 k0,
-							       uint8_t *dst)
+							       uint8_t *dst, ScopeWvsHis his)
 {
 	constexpr int U = WVS_U;
 	constexpr u32 slot0 = 0, slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1), nch = slot2 + ((CH >> 2) & 1);
@@ -909,7 +971,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 		const bool live0 = x0 < W, live1 = x0 + 1u < W;
 
 		const uint4 zero = make_uint4(0, 0, 0, 0);
-		for (u32 i = threadIdx.x * 4; i < nch * WVS_CH_WORDS; i += blockDim.x * 4)
+		for (u32 i = threadIdx.x * 4; i < nch * WVS_CH_WORDS + (HIS ? 768u : 0u); i += blockDim.x * 4)
 			*(uint4 *)&tab[i] = zero;
 		__syncthreads();
 
@@ -947,14 +1009,18 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 		 * Streaming (nt) stores: the table is not read again here and must not displace the frames in L2. */
 		uint8_t *table = dst + ((size_t)ub.frame * bands + ub.band) * ((size_t)SCOPE_WVS_ROWS * W * 4);
 		const u32 xg = threadIdx.x & 15u; /* columns 4*xg .. 4*xg+3 of the strip = words 2*xg, 2*xg+1 */
-		auto gather = [&](u32 value, u32 g, u32(&o)[4]) {
+		u32 *hsum = tab + nch * WVS_CH_WORDS; /* HIS: [3 slots][256 values] totals of this unit */
+		/* n[c] = this lane's four columns of channel slot c added up (HIS) */
+		auto gather = [&](u32 value, u32 g, u32(&o)[4], u32(&n)[3]) {
 			o[0] = o[1] = o[2] = o[3] = 0;
+			n[0] = n[1] = n[2] = 0;
 			if (CH & 1) {
 				const uint2 c = *(const uint2 *)&tab[slot0 * WVS_CH_WORDS + (value << 5) + 2u * g];
 				o[0] |= min(c.x & 0xffffu, 255u);
 				o[1] |= min(c.x >> 16, 255u);
 				o[2] |= min(c.y & 0xffffu, 255u);
 				o[3] |= min(c.y >> 16, 255u);
+				n[0] = (c.x & 0xffffu) + (c.x >> 16) + (c.y & 0xffffu) + (c.y >> 16);
 			}
 			if (CH & 2) {
 				const uint2 c = *(const uint2 *)&tab[slot1 * WVS_CH_WORDS + (value << 5) + 2u * g];
@@ -962,6 +1028,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 				o[1] |= min(c.x >> 16, 255u) << 8;
 				o[2] |= min(c.y & 0xffffu, 255u) << 8;
 				o[3] |= min(c.y >> 16, 255u) << 8;
+				n[1] = (c.x & 0xffffu) + (c.x >> 16) + (c.y & 0xffffu) + (c.y >> 16);
 			}
 			if (CH & 4) {
 				const uint2 c = *(const uint2 *)&tab[slot2 * WVS_CH_WORDS + (value << 5) + 2u * g];
@@ -969,7 +1036,19 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 				o[1] |= min(c.x >> 16, 255u) << 16;
 				o[2] |= min(c.y & 0xffffu, 255u) << 16;
 				o[3] |= min(c.y >> 16, 255u) << 16;
+				n[2] = (c.x & 0xffffu) + (c.x >> 16) + (c.y & 0xffffu) + (c.y >> 16);
 			}
+		};
+		/* the 16 lanes that share `value` (one DPP row) add their column sums; one lane per row and channel hands the
+		 * total to LDS (a value has one owner row per unit, the LDS add is an atomic only so that the one-lane waves
+		 * of the CPU emulation, where every lane is its own row, add up as well) */
+		auto tally = [&](u32 value, bool real, const u32(&n)[3]) {
+			if (CH & 1)
+				scope_row16_add(&hsum[0u * 256u + value], real ? n[0] : 0u);
+			if (CH & 2)
+				scope_row16_add(&hsum[1u * 256u + value], real ? n[1] : 0u);
+			if (CH & 4)
+				scope_row16_add(&hsum[2u * 256u + value], real ? n[2] : 0u);
 		};
 		if (WIDE) {
 			/* width % 4 == 0 and a 16-byte aligned table: a fixed number of unconditional vector stores per
@@ -981,23 +1060,49 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 #pragma unroll
 			for (u32 i = 0; i < 256u / (SCOPE_BLOCK / 16u); i++) {
 				const u32 value = (threadIdx.x >> 4) + i * (SCOPE_BLOCK / 16u);
-				u32 o[4];
-				gather(value, g, o);
+				u32 o[4], n[3];
+				gather(value, g, o, n);
 				const scope_v4 t = {o[0], o[1], o[2], o[3]};
 				__builtin_nontemporal_store(t, ocol + (size_t)(255u - value) * (W >> 2));
+				if (HIS)
+					tally(value, xg < groups, n); /* lanes past the right edge repeat a column group */
 			}
 		} else {
 			const u32 xo = xs + (xg << 2);
 			for (u32 value = threadIdx.x >> 4; value < 256u; value += blockDim.x >> 4) {
-				u32 o[4];
-				gather(value, xg, o);
+				u32 o[4], n[3];
+				gather(value, xg, o, n);
 				u32 *orow = (u32 *)(table + ((size_t)(255u - value) * W + xo) * 4);
 				for (u32 j = 0; j < 4; j++)
 					if (xo + j < W)
 						orow[j] = o[j];
+				if (HIS)
+					tally(value, true, n); /* columns past the right edge hold no counts */
 			}
 		}
 		__syncthreads(); /* the table is zeroed again next */
+		if (HIS) {
+			/* this unit's totals -> the frame's accumulator: slot-major, so that a wave instruction covers 64
+			 * consecutive words (two cache lines); channels the caller did not ask for are dropped here */
+			u32 *acc = his.acc + (size_t)ub.frame * SCOPE_HIS_WORDS;
+			for (u32 t = threadIdx.x; t < 768u; t += blockDim.x) {
+				const u32 byte = t >> 8; /* hsum is [texel byte][value]; histogram slot = 2 - byte (R,G,B) */
+				const u32 v = hsum[t];
+				if (v && ((CH & his.chmask) >> byte) & 1u)
+					__hip_atomic_fetch_add(&acc[(2u - byte) * 256u + (t & 255u)], v, __ATOMIC_RELAXED,
+							       __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (scope_last_arrival(&his.tickets[ub.frame], strips * bands, &hsum[0])) {
+				for (u32 t = threadIdx.x; t < SCOPE_HIS_WORDS; t += blockDim.x) {
+					const u32 value = t >> 2, slot = t & 3u; /* slot 0 = R = byte 2, 1 = G, 2 = B, 3 unused */
+					his.out[(size_t)ub.frame * SCOPE_HIS_WORDS + t] =
+						__hip_atomic_exchange(&acc[slot * 256u + value], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				if (threadIdx.x == 0)
+					__hip_atomic_store(&his.tickets[ub.frame], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			__syncthreads(); /* hsum[0] carried the verdict */
+		}
 	};
 	u32 unit_b = blockIdx.x; /* < total: the grid never exceeds the unit count */
 	run_unit(unit_b, std::false_type());
@@ -1096,6 +1201,101 @@ __global__ __launch_bounds__(256) void scope_sat_reduce_kernel(const uint8_t *pa
 	q[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+/* The same sum over SPARSE partials (scope_vss_kernel with pmask): only the 16-bin groups a slice has flagged are read.
+ * Parallel in both directions -- round 1's kernel gave a one-frame launch 16 workgroups that walked 256 partials one
+ * after the other (74 us): a workgroup of 256 threads takes gpw = 256 >> sl_log2 groups, and the 2^sl_log2 threads
+ * that share a group take every 2^sl_log2-th slice, four loads in flight each, and meet in LDS.  One frame of 256
+ * slices = 256 workgroups x 16 groups x 16 slice lanes.
+ * mask_block = blockDim.x of the producing launch: group g is bit g / mask_block of byte g % mask_block of a mask.
+ * grid = (4096 / gpw, n_frames); dynamic LDS = 8 KiB + 32 * gpw bytes. */
+__global__ __launch_bounds__(256) void scope_sat_reduce_sparse_kernel(const uint8_t *part, const uint8_t *pmask, uint8_t *out,
+									     u32 slices, u32 mask_block, u32 sl_log2, u32 packed16)
+{
+	const u32 frame = blockIdx.y;
+	const u32 gpw = 256u >> sl_log2, nsl = 1u << sl_log2;
+	const u32 gi = threadIdx.x & (gpw - 1u), sl = threadIdx.x >> (8u - sl_log2);
+	const u32 g = blockIdx.x * gpw + gi; /* < 4096 */
+	const u32 mbyte = g % mask_block, mbit = g / mask_block;
+	/* blocked layout (scope_vss_kernel): consecutive slices of one group are 16 cells (256 B) / 16 mask bytes apart */
+	const uint4 *p = (const uint4 *)part + ((u64)frame * 256u + (g >> 4)) * slices * 16u + (g & 15u);
+	const uint8_t *m = pmask + ((u64)frame * (mask_block >> 4) + (mbyte >> 4)) * slices * 16u + (mbyte & 15u);
+	u32 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* even bytes of the four words, then the odd ones: 16-bit lanes, <= 256 * 255 */
+	/* Two round trips to memory, not two per slice: a lane has at most 16 slices (256 / 16 slice lanes); all their mask
+	 * bytes are requested at once, then all the flagged groups (partials written by other XCDs come from the
+	 * Infinity Cache at ~1 us a trip -- with four loads in flight this kernel took 8.4 us for one frame). */
+	/* Every load is unconditional (a lane without a slice, or with an unflagged group, re-reads cell 0 of its own
+	 * column, which is always mapped, and drops the value): predicated loads made hipcc wait for each one inside
+	 * its branch -- 32 serial round trips, 10 us for one frame. */
+	u32 mb[16];
+	bool on[16];
+	uint4 q[16];
+#pragma unroll
+	for (u32 k = 0; k < 16; k++) {
+		const u32 s = sl + k * nsl;
+		mb[k] = m[(s < slices ? s : 0u) * 16u];
+	}
+#pragma unroll
+	for (u32 k = 0; k < 16; k++) {
+		const u32 s = sl + k * nsl;
+		on[k] = (s < slices) & (((mb[k] >> mbit) & 1u) != 0);
+		q[k] = p[(on[k] ? s : 0u) * 16u];
+	}
+#pragma unroll
+	for (u32 k = 0; k < 16; k++)
+		if (!on[k])
+			q[k] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+	for (u32 k = 0; k < 16; k++) {
+		acc[0] += q[k].x & 0x00ff00ffu;
+		acc[4] += (q[k].x >> 8) & 0x00ff00ffu;
+		acc[1] += q[k].y & 0x00ff00ffu;
+		acc[5] += (q[k].y >> 8) & 0x00ff00ffu;
+		acc[2] += q[k].z & 0x00ff00ffu;
+		acc[6] += (q[k].z >> 8) & 0x00ff00ffu;
+		acc[3] += q[k].w & 0x00ff00ffu;
+		acc[7] += (q[k].w >> 8) & 0x00ff00ffu;
+	}
+	if (sl_log2) { /* uniform: the slice lanes of a group meet in LDS */
+		u32 *red = scope_lds; /* [nsl][gpw][8] = 2048 words, then the totals [gpw][8] */
+#pragma unroll
+		for (u32 j = 0; j < 8; j++)
+			red[(sl * gpw + gi) * 8u + j] = acc[j];
+		__syncthreads();
+		u32 *tot = red + 2048;
+		for (u32 i = threadIdx.x; i < gpw * 8u; i += blockDim.x) { /* i = gi' * 8 + j */
+			u32 sum = 0;
+			for (u32 l = 0; l < nsl; l++)
+				sum += red[l * gpw * 8u + i];
+			tot[i] = sum;
+		}
+		__syncthreads();
+		if (threadIdx.x >= gpw)
+			return;
+#pragma unroll
+		for (u32 j = 0; j < 8; j++)
+			acc[j] = tot[threadIdx.x * 8u + j];
+	}
+	/* acc[j] / acc[4 + j]: bins 0,2 / 1,3 of word j.  Saturate and store. */
+	u32 b[16];
+#pragma unroll
+	for (u32 j = 0; j < 4; j++) {
+		b[4 * j + 0] = min(acc[j] & 0xffffu, 255u);
+		b[4 * j + 1] = min(acc[4 + j] & 0xffffu, 255u);
+		b[4 * j + 2] = min(acc[j] >> 16, 255u);
+		b[4 * j + 3] = min(acc[4 + j] >> 16, 255u);
+	}
+	if (!packed16) {
+		((uint4 *)out)[(u64)frame * (SCOPE_VSS_BINS / 16) + g] =
+			make_uint4(b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24, b[4] | b[5] << 8 | b[6] << 16 | b[7] << 24,
+				   b[8] | b[9] << 8 | b[10] << 16 | b[11] << 24, b[12] | b[13] << 8 | b[14] << 16 | b[15] << 24);
+		return;
+	}
+	/* the wire format of the multi-GPU sum: two bins per 32-bit word, lo | hi << 16 (scope_table_pack_u8_u16x2) */
+	uint4 *wire = (uint4 *)out + ((u64)frame * (SCOPE_VSS_BINS / 16) + g) * 2;
+	wire[0] = make_uint4(b[0] | b[1] << 16, b[2] | b[3] << 16, b[4] | b[5] << 16, b[6] | b[7] << 16);
+	wire[1] = make_uint4(b[8] | b[9] << 16, b[10] | b[11] << 16, b[12] | b[13] << 16, b[14] | b[15] << 16);
+}
+
 __global__ __launch_bounds__(256) void scope_sum_reduce_kernel(const u32 *part, u32 *out, u32 slices, u32 len)
 {
 	const u32 frame = blockIdx.y;
@@ -1172,7 +1372,8 @@ Regions split_regions(const ScopeFrameSet &fs)
 
 const u32 VSS_LDS_BYTES = VSS_WORDS * 4u;
 const u32 HIS_LDS_BYTES = HIS_WORDS * 4u;
-const u32 WVS_LDS_BYTES = 3u * WVS_CH_WORDS * 4u;
+const u32 WVS_HIS_LDS_BYTES = 768u * 4u; /* the histogram totals of one unit */
+const u32 WVS_LDS_BYTES = 3u * WVS_CH_WORDS * 4u + WVS_HIS_LDS_BYTES;
 
 /* Every kernel variant is launched through one of these; `allow` only raises the dynamic-LDS limit
  * (scope_kernels_init walks all variants once with allow = true). */
@@ -1181,7 +1382,7 @@ struct VssArgs {
 	u32 slices, glog2, block;
 	Regions rg;
 	ScopeK0 k0;
-	uint8_t *dst;
+	uint8_t *dst, *pmask;
 	hipStream_t st;
 };
 
@@ -1192,7 +1393,7 @@ template <int U, bool NT, int MERGE, bool FUSE, int HASH> hipError_t vss_variant
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)VSS_LDS_BYTES);
 	hipLaunchKernelGGL((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(a->block),
 			   VSS_LDS_BYTES, a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->k0,
-			   a->dst);
+			   a->dst, a->pmask);
 	return hipGetLastError();
 }
 
@@ -1230,7 +1431,7 @@ struct HisArgs {
 	u32 slices, chmask, block;
 	Regions rg;
 	ScopeK0 k0;
-	u32 *dst, *folded, *tickets;
+	u32 *dst, *acc, *tickets;
 	hipStream_t st;
 };
 
@@ -1240,7 +1441,7 @@ template <int U, bool NT, bool FUSE> hipError_t his_variant(const HisArgs *a)
 		return hipFuncSetAttribute((const void *)scope_his_kernel<U, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
 					   (int)HIS_LDS_BYTES);
 	hipLaunchKernelGGL((scope_his_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->slices), dim3(a->block), HIS_LDS_BYTES,
-			   a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->chmask, a->k0, a->dst, a->folded,
+			   a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->chmask, a->k0, a->dst, a->acc,
 			   a->tickets);
 	return hipGetLastError();
 }
@@ -1266,42 +1467,47 @@ struct WvsArgs {
 	u32 strips, bands, lds, grid;
 	ScopeK0 k0;
 	uint8_t *dst;
+	ScopeWvsHis his;
 	hipStream_t st;
 };
 
-template <int CH, bool FUSE, bool WIDE> hipError_t wvs_variant(const WvsArgs *a)
+template <int CH, bool FUSE, bool WIDE, bool HIS> hipError_t wvs_variant(const WvsArgs *a)
 {
 	if (!a)
-		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE, WIDE>,
+		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE, WIDE, HIS>,
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WVS_LDS_BYTES);
-	hipLaunchKernelGGL((scope_wvs_kernel<CH, FUSE, WIDE>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, *a->fs,
-			   a->strips, a->bands, a->k0, a->dst);
+	hipLaunchKernelGGL((scope_wvs_kernel<CH, FUSE, WIDE, HIS>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, *a->fs,
+			   a->strips, a->bands, a->k0, a->dst, a->his);
 	return hipGetLastError();
 }
-template <int CH> hipError_t wvs_pick_shape(int fuse, int wide, const WvsArgs *a)
+template <int CH, bool HIS> hipError_t wvs_pick_shape(int fuse, int wide, const WvsArgs *a)
 {
 	if (fuse)
-		return wide ? wvs_variant<CH, true, true>(a) : wvs_variant<CH, true, false>(a);
-	return wide ? wvs_variant<CH, false, true>(a) : wvs_variant<CH, false, false>(a);
+		return wide ? wvs_variant<CH, true, true, HIS>(a) : wvs_variant<CH, true, false, HIS>(a);
+	return wide ? wvs_variant<CH, false, true, HIS>(a) : wvs_variant<CH, false, false, HIS>(a);
 }
-hipError_t wvs_pick(u32 chmask, int fuse, int wide, const WvsArgs *a)
+template <bool HIS> hipError_t wvs_pick_ch(u32 chmask, int fuse, int wide, const WvsArgs *a)
 {
 	switch (chmask & 7u) {
 	case 1:
-		return wvs_pick_shape<1>(fuse, wide, a);
+		return wvs_pick_shape<1, HIS>(fuse, wide, a);
 	case 2:
-		return wvs_pick_shape<2>(fuse, wide, a);
+		return wvs_pick_shape<2, HIS>(fuse, wide, a);
 	case 3:
-		return wvs_pick_shape<3>(fuse, wide, a);
+		return wvs_pick_shape<3, HIS>(fuse, wide, a);
 	case 4:
-		return wvs_pick_shape<4>(fuse, wide, a);
+		return wvs_pick_shape<4, HIS>(fuse, wide, a);
 	case 5:
-		return wvs_pick_shape<5>(fuse, wide, a);
+		return wvs_pick_shape<5, HIS>(fuse, wide, a);
 	case 6:
-		return wvs_pick_shape<6>(fuse, wide, a);
+		return wvs_pick_shape<6, HIS>(fuse, wide, a);
 	default:
-		return wvs_pick_shape<7>(fuse, wide, a);
+		return wvs_pick_shape<7, HIS>(fuse, wide, a);
 	}
+}
+hipError_t wvs_pick(u32 chmask, int fuse, int wide, int with_his, const WvsArgs *a)
+{
+	return with_his ? wvs_pick_ch<true>(chmask, fuse, wide, a) : wvs_pick_ch<false>(chmask, fuse, wide, a);
 }
 
 } // namespace
@@ -1320,9 +1526,9 @@ hipError_t scope_kernels_init(void)
 					e = his_pick(unroll, nt, fuse, NULL);
 			}
 	for (u32 chmask = 1; chmask <= 7; chmask++)
-		for (int shape = 0; shape < 4; shape++)
+		for (int shape = 0; shape < 8; shape++)
 			if (e == hipSuccess)
-				e = wvs_pick(chmask, shape & 1, shape >> 1, NULL);
+				e = wvs_pick(chmask, shape & 1, (shape >> 1) & 1, shape >> 2, NULL);
 	return e;
 }
 
@@ -1369,27 +1575,41 @@ static u32 scope_block(int requested)
 	return b > SCOPE_BLOCK ? SCOPE_BLOCK : b;
 }
 
-hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
-			    const ScopeTuning &tn, hipStream_t st)
+uint32_t scope_vss_mask_block(const ScopeTuning &tn)
 {
-	u32 glog2 = tn.vss_groups_log2 < 0 ? 0u : (u32)tn.vss_groups_log2;
+	const u32 b = scope_block(tn.vss_block);
+	return b >= 512u ? b : 0u; /* a thread's groups must fit the 8 bits of its mask byte */
+}
+
+hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
+			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st)
+{
+	/* Small launches -- one to a dozen frames, >= 12 workgroups per frame -- give every workgroup well under a megabyte:
+	 * cutting that into 8 lane-group streams leaves runs of a few KiB per stream and the memory system answers
+	 * 10-15 % slower (12 frames: 0.49 -> 0.59 of peak, 3 frames 0.36 -> 0.41; profiles/round2/latency_r2e.jsonl).
+	 * There the slice is walked as ONE stream, two loads per lane in flight; the big batches keep 8 streams x 4. */
+	const bool small = slices >= 12;
+	u32 glog2 = tn.vss_groups_log2 < 0 ? (small ? 0u : 3u) : (u32)tn.vss_groups_log2;
 	if (glog2 > 3)
 		glog2 = 3; /* lane groups of >= 8 lanes: every request still covers a whole 128-byte line */
-	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), split_regions(fs), scope_k0_matrix(colorspace), dst, st};
-	return vss_pick(fuse_k0 ? tn.vss_fused_unroll : tn.vss_unroll, tn.nt_loads, tn.vss_merge, fuse_k0, tn.vss_hash, &a);
+	const int unroll = fuse_k0 ? tn.vss_fused_unroll : (tn.vss_unroll > 0 ? tn.vss_unroll : (small ? 2 : 4));
+	if (pmask && !scope_vss_mask_block(tn))
+		return hipErrorInvalidValue;
+	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), split_regions(fs), scope_k0_matrix(colorspace), dst, pmask, st};
+	return vss_pick(unroll, tn.nt_loads, tn.vss_merge, fuse_k0, tn.vss_hash, &a);
 }
 
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint32_t *dst, uint32_t *folded, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st)
+			    uint32_t *dst, uint32_t *acc, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st)
 {
 	if (!tickets || slices < 2)
-		folded = NULL;
-	const HisArgs a = {&fs, slices, chmask, scope_block(tn.his_block), split_regions(fs), scope_k0_matrix(colorspace), dst, folded, tickets, st};
+		acc = NULL;
+	const HisArgs a = {&fs, slices, chmask, scope_block(tn.his_block), split_regions(fs), scope_k0_matrix(colorspace), dst, acc, tickets, st};
 	return his_pick(tn.his_unroll, tn.nt_loads, fuse_k0, &a);
 }
 
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st)
+			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st, const ScopeHisSink *his)
 {
 	const u32 strips = (fs.width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
 	const u32 nch = (chmask & 1u) + ((chmask >> 1) & 1u) + ((chmask >> 2) & 1u);
@@ -1401,15 +1621,18 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 	for (u32 f = 0; wide && f < fs.n_frames; f++)
 		wide = (((size_t)fs.plane[f]) & 7u) == 0;
 	/* persistent workgroups: as many as are resident at once (LDS- or thread-limited), each walks units */
-	const u32 lds = nch * WVS_CH_WORDS * 4u;
+	const u32 lds = nch * WVS_CH_WORDS * 4u + (his ? WVS_HIS_LDS_BYTES : 0u);
 	u32 per_cu = max(1u, min((u32)(SCOPE_CU_LDS_BYTES / lds), (u32)(2048u / SCOPE_BLOCK)));
 	if (tn.wvs_per_cu > 0 && (u32)tn.wvs_per_cu < per_cu)
 		per_cu = (u32)tn.wvs_per_cu;
 	const u32 resident = per_cu * max(1u, num_cu);
 	const u32 total = fs.n_frames * strips * bands;
 	const u32 grid = (tn.wvs_persist && total > resident) ? resident : total;
-	const WvsArgs a = {&fs, strips, bands, lds, grid, scope_k0_matrix(colorspace), dst, st};
-	return wvs_pick(chmask, fuse_k0, wide, &a);
+	ScopeWvsHis h = {NULL, NULL, NULL, 0};
+	if (his)
+		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
+	const WvsArgs a = {&fs, strips, bands, lds, grid, scope_k0_matrix(colorspace), dst, h, st};
+	return wvs_pick(chmask, fuse_k0, wide, his != NULL, &a);
 }
 
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,
@@ -1419,6 +1642,19 @@ hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n
 	const u32 blocks = (u32)((len16 + 255) / 256);
 	hipLaunchKernelGGL(scope_sat_reduce_kernel, dim3(blocks, n_frames), dim3(256), 0, st, part, out, slices, len16,
 			   packed16 ? 1u : 0u);
+	return hipGetLastError();
+}
+
+hipError_t scope_launch_sat_reduce_sparse(const uint8_t *part, const uint8_t *pmask, uint8_t *out, uint32_t n_frames,
+					  uint32_t slices, uint32_t mask_block, int packed16, hipStream_t st)
+{
+	u32 sl_log2 = 0;
+	while (sl_log2 < 4 && (1u << sl_log2) < slices)
+		sl_log2++;
+	const u32 gpw = 256u >> sl_log2;
+	const u32 lds = sl_log2 ? 8192u + 32u * gpw : 0u;
+	hipLaunchKernelGGL(scope_sat_reduce_sparse_kernel, dim3(SCOPE_VSS_BINS / 16 / gpw, n_frames), dim3(256), lds, st, part,
+			   pmask, out, slices, mask_block, sl_log2, packed16 ? 1u : 0u);
 	return hipGetLastError();
 }
 

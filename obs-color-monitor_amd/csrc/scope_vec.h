@@ -85,6 +85,25 @@ template <unsigned TT> __device__ __forceinline__ unsigned scope_bitop3(unsigned
 	return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
 }
 
+/* Every VMEM operation of this wave (loads, stores, atomics without return) has been acknowledged.  Inline asm:
+ * hipcc (ROCm 7.2) drops a builtin wait when its own scoreboard says nothing is outstanding (MI355X_MICROARCH.md). */
+__device__ __forceinline__ void scope_drain_vmem()
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+/* *dst += the sum of x over the 16 lanes of a DPP row (lanes 16r .. 16r+15 of the wave; every lane active): four
+ * row_shr adds leave the row's total in its last lane, which adds it to LDS.  (LDS atomic: see the caller.) */
+__device__ __forceinline__ void scope_row16_add(unsigned *dst, unsigned x)
+{
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+	x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+	if ((threadIdx.x & 15u) == 15u && x)
+		atomicAdd(dst, x);
+}
+
 /* Sum over the 64 lanes of a wave; every lane must be active (uniform control flow). */
 __device__ __forceinline__ unsigned scope_wave_sum(unsigned x)
 {

@@ -30,11 +30,13 @@ ABI_SYMBOLS = (
     "scope_convert_rgb_yuv",
     "scope_vectorscope", "scope_waveform", "scope_histogram_counts", "scope_histogram", "scope_histogram_level",
     "scope_vectorscope_batch", "scope_waveform_batch", "scope_histogram_counts_batch",
+    "scope_waveform_histogram", "scope_waveform_histogram_batch",
     "scope_table_widen_u8_u32", "scope_table_clamp_u32_u8",
     "scope_table_pack_u8_u16x2", "scope_table_unpack_clamp_u16x2_u8",
     "scope_ctx_profile", "scope_ctx_kernel_ms",
     "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect", "scope_pipe_size",
     "scope_region_size", "scope_stage_region", "scope_surface_begin", "scope_surface_end",
+    "scope_rccl_unique_id", "scope_rccl_comm_create", "scope_rccl_comm_destroy", "scope_table_allreduce",
     "scope_display_vectorscope", "scope_display_vectorscope_zoom", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
 )
 
@@ -122,10 +124,16 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_vectorscope_batch": (i32, [vp, C.POINTER(Batch), u32, vp]),
         "scope_waveform_batch": (i32, [vp, C.POINTER(Batch), u32, u32, vp]),
         "scope_histogram_counts_batch": (i32, [vp, C.POINTER(Batch), u32, u32, vp]),
+        "scope_waveform_histogram": (i32, [vp, C.POINTER(SurfaceData), u32, u32, u32, vp, vp]),
+        "scope_waveform_histogram_batch": (i32, [vp, C.POINTER(Batch), u32, u32, u32, vp, vp]),
         "scope_table_widen_u8_u32": (i32, [vp, vp, vp, u64]),
         "scope_table_clamp_u32_u8": (i32, [vp, vp, vp, u64]),
         "scope_table_pack_u8_u16x2": (i32, [vp, vp, vp, u64]),
         "scope_table_unpack_clamp_u16x2_u8": (i32, [vp, vp, vp, u64]),
+        "scope_rccl_unique_id": (i32, [vp]),
+        "scope_rccl_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "scope_rccl_comm_destroy": (i32, [vp]),
+        "scope_table_allreduce": (i32, [vp, vp, vp, u64]),
         "scope_ctx_profile": (i32, [vp, i32]),
         "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
         "scope_display_vectorscope": (i32, [vp, vp, i32, i32, i32, u32, vp]),
@@ -280,6 +288,22 @@ class ScopeContext:
                                                        out.ctypes.data_as(C.c_void_p)), allow=(ENODATA,))
         return out, st
 
+    def waveform_histogram(self, rgb=None, yuv=None, width=0, wvs_components=COMP_RGB, his_components=COMP_RGB,
+                           colorspace=2, fuse_k0=False):
+        """K2 + K3 of one surface in one pass where the masks allow; (waveform table, counts, status)."""
+        out = np.full((256, width, 4), 0xEE, dtype=np.uint8)
+        cnt = np.full((256, 4), 0xEEEEEEEE, dtype=np.uint32)
+        sd = self._sd(rgb, yuv, width, colorspace)
+        st = self._check(self.L.scope_waveform_histogram(self.h, C.byref(sd), wvs_components, his_components,
+                                                         FUSE_K0 if fuse_k0 else 0, _hptr(out),
+                                                         cnt.ctypes.data_as(C.c_void_p)), allow=(ENODATA,))
+        return out, cnt, st
+
+    def waveform_histogram_batch_dev(self, batch, wvs_components, his_components, wvs_dev, his_dev, sync=True):
+        self._check(self.L.scope_waveform_histogram_batch(self.h, C.byref(batch), wvs_components, his_components,
+                                                          IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC),
+                                                          _dptr(wvs_dev), _dptr(his_dev)))
+
     def histogram(self, rgb=None, yuv=None, width=0, components=COMP_RGB, logscale=0, level_fixed=0, level_ratio=0,
                   colorspace=2, fuse_k0=False, hi_max_in=(0, 0, 0)):
         tex = np.full(4096, 0xEE, dtype=np.uint8)
@@ -395,6 +419,27 @@ class ScopeContext:
 
     def unpack16_clamp_dev(self, in_dev, out_dev, n_pairs):
         self._check(self.L.scope_table_unpack_clamp_u16x2_u8(self.h, _dptr(in_dev), _dptr(out_dev), n_pairs))
+
+    # -- the table sum over RCCL through the C-ABI (no torch.distributed in the data path) ---------------------------
+    def rccl_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        st = self.L.scope_rccl_unique_id(C.cast(buf, C.c_void_p))
+        if st != OK:
+            raise ScopeError(st, "scope_rccl_unique_id")
+        return bytes(buf)
+
+    def rccl_comm_create(self, unique_id: bytes, n_ranks: int, rank: int) -> int:
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        comm = C.c_void_p()
+        self._check(self.L.scope_rccl_comm_create(self.h, C.cast(buf, C.c_void_p), n_ranks, rank, C.byref(comm)))
+        return int(comm.value)
+
+    def rccl_comm_destroy(self, comm: int):
+        self.L.scope_rccl_comm_destroy(C.c_void_p(comm))
+
+    def table_allreduce(self, comm: int, words_dev, n_words: int):
+        """In-place uint32 sum over the communicator, enqueued on the context's stream."""
+        self._check(self.L.scope_table_allreduce(self.h, C.c_void_p(comm), _dptr(words_dev), n_words))
 
     def profile(self, enable: bool):
         self._check(self.L.scope_ctx_profile(self.h, int(enable)))

@@ -81,6 +81,17 @@ template <unsigned TT> static inline unsigned scope_bitop3(unsigned a, unsigned 
 	return out;
 }
 
+/* the emulated wave has one lane = one DPP row of its own */
+static inline void scope_row16_add(unsigned *dst, unsigned x)
+{
+	if (x)
+		__atomic_fetch_add(dst, x, __ATOMIC_RELAXED);
+}
+
+static inline void scope_drain_vmem()
+{
+}
+
 static inline unsigned scope_wave_sum(unsigned x)
 {
 	return x;

@@ -11,7 +11,7 @@ DISTS = {1: "uniform", 2: "concentrated", 3: "flat", 4: "bars", 5: "alpha_holes"
 COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
 
 
-DEFAULTS = {"vss.merge": 3, "vss.unroll": 4, "vss.fused_unroll": 2, "vss.hash": 0, "vss.groups": 3, "his.unroll": 1, "wvs.wide": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1,
+DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 2, "vss.hash": 0, "vss.groups": -1, "his.unroll": 1, "wvs.wide": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.block": 0, "his.block": 0,
             "nt": 1, "slices": 0}
 
 
@@ -249,6 +249,45 @@ def check_surface_fanout(ctx, oracle, w, h, linesize=None):
     assert ctx.surface_end() == (1, 0)
 
 
+def check_waveform_histogram(ctx, oracle, w, h, dist, linesize=None, colorspace=2):
+    """scope_waveform_histogram: K2 + K3 of one surface, one pass where the masks allow (same plane kind, histogram
+    channels a subset of the waveform's), two passes otherwise -- always the tables of the two separate scopes."""
+    rgb, yuv = frames(oracle, w, h, dist, linesize, colorspace=colorspace)
+    for wc, hc in ((0x07, 0x07), (0x70, 0x70), (0x70, 0x20), (0x07, 0x02), (0x05, 0x04), (0x13, 0x01),
+                   (0x20, 0x70), (0x07, 0x70), (0x50, 0x07), (0x01, 0x06)):
+        wv, cnt, st = ctx.waveform_histogram(rgb=rgb, yuv=yuv, width=w, wvs_components=wc, his_components=hc, colorspace=colorspace)
+        assert st == 0
+        assert_same(wv, oracle.waveform(rgb, yuv, w, wc), f"waveform+histogram: waveform {wc:#x}/{hc:#x} {w}x{h} d{dist}")
+        assert_same(cnt, oracle.histogram_counts(rgb, yuv, w, hc), f"waveform+histogram: counts {wc:#x}/{hc:#x} {w}x{h} d{dist}")
+    # fused K0: only the RGB plane exists
+    for wc, hc in ((0x70, 0x70), (0x20, 0x20), (0x70, 0x50), (0x07, 0x07)):
+        wv, cnt, st = ctx.waveform_histogram(rgb=rgb, yuv=None, width=w, wvs_components=wc, his_components=hc,
+                                             colorspace=colorspace, fuse_k0=True)
+        assert st == 0
+        assert_same(wv, oracle.waveform(rgb, yuv, w, wc), f"waveform+histogram fused K0: waveform {wc:#x}/{hc:#x}")
+        assert_same(cnt, oracle.histogram_counts(rgb, yuv, w, hc), f"waveform+histogram fused K0: counts {wc:#x}/{hc:#x}")
+
+
+def check_surface_waveform_feeds_histogram(ctx, oracle, w, h):
+    """Inside scope_surface_begin/end the waveform pass leaves the histogram of its channels behind: the dock's
+    histogram callback on the same surface costs neither an upload nor a kernel."""
+    rgb, yuv = frames(oracle, w, h, 5)
+    ctx.surface_begin()
+    wv, st = ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x07)
+    assert st == 0
+    assert_same(wv, oracle.waveform(rgb, yuv, w, 0x07), "dock waveform")
+    for hc in (0x07, 0x02, 0x05):  # every subset of the waveform's channels comes from the same side table
+        cnt, st = ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=hc)
+        assert st == 0
+        assert_same(cnt, oracle.histogram_counts(rgb, yuv, w, hc), f"dock histogram {hc:#x} from the waveform pass")
+    f, hi, st = ctx.histogram(rgb=rgb, yuv=yuv, width=w, components=0x07, logscale=1)
+    want_f, want_hi = oracle.histogram(rgb, yuv, w, 0x07, 1, 0, 0, (0, 0, 0))
+    assert st == 0 and np.array_equal(hi, want_hi) and np.array_equal(f.view(np.uint32), want_f.view(np.uint32))
+    cnt, st = ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=0x70)  # another plane: its own pass
+    assert_same(cnt, oracle.histogram_counts(rgb, yuv, w, 0x70), "dock histogram YUV")
+    assert ctx.surface_end() == (2, 4)  # RGB and YUV uploaded once; four histogram calls served without an upload
+
+
 REGIONS = ((1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (3, 0, 0, 0, 0), (1, 5, 3, 17, 9), (2, 1, 2, 7, 5), (4, 0, 1, 3, 2), (128, 0, 0, 0, 0))
 
 
@@ -308,6 +347,47 @@ def check_pipeline(ctx, oracle, w, h, n_frames=7, depth=3, linesize=None, region
             check(done, pipe.collect())
             done += 1
         assert pipe.collect() is None
+    finally:
+        pipe.close()
+
+
+def check_pipeline_tables_stay_valid(ctx, oracle, w, h, depth=2):
+    """The tables scope_pipe_collect hands out stay untouched until the NEXT scope_pipe_collect, however many frames are
+    submitted in between -- also when the ring was full and the very next submit re-uses the collected frame's ring
+    slot (the pipe rotates depth + 1 pinned table buffers)."""
+    import obs_color_monitor_amd as ocm
+
+    frames_ = [oracle.fill_frame(w, h, 1 + i % 5, 40 + i) for i in range(2 * depth + 2)]
+
+    def same_as_frame(held, i, what):
+        f = frames_[i]
+        yuv = oracle.rgb_to_yuv(f, w, 2)
+        assert_same(held[0], oracle.vectorscope(yuv, w), f"{what}: vectorscope of frame {i}")
+        assert_same(held[1], oracle.waveform(f, yuv, w, 0x07), f"{what}: waveform of frame {i}")
+        assert_same(held[2], oracle.histogram_counts(f, yuv, w, 0x07), f"{what}: counts of frame {i}")
+
+    def submit(i):
+        return pipe.submit(frames_[i].ctypes.data, 4 * w)
+
+    pipe = ocm.ScopePipe(ctx, w, h, depth=depth, colorspace=2, wvs_components=0x07, his_components=0x07)
+    try:
+        # a full ring: the oldest frame is collected and the next submit takes its slot at once
+        for i in range(depth):
+            assert submit(i)
+        assert not submit(depth)
+        held = pipe.collect()  # views into the pipe's pinned memory, NOT copied
+        assert submit(depth) and not submit(depth + 1)
+        ctx.sync()  # the new frame's tables have reached the host
+        same_as_frame(held, 0, "full ring, one more frame submitted")
+        while pipe.collect() is not None:
+            pass
+        # one frame in flight: after its collect the whole ring refills before the next collect
+        assert submit(depth + 1)
+        held = pipe.collect()
+        for i in range(depth):
+            assert submit(i)
+        ctx.sync()
+        same_as_frame(held, depth + 1, "ring refilled completely")
     finally:
         pipe.close()
 

@@ -195,6 +195,11 @@ def test_frame_pipeline(emul_ctx, oracle):
     pc.check_pipeline(emul_ctx, oracle, 70, 20, n_frames=5, depth=2, linesize=4 * 70 + 24)
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_frame_pipeline_tables_stay_valid(emul_ctx, oracle, depth):
+    pc.check_pipeline_tables_stay_valid(emul_ctx, oracle, 70, 20, depth)
+
+
 @pytest.mark.parametrize("region", [(2, 0, 0, 0, 0), (1, 3, 2, 33, 11), (3, 1, 1, 20, 4)])
 def test_frame_pipeline_scaled_and_cropped(emul_ctx, oracle, region):
     """target_scale and the ROI rectangle applied on the device before the scopes."""
@@ -213,6 +218,17 @@ def test_stage_region_rejects_bad_arguments(emul_ctx, oracle):
     for bad in ((0, 0, 0, 0, 0), (2, 8, 0, 1, 1), (2, 0, 0, 9, 1), (2, 7, 3, 2, 2), (32, 0, 0, 0, 0)):
         with pytest.raises(ocm.ScopeError):
             emul_ctx.stage_region(plane, 16, *bad)
+
+
+@pytest.mark.parametrize("w,h,dist", [(70, 36, 5), (64, 9, 1), (130, 21, 2), (1, 1, 1), (66, 50, 3)])
+def test_waveform_histogram_one_pass(emul_ctx, oracle, w, h, dist):
+    pc.check_waveform_histogram(emul_ctx, oracle, w, h, dist)
+    with pc.options(emul_ctx, slices=3):  # row bands: partial waveform tables, the histogram still complete
+        pc.check_waveform_histogram(emul_ctx, oracle, w, h, dist)
+
+
+def test_surface_waveform_feeds_histogram(emul_ctx, oracle):
+    pc.check_surface_waveform_feeds_histogram(emul_ctx, oracle, 70, 36)
 
 
 def test_display_post_passes(emul_ctx, oracle):

@@ -96,18 +96,137 @@ def test_component_masks(hip_ctx, oracle, comp):
 
 @pytest.mark.parametrize("fold", [0, 1])
 def test_partial_tables_combined_in_kernel_or_by_reduce_kernel(hip_ctx, oracle, fold):
-    """slices > 1: partial tables are combined by a reduce kernel or -- histogram, at most 16 partials per frame --
-    by the last workgroup of the frame.  Repeated launches check that the arrival tickets are back at zero each
-    time; 256 partials per frame is the single-frame case on 256 CUs (always the reduce kernel)."""
+    """slices > 1: the vectorscope's partial tables are combined by a reduce kernel; the histogram's slices meet
+    inside the launch (fold=1: device-scope atomics + the last workgroup of the frame) or through partial tables and a
+    reduce kernel (fold=0).  Repeated launches check that tickets and accumulators are back at zero each time;
+    256 slices per frame is the single-frame case on 256 CUs."""
     with pc.options(hip_ctx, fold=fold):
         for _ in range(4):
             pc.check_vectorscope(hip_ctx, oracle, 1920, 1080, 2)  # one frame -> 256 slices, saturated bins
             pc.check_histogram_counts(hip_ctx, oracle, 1920, 1080, 5, 0x07)
         pc.check_batches(hip_ctx, oracle, 640, 360, 7)
-        pc.check_batches(hip_ctx, oracle, 320, 180, 32)  # 8 partials per frame: folded in-kernel
+        pc.check_batches(hip_ctx, oracle, 320, 180, 32)  # 8 slices per frame
         with pc.options(hip_ctx, fold=fold, slices=3):
             for _ in range(3):
                 pc.check_batches(hip_ctx, oracle, 640, 360, 5)
+
+
+@pytest.mark.parametrize("sparse", [0, 1])
+@pytest.mark.parametrize("slices", [2, 3, 5, 16, 17, 85, 128, 255, 256])
+def test_vectorscope_sparse_partials(hip_ctx, oracle, sparse, slices):
+    """Partial tables that hold only the non-empty 16-bin groups (+ a mask byte per thread), in the blocked layout the
+    parallel reduce kernel reads, against dense partials: every slice count that changes the reduction's shape
+    (slice lanes 2..16, ragged last round), flat / concentrated / noisy / alpha-holed content, plain and fused K0."""
+    with pc.options(hip_ctx, **{"vss.sparse": sparse, "slices": slices}):
+        for dist in (1, 2, 3, 5):
+            pc.check_vectorscope(hip_ctx, oracle, 640, 360, dist)
+        pc.check_vectorscope(hip_ctx, oracle, 1279, 300, 2, 5120)
+        pc.check_vectorscope(hip_ctx, oracle, 640, 360, 1, fuse=True)
+        pc.check_vectorscope(hip_ctx, oracle, 33, 5, 1, 140)  # most slices are empty
+
+
+@pytest.mark.parametrize("block", [256, 512, 768, 1024])
+def test_vectorscope_sparse_partials_workgroup_sizes(hip_ctx, oracle, block):
+    """The mask byte of a thread covers its 4096 / blockDim groups: 8 at 512 threads; below that the launch falls back
+    to dense partials."""
+    with pc.options(hip_ctx, **{"vss.block": block}):
+        pc.check_vectorscope(hip_ctx, oracle, 1920, 1080, 1)
+        pc.check_vectorscope(hip_ctx, oracle, 640, 360, 2)
+        with pc.options(hip_ctx, slices=7):
+            pc.check_vectorscope(hip_ctx, oracle, 640, 360, 5)
+
+
+def test_one_and_three_frame_launches_4k(hip_ctx, oracle):
+    """The reference's call shape (one surface per callback, ring of 3: src/common.c:366-368, src/common.h:46) at
+    3840x2160 through the device-pointer batch entry points, all three scopes, tables checked for every frame."""
+    import torch
+
+    w, h = 3840, 2160
+    rgbs = [oracle.fill_frame(w, h, d, 40 + d) for d in (1, 2, 5)]
+    yuvs = [oracle.rgb_to_yuv(r, w, 2) for r in rgbs]
+    ty, tr = torch.from_numpy(np.stack(yuvs)).cuda(), torch.from_numpy(np.stack(rgbs)).cuda()
+    for n in (1, 3):
+        by = hip_ctx.make_device_batch(ty[:n], 4 * w, w, h, planes_are_rgb=False)
+        br = hip_ctx.make_device_batch(tr[:n], 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+        vss = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
+        cnt = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+        wvs = torch.empty((n, 256 * w * 4), dtype=torch.uint8, device="cuda")
+        for rep in range(3):  # accumulators and tickets must come back to zero
+            for batch in (by, br):
+                vss.fill_(0xEE)
+                hip_ctx.vectorscope_batch_dev(batch, vss)
+                for f in range(n):
+                    pc.assert_same(vss[f].cpu().numpy().reshape(256, 256), oracle.vectorscope(yuvs[f], w), f"vss n{n} f{f}")
+            cnt.fill_(-1)
+            hip_ctx.histogram_counts_batch_dev(br, 0x07, cnt)
+            for f in range(n):
+                pc.assert_same(cnt[f].cpu().numpy().view(np.uint32).reshape(256, 4),
+                               oracle.histogram_counts(rgbs[f], None, w, 0x07), f"his n{n} f{f}")
+        hip_ctx.waveform_batch_dev(br, 0x07, wvs)
+        for f in range(n):
+            pc.assert_same(wvs[f].cpu().numpy().reshape(256, w, 4), oracle.waveform(rgbs[f], None, w, 0x07), f"wvs n{n} f{f}")
+
+
+@pytest.mark.parametrize("w,h,dist", [(640, 360, 5), (70, 9, 1), (1279, 300, 2), (330, 77, 3), (3840, 2160, 5)])
+def test_waveform_histogram_one_pass(hip_ctx, oracle, w, h, dist):
+    """K2 + K3 from one read of the plane (the histogram is added up from the waveform's per-column counters at
+    flush time), every mask pairing incl. the ones that cannot share a pass, single frames (row bands) and batches."""
+    pc.check_waveform_histogram(hip_ctx, oracle, w, h, dist)
+    if w < 3000:
+        with pc.options(hip_ctx, slices=1):
+            pc.check_waveform_histogram(hip_ctx, oracle, w, h, dist, None, 1)
+
+
+def test_waveform_histogram_batch_device(hip_ctx, oracle):
+    import torch
+
+    w, h, n = 1280, 720, 5
+    rgbs = [oracle.fill_frame(w, h, 1 + i % 5, 500 + i) for i in range(n)]
+    tr = torch.from_numpy(np.stack(rgbs)).cuda()
+    b = hip_ctx.make_device_batch(tr, 4 * w, w, h, planes_are_rgb=True, colorspace=1)
+    wv = torch.empty((n, 256 * w * 4), dtype=torch.uint8, device="cuda")
+    cnt = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+    for wc, hc in ((0x07, 0x07), (0x70, 0x20), (0x07, 0x70)):
+        for rep in range(3):
+            cnt.fill_(-1)
+            hip_ctx.waveform_histogram_batch_dev(b, wc, hc, wv, cnt)
+            for f in range(n):
+                yuv = oracle.rgb_to_yuv(rgbs[f], w, 1)
+                pc.assert_same(wv[f].cpu().numpy().reshape(256, w, 4), oracle.waveform(rgbs[f], yuv, w, wc), f"batch waveform {wc:#x} f{f}")
+                pc.assert_same(cnt[f].cpu().numpy().view(np.uint32).reshape(256, 4), oracle.histogram_counts(rgbs[f], yuv, w, hc),
+                               f"batch counts {hc:#x} f{f}")
+
+
+def test_surface_waveform_feeds_histogram(hip_ctx, oracle):
+    pc.check_surface_waveform_feeds_histogram(hip_ctx, oracle, 640, 360)
+    pc.check_surface_waveform_feeds_histogram(hip_ctx, oracle, 1279, 301)
+
+
+def test_histogram_in_kernel_combine_stress(hip_ctx, oracle):
+    """The in-launch combine of the histogram hands data between workgroups with device-scope atomics and an arrival
+    ticket (scope_last_arrival).  4000 back-to-back launches over rotating frames, 1..256 slices per frame, every count
+    of every launch compared on the device with the tables of the two-kernel path (fold=0)."""
+    import torch
+
+    w, h, pool = 1280, 720, 8
+    frames = torch.from_numpy(np.stack([oracle.fill_frame(w, h, 1 + i % 5, 900 + i) for i in range(pool)])).cuda()
+    for n, slices in ((1, 0), (3, 0), (8, 0), (1, 37)):
+        groups = pool // n
+        batches = [hip_ctx.make_device_batch(frames[g * n:(g + 1) * n], 4 * w, w, h, planes_are_rgb=True) for g in range(groups)]
+        want = torch.empty((groups, n, 1024), dtype=torch.int32, device="cuda")
+        with pc.options(hip_ctx, fold=0, slices=slices):
+            for g in range(groups):
+                hip_ctx.histogram_counts_batch_dev(batches[g], 0x07, want[g])
+        reps = 1000
+        got = torch.empty((reps, n, 1024), dtype=torch.int32, device="cuda")
+        with pc.options(hip_ctx, fold=1, slices=slices):
+            for i in range(reps):
+                hip_ctx.histogram_counts_batch_dev(batches[i % groups], 0x07, got[i], sync=False)
+            hip_ctx.sync()
+        idx = torch.arange(reps, device="cuda") % groups
+        assert torch.equal(got, want[idx]), f"n={n} slices={slices}"
+    pc.assert_same(want[0, 0].cpu().numpy().view(np.uint32).reshape(256, 4),
+                   oracle.histogram_counts(frames[0].cpu().numpy(), None, w, 0x07), "fold=0 reference")
 
 
 def test_waveform_taller_than_16_bit_counters(hip_ctx, oracle):
@@ -371,6 +490,11 @@ def test_frame_pipeline_streams(hip_ctx, oracle):
     pc.check_pipeline(hip_ctx, oracle, 3840, 2160, n_frames=5, depth=3)
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_frame_pipeline_tables_stay_valid(hip_ctx, oracle, depth):
+    pc.check_pipeline_tables_stay_valid(hip_ctx, oracle, 1280, 720, depth)
+
+
 @pytest.mark.parametrize("region", [(2, 0, 0, 0, 0), (1, 100, 50, 333, 111), (3, 7, 5, 200, 100)])
 def test_frame_pipeline_scaled_and_cropped(hip_ctx, oracle, region):
     """target_scale (the reference's default is 2) and the ROI rectangle on the device."""
@@ -464,3 +588,39 @@ def test_table_all_reduce_side_stream_buckets(hip_ctx, oracle):
         hip_ctx.set_stream(None)
         if created:
             dist.destroy_process_group()
+
+
+def test_table_allreduce_through_the_c_abi(hip_ctx, oracle):
+    """scope_table_allreduce: RCCL called from the C-ABI with a communicator made by scope_rccl_comm_create (a one-rank
+    clique on this 1-GPU box), on the context's stream between the packed-output vectorscope and the unpack/clamp
+    pass -- the data path a C host uses for row tiles, no torch.distributed in it."""
+    import torch
+
+    w, h, n = 640, 360, 3
+    uid = hip_ctx.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = hip_ctx.rccl_comm_create(uid, 1, 0)
+    try:
+        yuvs = [oracle.rgb_to_yuv(oracle.fill_frame(w, h, 1 + i, 70 + i), w, 2) for i in range(n)]
+        ty = torch.from_numpy(np.stack(yuvs)).cuda()
+        batch = hip_ctx.make_device_batch(ty, 4 * w, w, h, planes_are_rgb=False)
+        wire = torch.empty((n, 32768), dtype=torch.int32, device="cuda")
+        out = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            hip_ctx.vectorscope_batch_dev(batch, wire, sync=False, packed16=True)
+            hip_ctx.table_allreduce(comm, wire, n * 32768)
+            hip_ctx.unpack16_clamp_dev(wire, out, n * 32768)
+            hip_ctx.sync()
+            for f in range(n):
+                pc.assert_same(out[f].cpu().numpy().reshape(256, 256), oracle.vectorscope(yuvs[f], w), f"frame {f}")
+        cnt = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+        tr = torch.from_numpy(np.stack([oracle.fill_frame(w, h, 5, 3 + i) for i in range(n)])).cuda()
+        br = hip_ctx.make_device_batch(tr, 4 * w, w, h, planes_are_rgb=True)
+        hip_ctx.histogram_counts_batch_dev(br, 0x07, cnt, sync=False)
+        hip_ctx.table_allreduce(comm, cnt, n * 1024)
+        hip_ctx.sync()
+        for f in range(n):
+            pc.assert_same(cnt[f].cpu().numpy().view(np.uint32).reshape(256, 4),
+                           oracle.histogram_counts(tr[f].cpu().numpy(), None, w, 0x07), f"histogram frame {f}")
+    finally:
+        hip_ctx.rccl_comm_destroy(comm)

@@ -240,10 +240,66 @@ static int placement_main()
 	return 0;
 }
 
+// Round 2: what does ONE 4K frame (33 MB) cost when nothing but the read is done?  The yardstick for the one- and
+// three-frame launches of the scopes (tools/latency_probe.py): launches back to back over a pool of 24 distinct frames.
+template <typename K> static float run_small(K launch, int reps)
+{
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0);
+	hipEventCreate(&e1);
+	for (int i = 0; i < 20; i++)
+		launch(i);
+	hipEventRecord(e0, 0);
+	for (int i = 0; i < reps; i++)
+		launch(i);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	return ms / reps * 1e3f;
+}
+
+static int small_main()
+{
+	const uint64_t frame = 3840ull * 2160 * 4, pool = 24;
+	uint32_t *buf, *sink;
+	if (hipMalloc((void **)&buf, frame * pool) != hipSuccess || hipMalloc((void **)&sink, 64) != hipSuccess)
+		return 1;
+	hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf, frame * pool / 4);
+	for (int i = 0; i < 300; i++)
+		hipLaunchKernelGGL((read_kernel<4, true>), dim3(256), dim3(1024), 0, 0, (const v4 *)buf, frame * pool / 16, sink);
+	hipDeviceSynchronize();
+	for (int nf : {1, 3, 6}) {
+		const uint64_t n16 = frame * nf / 16;
+		const int groups = (int)(pool / nf);
+		auto at = [&](int i) { return (const v4 *)((const uint8_t *)buf + (uint64_t)(i % groups) * nf * frame); };
+		const int reps = 600;
+		printf("%d frame(s) per launch, us per launch (back to back):\n", nf);
+#define SMALL(label, expr) printf("  %-58s %7.2f us  %7.1f GB/s\n", label, t = run_small([&](int i) { expr; }, reps), frame * nf / (t * 1e-6) / 1e9)
+		float t;
+		SMALL("256 x 1024 threads, contiguous share, 4 loads/lane", hipLaunchKernelGGL((read_kernel<4, true>), dim3(256), dim3(1024), 0, 0, at(i), n16, sink));
+		SMALL("256 x 1024 threads, contiguous share, 2 loads/lane", hipLaunchKernelGGL((read_kernel<2, true>), dim3(256), dim3(1024), 0, 0, at(i), n16, sink));
+		SMALL("256 x 1024, ping-pong 4+4, interleaved chunks", hipLaunchKernelGGL((read_pp<4, true, 0>), dim3(256), dim3(1024), 0, 0, at(i), n16, sink));
+		SMALL("256 x 1024, ping-pong 4+4, contiguous share", hipLaunchKernelGGL((read_pp<4, true, 1>), dim3(256), dim3(1024), 0, 0, at(i), n16, sink));
+		SMALL("256 x 1024, ping-pong 2+2, contiguous share", hipLaunchKernelGGL((read_pp<2, true, 1>), dim3(256), dim3(1024), 0, 0, at(i), n16, sink));
+		SMALL("256 x 1024, ping-pong 4+4, contiguous + 8 lane-group streams", hipLaunchKernelGGL((read_pp<4, true, 2>), dim3(256), dim3(1024), 0, 0, at(i), n16, sink));
+		SMALL("512 x 512, ping-pong 4+4, interleaved chunks", hipLaunchKernelGGL((read_pp<4, true, 0>), dim3(512), dim3(512), 0, 0, at(i), n16, sink));
+		SMALL("1024 x 256, ping-pong 4+4, interleaved chunks", hipLaunchKernelGGL((read_pp<4, true, 0>), dim3(1024), dim3(256), 0, 0, at(i), n16, sink));
+		SMALL("2048 x 256 threads, contiguous share, 4 loads/lane", hipLaunchKernelGGL((read_kernel<4, true>), dim3(2048), dim3(256), 0, 0, at(i), n16, sink));
+		SMALL("8192 x 256 threads, contiguous share, 4 loads/lane", hipLaunchKernelGGL((read_kernel<4, true>), dim3(8192), dim3(256), 0, 0, at(i), n16, sink));
+		SMALL("empty kernel, 256 x 1024", hipLaunchKernelGGL((read_kernel<4, true>), dim3(256), dim3(1024), 0, 0, at(i), (uint64_t)0, sink));
+	}
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc > 1 && !strcmp(argv[1], "placement"))
 		return placement_main();
+	if (argc > 1 && !strcmp(argv[1], "small"))
+		return small_main();
 	const uint64_t bytes = 32ull * 3840 * 2160 * 4;
 	const uint64_t n16 = bytes / 16;
 	uint32_t *buf, *sink;

@@ -13,7 +13,7 @@ from obs_color_monitor_amd.synth import make_frames
 lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libscope_hip_trace.so")
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 c = ocm.ScopeContext(0, lib); c.set_stream(stream.cuda_stream)
-for n in (8, 64):
+for n in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("8", "64"))]:
     rgb, yuv = make_frames(torch, c, n, W, H, "uniform", 7)
     out = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
     b = c.make_device_batch(yuv, 4 * W, W, H, planes_are_rgb=False)
@@ -24,7 +24,8 @@ for n in (8, 64):
         c.vectorscope_batch_dev(b, out, sync=True)
         buf = (ctypes.c_ulonglong * 4096)()
         assert c.L.scope_debug_read(buf) == 0
-        t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4)[:256].astype(np.int64)
+        nwg = n * max(1, 256 // n) if n < 256 else 256
+        t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4)[:nwg].astype(np.int64)
         t0 = t[:, 0].min()
         us = (t - t0) / 100.0   # 100 MHz
         res.append((us[:, 0].max(), np.median(us[:, 1]), us[:, 1].min(), us[:, 1].max(), us[:, 2].max(), np.percentile(us[:, 1], 10), np.percentile(us[:, 1], 90)))
