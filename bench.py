@@ -124,8 +124,10 @@ class Workload:
 
 
 def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=None):
-    """settle -> warm-up -> EXACTLY `steps` steps between (barrier +) synchronize -> at least min_s more of the same.
-    Returns (elapsed of the K steps, sustained dict, kernel launches, kernel ms)."""
+    """settle -> warm-up -> EXACTLY `steps` steps between (barrier +) synchronize -> at least min_s more of the same ->
+    a short leg with the accumulation kernel bracketed by HIP events (the bracket costs a few microseconds of stream time
+    per launch -- a quarter of a one-frame step -- so it stays out of the two timed legs).
+    Returns (elapsed of the K steps, sustained dict, bracketed kernel launches, their summed ms)."""
     t_end = time.perf_counter() + settle_s
     i = 0
     while time.perf_counter() < t_end:
@@ -138,7 +140,6 @@ def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=Non
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.profile(True)
     t0 = time.perf_counter()
     for j in range(steps):
         step(j)
@@ -146,7 +147,7 @@ def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=Non
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # the sustained leg: the same step for >= min_s, in chunks so that the host stays a little ahead of the GPU
+    # the sustained leg: the same step for >= min_s; the host only enqueues (its own pace is reported beside the GPU's)
     s_steps, e0, e1 = 0, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     chunk = max(8, steps)
     t1 = time.perf_counter()
@@ -157,10 +158,16 @@ def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=Non
         s_steps += chunk
         if time.perf_counter() - t1 >= min_s:
             break
+    host_s = time.perf_counter() - t1
     e1.record(stream)
     torch.cuda.synchronize()
     sustained = {"seconds": round(time.perf_counter() - t1, 3), "steps": s_steps,
-                 "ms_per_step": round(e0.elapsed_time(e1) / s_steps, 5)}
+                 "ms_per_step": round(e0.elapsed_time(e1) / s_steps, 5),
+                 "host_enqueue_ms_per_step": round(host_s / s_steps * 1e3, 5)}
+    ctx.profile(True)
+    for j in range(min(400, max(60, steps))):
+        step(j)
+    torch.cuda.synchronize()
     launches, kernel_ms = ctx.kernel_ms()
     ctx.profile(False)
     return elapsed, sustained, launches, kernel_ms
@@ -490,14 +497,15 @@ def main():
                 ok = lw.check(o, rgb, yuv, np, frames=[nf - 1])
                 us = sus["ms_per_step"] * 1e3
                 latency[f"{v}_x{nf}"] = {
-                    "frames_per_call": nf, "us_per_call": round(us, 2),
+                    "frames_per_call": nf, "us_per_call": round(us, 2), "us_host_enqueue_per_call": round(sus["host_enqueue_ms_per_step"] * 1e3, 2),
                     "us_accumulation_kernel": round(kms / ln * 1e3, 2) if ln else None,
                     "gbps": round(lw.algo_bytes / (us * 1e-6) / 1e9, 1), "frac_of_peak": round(lw.algo_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                     "parity": bool(ok)}
                 del lw
         latency["note"] = ("us_per_call = stream time per call in steady state, calls back to back on one stream over 24 rotating "
-                           "frames: every kernel of the call (accumulation + partial-table reduction) and the gaps between them; "
-                           "the HIP-event bracket of the accumulation kernel alone adds ~3 us of event overhead at this scale")
+                           "frames: every kernel of the call (accumulation + partial-table reduction) and the gaps between them, no "
+                           "event brackets in between; us_accumulation_kernel comes from a separate bracketed leg and carries "
+                           "~2-3 us of event overhead at this scale (rocprofv3 --stats of the same launches: profiles/round2/)")
         result["latency"] = latency
         try:
             from obs_color_monitor_amd.stream import stream_leg
