@@ -27,6 +27,10 @@ extern "C" {
 typedef struct obs_data obs_data_t;
 typedef struct obs_source obs_source_t;
 typedef struct gs_effect gs_effect_t;
+typedef struct obs_properties obs_properties_t;
+typedef struct obs_property obs_property_t;
+struct obs_mouse_event; /* only ever passed through (vss_mouse_wheel ignores it, src/vectorscope.c:473-476) */
+typedef void (*obs_source_enum_proc_t)(obs_source_t *parent, obs_source_t *child, void *param);
 
 enum obs_source_type { OBS_SOURCE_TYPE_INPUT, OBS_SOURCE_TYPE_FILTER };
 #define OBS_SOURCE_VIDEO (1 << 0)
@@ -48,6 +52,11 @@ struct obs_source_info {
 	void (*update)(void *data, obs_data_t *settings);
 	void (*video_tick)(void *data, float seconds);
 	void (*video_render)(void *data, gs_effect_t *effect);
+	/* the rest of what the reference's tables set (src/vectorscope.c:484-519, src/waveform.c:402-417,
+	 * src/histogram.c:580-595, src/roi.c:572-593); appended so that the members above keep their offsets */
+	obs_properties_t *(*get_properties)(void *data);
+	void (*enum_active_sources)(void *data, obs_source_enum_proc_t enum_callback, void *param);
+	void (*mouse_wheel)(void *data, const struct obs_mouse_event *event, int x_delta, int y_delta);
 };
 
 enum { LOG_ERROR = 100, LOG_WARNING = 200, LOG_INFO = 300, LOG_DEBUG = 400 };
@@ -60,6 +69,24 @@ bool obs_data_get_bool(obs_data_t *data, const char *name);
 void obs_data_set_default_int(obs_data_t *data, const char *name, long long val);
 void obs_data_set_default_bool(obs_data_t *data, const char *name, bool val);
 void obs_register_source(const struct obs_source_info *info);
+
+/* the property calls the get_properties callbacks of this path make */
+enum obs_combo_type { OBS_COMBO_TYPE_LIST = 2 };
+enum obs_combo_format { OBS_COMBO_FORMAT_INT = 1 };
+obs_properties_t *obs_properties_create(void);
+void obs_properties_destroy(obs_properties_t *props);
+obs_property_t *obs_properties_add_int(obs_properties_t *props, const char *name, const char *description, int min, int max,
+				       int step);
+obs_property_t *obs_properties_add_bool(obs_properties_t *props, const char *name, const char *description);
+obs_property_t *obs_properties_add_list(obs_properties_t *props, const char *name, const char *description,
+					enum obs_combo_type type, enum obs_combo_format format);
+size_t obs_property_list_add_int(obs_property_t *p, const char *name, long long val);
+const char *obs_module_text(const char *lookup);
+
+/* libobs' profiler (util/profiler.h), which the reference's ENABLE_PROFILE build calls with the zone names mirrored in
+ * scope_common.h */
+void profile_start(const char *name);
+void profile_end(const char *name);
 
 #define UNUSED_PARAMETER(x) ((void)(x))
 

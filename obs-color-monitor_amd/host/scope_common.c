@@ -1,6 +1,12 @@
 /*
  * scope_common.c -- ring + "color-monitor" consumer thread of the reference
  * (src/common.c:335-403) for the stand-alone host, and the module's shared GPU context.
+ *
+ * One reference quirk is NOT reproduced: in the reference the producer stacks a raw RGB copy in
+ * front of the YUV rows whenever CM_FLAG_RAW_TEXTURE is set (src/common.c:191-205) but the consumer skips a first plane only
+ * for CM_FLAG_CONVERT_RGB (:358-364), so an ROI (always RAW_TEXTURE, src/roi.c:35) whose only scope is a vectorscope
+ * hands RGB rows to it as yuv_data.  Here the staged surface holds exactly the planes the flags ask for and the
+ * vectorscope gets the Y'CbCr rows.  Default docks never hit the case (waveform and histogram default to RGB).
  */
 #include "scope_common.h"
 
@@ -61,6 +67,7 @@ static void cm_pipeline_thread_loop(struct cm_source *src, struct cm_surface_que
 	if (item->cb) {
 		/* one staged surface, possibly several scopes behind the callback (roi_surface_cb fans out, src/roi.c:329-341):
 		 * every plane crosses PCIe once however many of them read it */
+		PROFILE_START(PROF_PIPELINE_THREAD); /* the reference brackets the whole loop body, src/common.c:393-395 */
 		const bool cached = scope_surface_begin(cm_gpu(), 0) == SCOPE_OK;
 		item->cb(item->cb_data, &surface_data);
 		if (cached) {
@@ -70,6 +77,7 @@ static void cm_pipeline_thread_loop(struct cm_source *src, struct cm_surface_que
 				src->plane_reuses += reuses;
 			}
 		}
+		PROFILE_END(PROF_PIPELINE_THREAD);
 	}
 	src->frames_processed++;
 }
@@ -124,6 +132,27 @@ void cm_get_defaults(obs_data_t *settings)
 	obs_data_set_default_bool(settings, "bypass", false);
 }
 
+void cm_get_properties(struct cm_source *src, obs_properties_t *props)
+{
+	if (!src)
+		return;
+	/* "target_name" lists OBS's sources (src/common.c:120-122): the stand-alone host has none to offer */
+	obs_properties_add_int(props, "target_scale", obs_module_text("Scale"), 1, 128, 1);
+	if (!(src->flags & CM_FLAG_ROI))
+		obs_properties_add_bool(props, "bypass", obs_module_text("Bypass"));
+}
+
+void cm_enum_sources(void *data, obs_source_enum_proc_t enum_callback, void *param)
+{
+	struct cm_source *src = data;
+	if (src->enumerating)
+		return;
+	src->enumerating = true;
+	if (src->target)
+		enum_callback(src->self, src->target, param);
+	src->enumerating = false;
+}
+
 void cm_update(struct cm_source *src, obs_data_t *settings)
 {
 	src->target_scale = (int)obs_data_get_int(settings, "target_scale"); /* src/common.c:88-90 */
@@ -137,10 +166,10 @@ void cm_update(struct cm_source *src, obs_data_t *settings)
 
 void cm_create(struct cm_source *src, obs_data_t *settings, obs_source_t *source)
 {
-	UNUSED_PARAMETER(source);
 	uint32_t flags = src->flags; /* the scope sets flags before or after, as in the reference */
 	memset(src, 0, sizeof *src);
 	src->flags = flags;
+	src->self = source;
 	src->i_write_queue = 0; /* src/common.c:33-35 */
 	src->i_staging_queue = 0;
 	src->i_read_queue = CM_SURFACE_QUEUE_SIZE - 1;
@@ -274,19 +303,27 @@ bool cm_render_target(struct cm_source *src, const uint8_t *target_rgb, uint32_t
 	uint32_t cx, cy;
 	if (scope_region_size(target_width, target_height, &region, &cx, &cy) != SCOPE_OK)
 		return false;
+	PROFILE_START(PROF_RENDER_TARGET);
 	const uint32_t out_linesize = cx * 4;
 	const size_t plane = (size_t)out_linesize * cy;
 	uint8_t *stacked = bzalloc(plane * 2);
-	if (!stacked)
+	if (!stacked) {
+		PROFILE_END(PROF_RENDER_TARGET);
 		return false;
+	}
 	/* RGB rows first, YUV rows after them -- the staged surface's layout (:284-291) */
 	int st = scope_stage_region(cm_gpu(), target_rgb, linesize, target_width, target_height, &region, stacked,
 				    out_linesize, 0);
-	if (st == SCOPE_OK && has_yuv)
+	if (st == SCOPE_OK && has_yuv) {
+		PROFILE_START(PROF_CONVERT_YUV);
 		st = scope_convert_rgb_yuv(cm_gpu(), stacked, out_linesize, stacked + plane, out_linesize, cx, cy,
 					   src->colorspace, 0);
+		PROFILE_END(PROF_CONVERT_YUV);
+	}
+	PROFILE_END(PROF_RENDER_TARGET);
 	bool staged = false;
 	if (st == SCOPE_OK) {
+		PROFILE_START(PROF_STAGE_SURFACE);
 		/* the rectangle is already applied: stage the planes as they are */
 		const uint32_t flags = src->flags;
 		src->flags &= ~(uint32_t)CM_FLAG_ROI;
@@ -296,6 +333,7 @@ bool cm_render_target(struct cm_source *src, const uint8_t *target_rgb, uint32_t
 			staged = cm_stage_surface(src, stacked + plane, out_linesize, cx, cy);
 		}
 		src->flags = flags;
+		PROFILE_END(PROF_STAGE_SURFACE);
 	} else {
 		blog(LOG_ERROR, "[obs-color-monitor] cm_render_target: %s (%s)", scope_strerror(st), scope_last_error(cm_gpu()));
 	}

@@ -37,6 +37,32 @@ typedef void (*cm_surface_cb_t)(void *data, struct cm_surface_data *surface_data
 
 #define CM_SURFACE_QUEUE_SIZE 3 /* src/common.h:46 */
 
+/* The reference's profiler zones, same names (src/common.c:10-21, src/vectorscope.c:10-20, src/waveform.c:8-18,
+ * src/histogram.c:10-19, src/roi.c:11-18): a build with ENABLE_PROFILE shows the GPU calls in the very zones the CPU loops
+ * used to fill, so before/after traces of OBS's profiler line up.  The stand-alone host builds with ENABLE_PROFILE and a
+ * counting profile_start/profile_end (fake_obs.c). */
+#ifdef ENABLE_PROFILE
+#define PROFILE_START(x) profile_start(x)
+#define PROFILE_END(x) profile_end(x)
+#else
+#define PROFILE_START(x)
+#define PROFILE_END(x)
+#endif
+#define PROF_PIPELINE_THREAD "cm_pipeline_thread_loop"
+#define PROF_RENDER_TARGET "render_target"
+#define PROF_CONVERT_YUV "convert_yuv"
+#define PROF_STAGE_SURFACE "stage_surface"
+#define PROF_STAGESURFACE_MAP "stage_surface_map"
+#define PROF_VSS_RENDER "vss_render"
+#define PROF_DRAW_VECTORSCOPE "draw_vectorscope"
+#define PROF_WVS_RENDER "wvs_render"
+#define PROF_DRAW_WAVEFORM "draw_waveform"
+#define PROF_HIS_RENDER "his_render"
+#define PROF_DRAW_HISTOGRAM "draw_histogram"
+#define PROF_ROI_RENDER "roi_render"
+#define PROF_DRAW "draw"
+#define PROF_DRAW_GRATICULE "graticule"
+
 /* One staged surface of the ring: what gs_stage_texture + gs_stagesurface_map hand to the
  * pipeline thread in the reference (src/common.h:34-44, src/common.c:343-364). */
 struct cm_surface_queue_item {
@@ -76,6 +102,9 @@ struct cm_source {
 	uint32_t flags;
 	bool bypass;
 
+	obs_source_t *self, *target; /* the scope's own source and the one it watches (a weak reference in the reference) */
+	bool enumerating;
+
 	uint64_t frames_dropped, frames_processed;
 	uint64_t plane_uploads, plane_reuses; /* host->HBM uploads done / saved by the per-surface cache */
 };
@@ -84,6 +113,8 @@ void cm_create(struct cm_source *src, obs_data_t *settings, obs_source_t *source
 void cm_destroy(struct cm_source *src);                                            /* src/common.c:54-79 */
 void cm_update(struct cm_source *src, obs_data_t *settings);                       /* src/common.c:81-98 */
 void cm_get_defaults(obs_data_t *settings);
+void cm_get_properties(struct cm_source *src, obs_properties_t *props);                     /* src/common.c:112-139 */
+void cm_enum_sources(void *data, obs_source_enum_proc_t enum_callback, void *param);        /* src/common.c:98-110 */
 void cm_request(struct cm_source *src, cm_surface_cb_t callback, void *data);      /* src/common.c:615-620 */
 void cm_tick(void *data, float unused);                                            /* src/common.c:575-595 */
 

@@ -7,6 +7,7 @@
  * callbacks are void; a failed frame leaves the previous table on screen).
  */
 #include "scope_sources.h"
+#include "scope_graticule.h"
 
 #include <math.h>
 #include <string.h>
@@ -79,15 +80,44 @@ static void vss_destroy(void *data)
 	bfree(src);
 }
 
-static void vss_get_defaults(obs_data_t *settings)
+static void vss_get_defaults_v1(obs_data_t *settings)
 {
 	cm_get_defaults(settings);
-	obs_data_set_default_int(settings, "intensity", 25); /* src/vectorscope.c:158 */
-	obs_data_set_default_int(settings, "color_type", 1); /* color_type_uv, :166 */
+	obs_data_set_default_int(settings, "intensity", 25);          /* src/vectorscope.c:158 */
+	obs_data_set_default_int(settings, "graticule", 1 | SCOPE_GRATICULE_IQ); /* :159 */
+	obs_data_set_default_int(settings, "graticule_skintone_color", SCOPE_SKIN_TONE_LINE); /* :160 */
 }
 
-void vss_mouse_wheel(void *data, int x_delta, int y_delta)
+static void vss_get_defaults(obs_data_t *settings)
 {
+	vss_get_defaults_v1(settings);
+	obs_data_set_default_int(settings, "color_type", 1); /* color_type_uv, :166; version 1 sources stay white */
+}
+
+/* src/vectorscope.c:169-196 minus the colour picker of the skin-tone line */
+static obs_properties_t *vss_get_properties(void *data)
+{
+	struct vss_source *src = data;
+	obs_properties_t *props = obs_properties_create();
+	cm_get_properties(&src->cm, props);
+	obs_properties_add_int(props, "intensity", obs_module_text("Intensity"), 1, 255, 1);
+	obs_property_t *prop = obs_properties_add_list(props, "color_type", obs_module_text("VS.Prop.ColorType"),
+						       OBS_COMBO_TYPE_LIST, OBS_COMBO_FORMAT_INT);
+	obs_property_list_add_int(prop, obs_module_text("VS.Prop.ColorType.White"), 0);
+	obs_property_list_add_int(prop, obs_module_text("VS.Prop.ColorType.UV"), 1);
+	prop = obs_properties_add_list(props, "graticule", obs_module_text("Graticule"), OBS_COMBO_TYPE_LIST,
+				       OBS_COMBO_FORMAT_INT);
+	obs_property_list_add_int(prop, obs_module_text("None"), 0);
+	obs_property_list_add_int(prop, obs_module_text("Amber"), 1);
+	obs_property_list_add_int(prop, obs_module_text("Amber, IQ"), 1 + SCOPE_GRATICULE_IQ);
+	obs_property_list_add_int(prop, obs_module_text("Green"), 2);
+	obs_property_list_add_int(prop, obs_module_text("Green, IQ"), 2 + SCOPE_GRATICULE_IQ);
+	return props;
+}
+
+void vss_mouse_wheel(void *data, const struct obs_mouse_event *event, int x_delta, int y_delta)
+{
+	UNUSED_PARAMETER(event);
 	UNUSED_PARAMETER(x_delta);
 	struct vss_source *src = data;
 	src->zoom *= expf((float)y_delta * 5e-4f); /* src/vectorscope.c:479 */
@@ -128,8 +158,10 @@ void vss_surface_cb(void *data, struct cm_surface_data *surface_data)
 	if (!src->tex_buf[src->w_tex_buf])
 		src->tex_buf[src->w_tex_buf] = bzalloc(VS_SIZE * VS_SIZE);
 
-	/* was: vss_draw_vectorscope(src->tex_buf[src->w_tex_buf], surface_data) */
+	/* was: vss_draw_vectorscope(src->tex_buf[src->w_tex_buf], surface_data), in the same profiler zone */
+	PROFILE_START(PROF_DRAW_VECTORSCOPE);
 	const int st = scope_vectorscope(cm_gpu(), as_scope(surface_data), 0, src->tex_buf[src->w_tex_buf]);
+	PROFILE_END(PROF_DRAW_VECTORSCOPE);
 	if (st != SCOPE_OK) {
 		log_failure("scope_vectorscope", st);
 		return; /* keep showing the previous table */
@@ -147,6 +179,25 @@ static void scope_render_nothing(void *data, gs_effect_t *effect)
 	UNUSED_PARAMETER(effect);
 }
 
+/* src/vectorscope.c:484-500: settings saved by plugin versions before "color_type" existed keep the white trace */
+const struct obs_source_info colormonitor_vectorscope_v1 = {
+	.id = "vectorscope_source",
+	.type = OBS_SOURCE_TYPE_INPUT,
+	.output_flags = OBS_SOURCE_VIDEO | OBS_SOURCE_CUSTOM_DRAW | OBS_SOURCE_INTERACTION | OBS_SOURCE_CAP_OBSOLETE,
+	.get_name = vss_get_name,
+	.create = vss_create,
+	.destroy = vss_destroy,
+	.update = vss_update,
+	.get_defaults = vss_get_defaults_v1,
+	.get_properties = vss_get_properties,
+	.get_width = vss_get_width,
+	.get_height = vss_get_width,
+	.enum_active_sources = cm_enum_sources,
+	.video_render = vss_render,
+	.video_tick = cm_tick,
+	.mouse_wheel = vss_mouse_wheel,
+};
+
 const struct obs_source_info colormonitor_vectorscope_v2 = {
 	.id = "vectorscope_source",
 	.version = 2,
@@ -157,10 +208,13 @@ const struct obs_source_info colormonitor_vectorscope_v2 = {
 	.destroy = vss_destroy,
 	.update = vss_update,
 	.get_defaults = vss_get_defaults,
+	.get_properties = vss_get_properties,
 	.get_width = vss_get_width,
 	.get_height = vss_get_width,
+	.enum_active_sources = cm_enum_sources,
 	.video_render = vss_render,
 	.video_tick = cm_tick,
+	.mouse_wheel = vss_mouse_wheel,
 };
 
 /* -- waveform ----------------------------------------------------------------------------------------- */
@@ -202,6 +256,32 @@ static void wvs_destroy(void *data)
 	bfree(src->tex_buf[1]);
 	bfree(src->pic.rgba);
 	bfree(src);
+}
+
+/* src/waveform.c:133-170 */
+static obs_properties_t *wvs_get_properties(void *data)
+{
+	struct wvs_source *src = data;
+	obs_properties_t *props = obs_properties_create();
+	cm_get_properties(&src->cm, props);
+	obs_property_t *prop = obs_properties_add_list(props, "display", obs_module_text("Display"), OBS_COMBO_TYPE_LIST,
+						       OBS_COMBO_FORMAT_INT);
+	obs_property_list_add_int(prop, obs_module_text("Overlay"), 0);
+	obs_property_list_add_int(prop, obs_module_text("Stack"), 1);
+	obs_property_list_add_int(prop, obs_module_text("Parade"), 2);
+	prop = obs_properties_add_list(props, "components", obs_module_text("Components"), OBS_COMBO_TYPE_LIST,
+				       OBS_COMBO_FORMAT_INT);
+	obs_property_list_add_int(prop, obs_module_text("RGB"), COMP_RGB);
+	obs_property_list_add_int(prop, obs_module_text("Luma"), COMP_Y);
+	obs_property_list_add_int(prop, obs_module_text("Chroma"), COMP_UV);
+	obs_property_list_add_int(prop, obs_module_text("YUV"), COMP_YUV);
+	obs_properties_add_int(props, "intensity", obs_module_text("Intensity"), 1, 255, 1);
+	prop = obs_properties_add_list(props, "graticule_lines", obs_module_text("Graticule"), OBS_COMBO_TYPE_LIST,
+				       OBS_COMBO_FORMAT_INT);
+	static const int steps[] = {0, 1, 2, 4, 5, 10}; /* none, every 100 / 50 / 25 / 20 / 10 % */
+	for (size_t i = 0; i < sizeof steps / sizeof steps[0]; i++)
+		obs_property_list_add_int(prop, "Graticule.Step", steps[i]);
+	return props;
 }
 
 static void wvs_get_defaults(obs_data_t *settings)
@@ -270,8 +350,10 @@ void wvs_surface_cb(void *data, struct cm_surface_data *surface_data)
 
 	ensure_tex_buf_size(src, surface_data->width, src->w_tex_buf);
 
-	/* was: wvs_draw_waveform(src, src->tex_buf[src->w_tex_buf], surface_data) */
+	/* was: wvs_draw_waveform(src, src->tex_buf[src->w_tex_buf], surface_data), in the same profiler zone */
+	PROFILE_START(PROF_DRAW_WAVEFORM);
 	const int st = scope_waveform(cm_gpu(), as_scope(surface_data), src->components, 0, src->tex_buf[src->w_tex_buf]);
+	PROFILE_END(PROF_DRAW_WAVEFORM);
 	if (st != SCOPE_OK) {
 		log_failure("scope_waveform", st);
 		return;
@@ -288,8 +370,10 @@ const struct obs_source_info colormonitor_waveform = {
 	.destroy = wvs_destroy,
 	.update = wvs_update,
 	.get_defaults = wvs_get_defaults,
+	.get_properties = wvs_get_properties,
 	.get_width = wvs_get_width,
 	.get_height = wvs_get_height,
+	.enum_active_sources = cm_enum_sources,
 	.video_render = wvs_render,
 	.video_tick = cm_tick,
 };
@@ -337,6 +421,34 @@ static void his_destroy(void *data)
 	bfree(src->tex_buf[1]);
 	bfree(src->pic.rgba);
 	bfree(src);
+}
+
+/* src/histogram.c:233-302, the settings this path reads */
+static obs_properties_t *his_get_properties(void *data)
+{
+	struct his_source *src = data;
+	obs_properties_t *props = obs_properties_create();
+	cm_get_properties(&src->cm, props);
+	obs_property_t *prop = obs_properties_add_list(props, "display", obs_module_text("Display"), OBS_COMBO_TYPE_LIST,
+						       OBS_COMBO_FORMAT_INT);
+	obs_property_list_add_int(prop, obs_module_text("Overlay"), 0);
+	obs_property_list_add_int(prop, obs_module_text("Stack"), 1);
+	obs_property_list_add_int(prop, obs_module_text("Parade"), 2);
+	prop = obs_properties_add_list(props, "components", obs_module_text("Components"), OBS_COMBO_TYPE_LIST,
+				       OBS_COMBO_FORMAT_INT);
+	obs_property_list_add_int(prop, obs_module_text("RGB"), COMP_RGB);
+	obs_property_list_add_int(prop, obs_module_text("Luma"), COMP_Y);
+	obs_property_list_add_int(prop, obs_module_text("Chroma"), COMP_UV);
+	obs_property_list_add_int(prop, obs_module_text("YUV"), COMP_YUV);
+	obs_properties_add_int(props, "level_height", obs_module_text("Height"), 50, 2048, 1);
+	obs_properties_add_bool(props, "logscale", obs_module_text("Log scale"));
+	prop = obs_properties_add_list(props, "level_mode", obs_module_text("Level"), OBS_COMBO_TYPE_LIST, OBS_COMBO_FORMAT_INT);
+	obs_property_list_add_int(prop, obs_module_text("Auto"), 0);
+	obs_property_list_add_int(prop, obs_module_text("Pixels"), 1);
+	obs_property_list_add_int(prop, obs_module_text("Ratio"), 2);
+	obs_properties_add_int(props, "level_fixed_value", obs_module_text("Pixels"), 1, 1 << 30, 1);
+	obs_properties_add_int(props, "level_ratio_value", obs_module_text("Ratio"), 1, 1000, 1);
+	return props;
 }
 
 static void his_get_defaults(obs_data_t *settings)
@@ -397,10 +509,12 @@ void his_surface_cb(void *data, struct cm_surface_data *surface_data)
 	if (!src->tex_buf[src->w_tex_buf])
 		src->tex_buf[src->w_tex_buf] = bzalloc(sizeof(float) * HI_SIZE * 4);
 
-	/* was: his_draw_histogram(src, tex_buf, hi_max, surface_data) */
+	/* was: his_draw_histogram(src, tex_buf, hi_max, surface_data), in the same profiler zone */
+	PROFILE_START(PROF_DRAW_HISTOGRAM);
 	const int st = scope_histogram(cm_gpu(), as_scope(surface_data), src->components, src->logscale,
 				       src->level_fixed_value, src->level_ratio_value, 0, src->tex_buf[src->w_tex_buf],
 				       src->hi_max[src->w_tex_buf]);
+	PROFILE_END(PROF_DRAW_HISTOGRAM);
 	if (st != SCOPE_OK) {
 		log_failure("scope_histogram", st);
 		return;
@@ -417,8 +531,10 @@ const struct obs_source_info colormonitor_histogram = {
 	.destroy = his_destroy,
 	.update = his_update,
 	.get_defaults = his_get_defaults,
+	.get_properties = his_get_properties,
 	.get_width = his_get_width,
 	.get_height = his_get_height,
+	.enum_active_sources = cm_enum_sources,
 	.video_render = his_render,
 	.video_tick = cm_tick,
 };
@@ -563,6 +679,16 @@ static void roi_tick(void *data, float unused)
 	roi_update_flags(src);
 }
 
+/* src/roi.c:79-96 */
+static obs_properties_t *roi_get_properties(void *data)
+{
+	struct roi_source *src = data;
+	obs_properties_t *props = obs_properties_create();
+	cm_get_properties(&src->cm, props);
+	obs_properties_add_int(props, "interleave", obs_module_text("Interleave"), 0, 1, 1);
+	return props;
+}
+
 static uint32_t roi_get_size(void *data)
 {
 	UNUSED_PARAMETER(data);
@@ -578,8 +704,10 @@ const struct obs_source_info colormonitor_roi = {
 	.destroy = roi_destroy,
 	.update = roi_update,
 	.get_defaults = roi_get_defaults,
+	.get_properties = roi_get_properties,
 	.get_width = roi_get_size,
 	.get_height = roi_get_size,
+	.enum_active_sources = cm_enum_sources,
 	.video_render = scope_render_nothing,
 	.video_tick = roi_tick,
 };
@@ -590,6 +718,7 @@ bool obs_module_load(void)
 {
 	if (cm_gpu_open(0) != SCOPE_OK)
 		return false; /* no GPU: the module refuses to load rather than fall back to a CPU loop */
+	obs_register_source(&colormonitor_vectorscope_v1); /* src/plugin-main.c:82-85: the obsolete version stays loadable */
 	obs_register_source(&colormonitor_vectorscope_v2);
 	obs_register_source(&colormonitor_waveform);
 	obs_register_source(&colormonitor_histogram);

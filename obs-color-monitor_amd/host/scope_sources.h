@@ -38,7 +38,7 @@ struct vss_source {
 	struct scope_picture pic;
 };
 /* vss_mouse_wheel (src/vectorscope.c:473-483): zoom *= exp(y_delta * 5e-4), never below 1. */
-void vss_mouse_wheel(void *data, int x_delta, int y_delta);
+void vss_mouse_wheel(void *data, const struct obs_mouse_event *event, int x_delta, int y_delta);
 
 struct wvs_source {
 	struct cm_source cm;
@@ -75,6 +75,7 @@ struct roi_source {
 	size_t n_sources;
 };
 
+extern const struct obs_source_info colormonitor_vectorscope_v1; /* id "vectorscope_source", obsolete (src/vectorscope.c:484-500) */
 extern const struct obs_source_info colormonitor_vectorscope_v2; /* id "vectorscope_source", version 2 */
 extern const struct obs_source_info colormonitor_waveform;       /* id "waveform_source" */
 extern const struct obs_source_info colormonitor_histogram;      /* id "histogram_source" */

@@ -14,6 +14,9 @@ CB = {
     "defaults": C.CFUNCTYPE(None, C.c_void_p),
     "name": C.CFUNCTYPE(C.c_char_p, C.c_void_p),
     "render": C.CFUNCTYPE(None, C.c_void_p, C.c_void_p),
+    "props": C.CFUNCTYPE(C.c_void_p, C.c_void_p),
+    "enum": C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p),
+    "wheel": C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int),
 }
 
 
@@ -21,7 +24,8 @@ class SourceInfo(C.Structure):  # obs_shim.h's struct obs_source_info
     _fields_ = [("id", C.c_char_p), ("version", C.c_uint32), ("type", C.c_int), ("output_flags", C.c_uint32),
                 ("get_name", CB["name"]), ("create", CB["create"]), ("destroy", CB["destroy"]),
                 ("get_width", CB["size"]), ("get_height", CB["size"]), ("get_defaults", CB["defaults"]),
-                ("update", CB["update"]), ("video_tick", CB["tick"]), ("video_render", CB["render"])]
+                ("update", CB["update"]), ("video_tick", CB["tick"]), ("video_render", CB["render"]),
+                ("get_properties", CB["props"]), ("enum_active_sources", CB["enum"]), ("mouse_wheel", CB["wheel"])]
 
 
 class Host:
@@ -110,12 +114,74 @@ class Host:
         return (np.ctypeslib.as_array(p, (256, 4)).copy() if p else None), list(hi)
 
 
+def check_source_surface(host):
+    """The outer obs_source_info surface: the obsolete v1 table, get_properties, enum_active_sources, mouse_wheel."""
+    L = host.L
+    L.fake_obs_find_source_version.restype = C.POINTER(SourceInfo)
+    L.fake_obs_find_source_version.argtypes = [C.c_char_p, C.c_uint32]
+    L.fake_obs_properties_count.argtypes = [C.c_void_p]
+    L.fake_obs_property.restype = C.c_char_p
+    L.fake_obs_property.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 4
+    L.obs_properties_destroy.argtypes = [C.c_void_p]
+    L.obs_data_get_int.restype = C.c_longlong
+    L.obs_data_get_int.argtypes = [C.c_void_p, C.c_char_p]
+    v1 = L.fake_obs_find_source_version(b"vectorscope_source", 0).contents
+    v2 = L.fake_obs_find_source_version(b"vectorscope_source", 2).contents
+    OBSOLETE, INTERACTION = 1 << 9, 1 << 5
+    assert v1.output_flags & OBSOLETE and not v2.output_flags & OBSOLETE and v1.output_flags & INTERACTION
+    for info, color_type in ((v1, 0), (v2, 1)):  # settings saved before "color_type" existed keep the white trace
+        d = L.fake_obs_data_create()
+        info.get_defaults(d)
+        assert L.obs_data_get_int(d, b"color_type") == color_type
+        assert L.obs_data_get_int(d, b"intensity") == 25 and L.obs_data_get_int(d, b"graticule") == 1 | 256
+        assert L.obs_data_get_int(d, b"graticule_skintone_color") == 0x0054FF
+        L.fake_obs_data_release(d)
+    want = {
+        b"vectorscope_source": {"target_scale": (0, 1, 128), "bypass": (1, 0, 0), "intensity": (0, 1, 255), "color_type": (2, 0, 1),
+                                "graticule": (2, 0, 2 + 256)},
+        b"waveform_source": {"target_scale": (0, 1, 128), "bypass": (1, 0, 0), "display": (2, 0, 2), "components": (2, 0x07, 0x70),
+                             "intensity": (0, 1, 255), "graticule_lines": (2, 0, 10)},
+        b"histogram_source": {"target_scale": (0, 1, 128), "bypass": (1, 0, 0), "display": (2, 0, 2), "components": (2, 0x07, 0x70),
+                              "level_height": (0, 50, 2048), "logscale": (1, 0, 0), "level_mode": (2, 0, 2),
+                              "level_fixed_value": (0, 1, 1 << 30), "level_ratio_value": (0, 1, 1000)},
+        b"colormonitor_roi": {"target_scale": (0, 1, 128), "interleave": (0, 0, 1)},  # an ROI has no bypass (common.c:125-126)
+    }
+    seen = []
+    ENUM = CB["enum"]
+    for sid, props_want in want.items():
+        info, obj = host.create(sid.decode())
+        assert info.get_properties and info.enum_active_sources
+        props = info.get_properties(obj)
+        got = {}
+        for i in range(L.fake_obs_properties_count(props)):
+            kind, lo, hi, n = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            name = L.fake_obs_property(props, i, C.byref(kind), C.byref(lo), C.byref(hi), C.byref(n))
+            got[name.decode()] = (kind.value, lo.value, hi.value)
+        L.obs_properties_destroy(props)
+        assert got == props_want, (sid, got)
+        info.enum_active_sources(obj, ENUM(lambda parent, child, param: seen.append(child)), None)  # no target set: nothing
+        info.destroy(obj)
+    assert seen == []
+
+
+def check_profile_zones(host, expect_at_least):
+    """The GPU calls sit in the reference's profiler zones (ENABLE_PROFILE builds): every start has its end."""
+    L = host.L
+    L.fake_obs_profile_zone.restype = C.c_long
+    L.fake_obs_profile_zone.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    for name, least in expect_at_least.items():
+        bal = C.c_int(0)
+        n = L.fake_obs_profile_zone(name.encode(), C.byref(bal))
+        assert n >= least and bal.value == 1, (name, n, bal.value)
+
+
 def run_host_checks(host, oracle, w=96, h=40):
     ids = [b"vectorscope_source", b"waveform_source", b"histogram_source", b"colormonitor_roi"]
-    assert host.L.fake_obs_source_count() == 4
+    assert host.L.fake_obs_source_count() == 5  # the obsolete version-1 vectorscope stays registered (plugin-main.c:82-85)
     for i in ids:
         assert host.L.fake_obs_find_source(i).contents.id == i
     assert host.L.fake_obs_find_source(b"vectorscope_source").contents.version == 2
+    check_source_surface(host)
 
     frames = []
     for k, dist in enumerate((1, 2, 5)):
@@ -166,12 +232,12 @@ def run_host_checks(host, oracle, w=96, h=40):
     vinfo.video_render(vss, None)
     assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2))
     # the mouse wheel zooms the vectorscope about its centre (vss_mouse_wheel, vectorscope.c:473-483)
-    host.L.vss_mouse_wheel.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    host.L.vss_mouse_wheel(vss, 0, 1400)
+    assert vinfo.mouse_wheel  # the table carries it, with the reference's signature (src/vectorscope.c:473)
+    vinfo.mouse_wheel(vss, None, 0, 1400)
     zoom = float(np.float32(1.0) * np.exp(np.float32(1400 * 5e-4)).astype(np.float32))
     vinfo.video_render(vss, None)
     assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2, zoom))
-    host.L.vss_mouse_wheel(vss, 0, -100000)  # never below 1
+    vinfo.mouse_wheel(vss, None, 0, -100000)  # never below 1
     vinfo.video_render(vss, None)
     assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2))
     winfo.video_render(wvs, None)
@@ -259,3 +325,6 @@ def run_host_checks(host, oracle, w=96, h=40):
         host.L.roi_unregister_source(roi, host.L.scope_host_cm(obj))
     for info_, obj in ((winfo, wvs), (hinfo, his), (roi_info, roi)):
         info_.destroy(obj)
+    # every GPU call above ran inside the profiler zone the reference gives the CPU loop it replaces
+    check_profile_zones(host, {"cm_pipeline_thread_loop": 5, "draw_vectorscope": 3, "draw_waveform": 3, "draw_histogram": 2,
+                               "render_target": 2, "convert_yuv": 1, "stage_surface": 2})
