@@ -245,6 +245,35 @@ int scope_display_histogram(scope_ctx *ctx, const float *tex, const uint32_t *hi
 void scope_display_size(uint32_t base_w, uint32_t base_h, uint32_t components, int display, uint32_t *out_w,
 			uint32_t *out_h);
 
+/* ---- graticule over a finished picture -----------------------------------------------------------
+ * Replaces the two graticule draws of the scopes' video_render: the textured label quads of the vectorscope
+ * (DrawGraticule, data/vectorscope.effect:35-39 + src/vectorscope.c:447-454) and the GS_LINES lists drawn with OBS's
+ * "Solid" effect (src/vectorscope.c:456-462, src/waveform.c:308-332, src/histogram.c:492-520).  The geometry -- where
+ * the brackets, the skin-tone line and the scale lines go -- is the host's (obs-color-monitor_amd/host/
+ * scope_graticule.h restates the reference's vertex buffers); this call rasterises it into the RGBA8 picture a
+ * scope_display_* call produced: labels first, then the line segments (vertices 2k, 2k+1), each blended in list order
+ * with OBS's default source-alpha blend.  argb = what the reference hands gs_effect_set_color (amber 0x80FFBF00, green
+ * 0x8000FF00, src/vectorscope.c:141-144, src/waveform.c:311).
+ * PINNED, because the reference leaves it to the GPU OBS runs on: the rasterisation rule (pixel centres, major-axis
+ * sampling, half-open ends: csrc/scope_display.hip) and the label glyphs (this build's own 5x7 letters "R", "B", "Cy",
+ * "Yl", "G", "Mg", one 16x16 cell each, in the order of scope_graticule_vectorscope's labels; the reference's
+ * vectorscope-graticule.png is not copied).  The picture is a host or a device buffer (SCOPE_IN_DEVICE |
+ * SCOPE_OUT_DEVICE together); the lists are host memory; the call is synchronous. */
+struct scope_graticule_vertex {
+	float x, y;
+};
+struct scope_graticule_label {
+	float x, y, w, h;     /* quad in picture pixels */
+	float u0, v0, u1, v1; /* its range in the label strip, 0..1 */
+};
+#define SCOPE_LABEL_STRIP_W 96
+#define SCOPE_LABEL_STRIP_H 16
+int scope_display_graticule(scope_ctx *ctx, uint8_t *rgba, uint32_t width, uint32_t height,
+			    const struct scope_graticule_label *labels, uint32_t n_labels,
+			    const struct scope_graticule_vertex *lines, uint32_t n_line_vertices, uint32_t argb, uint32_t flags);
+/* The glyph texels (0 or 1) the labels are cut from: uint8[SCOPE_LABEL_STRIP_H][SCOPE_LABEL_STRIP_W]. */
+void scope_graticule_label_strip(uint8_t *alpha);
+
 /* ---- frame pipeline: the staging ring moved into HBM ----------------------------------------
  * Replaces the reference's 3-slot staging ring + pipeline thread (CM_SURFACE_QUEUE_SIZE,
  * src/common.h:46; cm_render_target / cm_pipeline_thread, src/common.c:223-403) for a host that

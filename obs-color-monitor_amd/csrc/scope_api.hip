@@ -1360,6 +1360,69 @@ int scope_display_histogram(scope_ctx *ctx, const float *tex, const uint32_t *hi
 			   });
 }
 
+/* ---- graticule over a finished picture ------------------------------------------------------------------------- */
+
+void scope_graticule_label_strip(uint8_t *alpha)
+{
+	if (alpha)
+		scope_graticule_strip(alpha);
+}
+
+int scope_display_graticule(scope_ctx *ctx, uint8_t *rgba, uint32_t width, uint32_t height,
+			    const struct scope_graticule_label *labels, uint32_t n_labels,
+			    const struct scope_graticule_vertex *lines, uint32_t n_line_vertices, uint32_t argb, uint32_t flags)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if (!rgba || (n_labels && !labels) || (n_line_vertices && !lines) || (n_line_vertices & 1u))
+		return fail(ctx, SCOPE_EINVAL, "scope_display_graticule: NULL list or an odd number of line vertices", hipSuccess);
+	const uint32_t dev = flags & (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE);
+	if (dev != 0 && dev != (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE))
+		return fail(ctx, SCOPE_EINVAL, "the picture is a host or a device buffer, not a mix", hipSuccess);
+	if ((uint64_t)width * height >= (1ull << 30) || n_labels > 4096 || n_line_vertices > 65536)
+		return fail(ctx, SCOPE_EINVAL, "scope_display_graticule: picture or list too large", hipSuccess);
+	const size_t pic_bytes = (size_t)width * height * 4;
+	if (!pic_bytes || (!n_labels && !n_line_vertices))
+		return SCOPE_OK;
+	/* the lists and the glyph strip travel together: [quads | segments | strip] */
+	const size_t quad_bytes = (size_t)n_labels * sizeof(struct scope_graticule_label);
+	const size_t seg_bytes = (size_t)n_line_vertices * sizeof(struct scope_graticule_vertex);
+	const size_t strip_at = round_up(quad_bytes + seg_bytes, 16), strip_bytes = 96 * 16;
+	const size_t list_bytes = strip_at + strip_bytes;
+	uint8_t *host = (uint8_t *)malloc(list_bytes);
+	if (!host)
+		return SCOPE_ENOMEM;
+	if (quad_bytes)
+		memcpy(host, labels, quad_bytes);
+	if (seg_bytes)
+		memcpy(host + quad_bytes, lines, seg_bytes);
+	scope_graticule_strip(host + strip_at);
+	st = grow(ctx, &ctx->stage_in, &ctx->stage_in_bytes, round_up(list_bytes, 256));
+	if (!st && !dev)
+		st = grow(ctx, &ctx->stage_out, &ctx->stage_out_bytes, round_up(pic_bytes, 256));
+	if (st) {
+		free(host);
+		return st;
+	}
+	hipError_t e = hipMemcpyAsync(ctx->stage_in, host, list_bytes, hipMemcpyHostToDevice, ctx->stream);
+	uint8_t *pic = dev ? rgba : ctx->stage_out;
+	if (e == hipSuccess && !dev)
+		e = hipMemcpyAsync(pic, rgba, pic_bytes, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess)
+		e = scope_launch_graticule(pic, width, height, (const float *)ctx->stage_in, n_labels,
+					   (const float *)(ctx->stage_in + quad_bytes), n_line_vertices / 2, ctx->stage_in + strip_at, argb,
+					   ctx->stream);
+	if (e == hipSuccess && !dev)
+		e = hipMemcpyAsync(rgba, pic, pic_bytes, hipMemcpyDeviceToHost, ctx->stream);
+	/* `host` is pageable: the upload has consumed it only once the stream has drained */
+	const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+	free(host);
+	if (e != hipSuccess || e2 != hipSuccess)
+		return fail(ctx, SCOPE_EIO, "scope_display_graticule", e != hipSuccess ? e : e2);
+	return SCOPE_OK;
+}
+
 /* ---- frame pipeline ---------------------------------------------------------------------------- */
 
 #define SCOPE_PIPE_MAX_DEPTH 16

@@ -140,4 +140,12 @@ hipError_t scope_launch_display_wvs(const uint8_t *table, uint8_t *out, uint32_t
 hipError_t scope_launch_display_his(const float *tex, uint8_t *out, float hm0, float hm1, float hm2,
 				    uint32_t n_components, int display, uint32_t out_w, uint32_t out_h, hipStream_t st);
 
+
+/* Graticule over a finished picture (RGBA8, bytes R,G,B,A): n_quads label quads (8 floats each: x, y, w, h, u0, v0, u1,
+ * v1) then n_segs line segments (4 floats each), blended in list order; strip = the 96x16 glyph texels of
+ * scope_graticule_strip on the device; argb as gs_effect_set_color takes it.  Rasterisation rule: scope_display.hip. */
+hipError_t scope_launch_graticule(uint8_t *pic, uint32_t w, uint32_t h, const float *quads, uint32_t n_quads, const float *segs,
+				  uint32_t n_segs, const uint8_t *strip, uint32_t argb, hipStream_t st);
+void scope_graticule_strip(uint8_t *alpha /* [16][96] */);
+
 #endif

@@ -57,6 +57,16 @@ static void vss_update(void *data, obs_data_t *settings)
 	if (src->intensity < 1)
 		src->intensity = 1;
 	src->color_type = (int)obs_data_get_int(settings, "color_type");
+	src->graticule = (int)obs_data_get_int(settings, "graticule"); /* :135-145 */
+	switch (src->graticule & (int)SCOPE_GRATICULE_COLOR_MASK) {
+	case 1:
+		src->graticule_color = 0x80FFBF00; /* amber */
+		break;
+	case 2:
+		src->graticule_color = 0x8000FF00; /* green */
+		break;
+	}
+	src->graticule_skintone_color = (uint32_t)obs_data_get_int(settings, "graticule_skintone_color") & 0xFFFFFF; /* :147 */
 }
 
 static void *vss_create(obs_data_t *settings, obs_source_t *source)
@@ -125,8 +135,8 @@ void vss_mouse_wheel(void *data, const struct obs_mouse_event *event, int x_delt
 		src->zoom = 1.0f;
 }
 
-/* src/vectorscope.c:382-471 minus the graticule draw (geometry: scope_graticule.h): upload, zoom transform and
- * PSDrawBare become one GPU pass */
+/* src/vectorscope.c:382-471: upload, zoom transform and PSDrawBare become one GPU pass, the label quads and the bracket /
+ * skin-tone lines a second one (scope_display_graticule; under a zoom they are scaled about 127.5 like the sprite, :395-408) */
 static void vss_render(void *data, gs_effect_t *effect)
 {
 	UNUSED_PARAMETER(effect);
@@ -137,9 +147,37 @@ static void vss_render(void *data, gs_effect_t *effect)
 	uint8_t *rgba = picture_reserve(&src->pic, VS_SIZE, VS_SIZE);
 	if (!rgba)
 		return;
-	log_failure("scope_display_vectorscope",
-		    scope_display_vectorscope_zoom(cm_gpu(), src->tex_buf[r_tex_buf], src->intensity, src->color_type,
-						   src->tex_cs[r_tex_buf], src->zoom, 0, rgba));
+	PROFILE_START(PROF_VSS_RENDER);
+	PROFILE_START(PROF_DRAW);
+	const int st = scope_display_vectorscope_zoom(cm_gpu(), src->tex_buf[r_tex_buf], src->intensity, src->color_type,
+						      src->tex_cs[r_tex_buf], src->zoom, 0, rgba);
+	PROFILE_END(PROF_DRAW);
+	log_failure("scope_display_vectorscope", st);
+	PROFILE_START(PROF_DRAW_GRATICULE);
+	if (st == SCOPE_OK && src->graticule) { /* :447-464 */
+		struct scope_label labels[SCOPE_VSS_LABELS];
+		struct scope_vertex lines[SCOPE_VSS_LINE_VERTICES_MAX];
+		const uint32_t n = scope_graticule_vectorscope(src->tex_cs[r_tex_buf], (uint32_t)src->graticule,
+							       src->graticule_skintone_color, labels, lines);
+		if (src->zoom > 1.01f) { /* the matrix pushed at :399-404: translate by ofst, scale by zoom */
+			const float ofst = 127.5f * (1.0f - src->zoom);
+			for (uint32_t i = 0; i < SCOPE_VSS_LABELS; i++) {
+				labels[i].x = labels[i].x * src->zoom + ofst;
+				labels[i].y = labels[i].y * src->zoom + ofst;
+				labels[i].w *= src->zoom;
+				labels[i].h *= src->zoom;
+			}
+			for (uint32_t i = 0; i < n; i++) {
+				lines[i].x = lines[i].x * src->zoom + ofst;
+				lines[i].y = lines[i].y * src->zoom + ofst;
+			}
+		}
+		log_failure("scope_display_graticule",
+			    scope_display_graticule(cm_gpu(), rgba, VS_SIZE, VS_SIZE, (const struct scope_graticule_label *)labels,
+						    SCOPE_VSS_LABELS, (const struct scope_graticule_vertex *)lines, n, src->graticule_color, 0));
+	}
+	PROFILE_END(PROF_DRAW_GRATICULE);
+	PROFILE_END(PROF_VSS_RENDER);
 }
 
 static uint32_t vss_get_width(void *data)
@@ -237,6 +275,7 @@ static void wvs_update(void *data, obs_data_t *settings)
 	src->intensity = (int)obs_data_get_int(settings, "intensity");
 	if (src->intensity < 1)
 		src->intensity = 1;
+	src->graticule_lines = (int)obs_data_get_int(settings, "graticule_lines"); /* src/waveform.c:108 */
 }
 
 static void *wvs_create(obs_data_t *settings, obs_source_t *source)
@@ -290,6 +329,7 @@ static void wvs_get_defaults(obs_data_t *settings)
 	obs_data_set_default_int(settings, "components", COMP_RGB); /* src/waveform.c:115 */
 	obs_data_set_default_int(settings, "display", 0);
 	obs_data_set_default_int(settings, "intensity", 51); /* src/waveform.c:114 */
+	obs_data_set_default_int(settings, "graticule_lines", 5); /* :116 */
 }
 
 /* src/waveform.c:334-392 minus graticule: upload + DrawOverlay/Stack/Parade become one GPU pass */
@@ -305,8 +345,28 @@ static void wvs_render(void *data, gs_effect_t *effect)
 	uint8_t *rgba = picture_reserve(&src->pic, w, h);
 	if (!rgba || !w || !h)
 		return;
-	log_failure("scope_display_waveform", scope_display_waveform(cm_gpu(), src->tex_buf[r], src->tex_buf_width[r],
-								      src->components, src->display, src->intensity, 0, rgba));
+	PROFILE_START(PROF_WVS_RENDER);
+	PROFILE_START(PROF_DRAW);
+	const int st = scope_display_waveform(cm_gpu(), src->tex_buf[r], src->tex_buf_width[r], src->components, src->display,
+					      src->intensity, 0, rgba);
+	PROFILE_END(PROF_DRAW);
+	log_failure("scope_display_waveform", st);
+	PROFILE_START(PROF_DRAW_GRATICULE);
+	if (st == SCOPE_OK && src->graticule_lines > 0) { /* src/waveform.c:381-389 */
+		uint32_t nc = 0;
+		for (uint32_t c = src->components & 0x77u; c; c >>= 1)
+			nc += c & 1u;
+		struct scope_vertex lines[2 * 3 * 64];
+		const uint32_t max = sizeof lines / sizeof lines[0];
+		uint32_t n = scope_graticule_waveform(src->graticule_lines, src->display, nc, src->tex_buf_width[r], lines, max);
+		if (n > max)
+			n = max;
+		log_failure("scope_display_graticule",
+			    scope_display_graticule(cm_gpu(), rgba, w, h, NULL, 0, (const struct scope_graticule_vertex *)lines, n,
+						    0x80FFBF00 /* amber, :311 */, 0));
+	}
+	PROFILE_END(PROF_DRAW_GRATICULE);
+	PROFILE_END(PROF_WVS_RENDER);
 }
 
 static uint32_t wvs_get_width(void *data)
@@ -402,6 +462,12 @@ static void his_update(void *data, obs_data_t *settings)
 	src->level_height = (int)obs_data_get_int(settings, "level_height"); /* src/histogram.c:123 */
 	if (src->level_height < 1)
 		src->level_height = 1;
+	/* :137-159; the reference's step settings are doubles, the shim's settings are integers: the step travels in 1/1000 */
+	src->graticule_vertical_lines = (int)obs_data_get_int(settings, "graticule_vertical_lines");
+	src->graticule_horizontal_step =
+		level_mode == 1   ? (float)obs_data_get_int(settings, "graticule_horizontal_step_fixed_milli") / 1000.0f
+		: level_mode == 2 ? (float)obs_data_get_int(settings, "graticule_horizontal_step_ratio_milli") / 1000.0f
+				  : 0.0f;
 }
 
 static void *his_create(obs_data_t *settings, obs_source_t *source)
@@ -459,6 +525,7 @@ static void his_get_defaults(obs_data_t *settings)
 	obs_data_set_default_int(settings, "level_mode", 0);
 	obs_data_set_default_int(settings, "display", 0);
 	obs_data_set_default_int(settings, "level_height", 200); /* src/histogram.c:168 */
+	obs_data_set_default_int(settings, "graticule_vertical_lines", 5); /* :169 */
 }
 
 static uint32_t his_get_width(void *data)
@@ -490,9 +557,29 @@ static void his_render(void *data, gs_effect_t *effect)
 	uint8_t *rgba = picture_reserve(&src->pic, w, h);
 	if (!rgba || !w || !h)
 		return;
-	log_failure("scope_display_histogram",
-		    scope_display_histogram(cm_gpu(), (const float *)src->tex_buf[r], src->hi_max[r], src->components,
-					    src->display, (uint32_t)src->level_height, 0, rgba));
+	PROFILE_START(PROF_HIS_RENDER);
+	PROFILE_START(PROF_DRAW);
+	const int st = scope_display_histogram(cm_gpu(), (const float *)src->tex_buf[r], src->hi_max[r], src->components,
+					       src->display, (uint32_t)src->level_height, 0, rgba);
+	PROFILE_END(PROF_DRAW);
+	log_failure("scope_display_histogram", st);
+	if (st == SCOPE_OK) { /* src/histogram.c:570-575 */
+		uint32_t nc = 0;
+		for (uint32_t c = src->components & 0x77u; c; c >>= 1)
+			nc += c & 1u;
+		struct scope_vertex lines[2048];
+		const uint32_t max = sizeof lines / sizeof lines[0];
+		uint32_t n = scope_graticule_histogram(src->graticule_vertical_lines, src->graticule_horizontal_step, src->logscale,
+						       src->level_fixed_value, src->level_ratio_value, src->display, nc,
+						       (uint32_t)src->level_height, lines, max);
+		if (n > max)
+			n = max;
+		if (n)
+			log_failure("scope_display_graticule",
+				    scope_display_graticule(cm_gpu(), rgba, w, h, NULL, 0, (const struct scope_graticule_vertex *)lines, n,
+							    0x80FFBF00 /* amber, :495 */, 0));
+	}
+	PROFILE_END(PROF_HIS_RENDER);
 }
 
 void his_surface_cb(void *data, struct cm_surface_data *surface_data)

@@ -35,6 +35,9 @@ struct vss_source {
 	int intensity;  /* src/vectorscope.c:55,129-131 */
 	int color_type; /* 0 white, 1 UV (src/vectorscope.c:36-39) */
 	float zoom;     /* 1.0 on creation (src/vectorscope.c:80); the mouse wheel changes it (:476-482) */
+	int graticule;  /* 0 none; & 3: 1 amber, 2 green; | 256: skin tone line as the I/Q cross (src/vectorscope.c:24-25,135-145) */
+	uint32_t graticule_color;          /* 0xAARRGGBB as handed to gs_effect_set_color */
+	uint32_t graticule_skintone_color; /* 0xBBGGRR */
 	struct scope_picture pic;
 };
 /* vss_mouse_wheel (src/vectorscope.c:473-483): zoom *= exp(y_delta * 5e-4), never below 1. */
@@ -48,6 +51,7 @@ struct wvs_source {
 	uint32_t components;
 	int display;   /* DISP_OVERLAY / DISP_STACK / DISP_PARADE, src/waveform.c:22-24 */
 	int intensity; /* src/waveform.c:104-106 */
+	int graticule_lines; /* src/waveform.c:108: 0 none, else the scale is cut into this many parts */
 	struct scope_picture pic;
 };
 
@@ -62,6 +66,8 @@ struct his_source {
 	bool logscale;
 	int display;
 	int level_height; /* src/histogram.c:53,123 */
+	int graticule_vertical_lines;    /* src/histogram.c:57,158 */
+	float graticule_horizontal_step; /* :58,140-151: in pixels (level_mode 1) or per cent (level_mode 2) */
 	struct scope_picture pic;
 };
 

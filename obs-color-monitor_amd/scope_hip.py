@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect", "scope_pipe_size",
     "scope_region_size", "scope_stage_region", "scope_surface_begin", "scope_surface_end",
     "scope_rccl_unique_id", "scope_rccl_comm_create", "scope_rccl_comm_destroy", "scope_table_allreduce",
+    "scope_display_graticule", "scope_graticule_label_strip",
     "scope_display_vectorscope", "scope_display_vectorscope_zoom", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
 )
 
@@ -141,6 +142,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_display_waveform": (i32, [vp, vp, u32, u32, i32, i32, u32, vp]),
         "scope_display_histogram": (i32, [vp, vp, vp, u32, i32, u32, u32, vp]),
         "scope_display_size": (None, [u32, u32, u32, i32, C.POINTER(u32), C.POINTER(u32)]),
+        "scope_display_graticule": (i32, [vp, vp, u32, u32, vp, u32, vp, u32, u32, u32]),
+        "scope_graticule_label_strip": (None, [vp]),
         "scope_pipe_create": (i32, [vp, C.POINTER(PipeConfig), C.POINTER(vp)]),
         "scope_pipe_destroy": (None, [vp]),
         "scope_pipe_submit": (i32, [vp, vp, u32]),
@@ -413,6 +416,22 @@ class ScopeContext:
         self._check(self.L.scope_display_histogram(self.h, t.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
                                                    components, display, level_height, 0, _hptr(out)))
         return out
+
+    def display_graticule(self, picture, labels=None, lines=None, argb=0x80FFBF00):
+        """Blends label quads (float32 [n, 8]: x, y, w, h, u0, v0, u1, v1) and GS_LINES segments (float32 [2k, 2]) into
+        an RGBA8 host picture [h, w, 4]; returns the new picture."""
+        pic = np.ascontiguousarray(picture, dtype=np.uint8).copy()
+        h, w = pic.shape[0], pic.shape[1]
+        lab = np.ascontiguousarray(labels if labels is not None else np.zeros((0, 8)), dtype=np.float32)
+        lin = np.ascontiguousarray(lines if lines is not None else np.zeros((0, 2)), dtype=np.float32)
+        self._check(self.L.scope_display_graticule(self.h, pic.ctypes.data_as(C.c_void_p), w, h, lab.ctypes.data_as(C.c_void_p),
+                                                   lab.shape[0], lin.ctypes.data_as(C.c_void_p), lin.shape[0], argb, 0))
+        return pic
+
+    def graticule_label_strip(self):
+        strip = np.zeros((16, 96), dtype=np.uint8)
+        self.L.scope_graticule_label_strip(strip.ctypes.data_as(C.c_void_p))
+        return strip
 
     def pack16_dev(self, in_dev, out_dev, n_pairs):
         self._check(self.L.scope_table_pack_u8_u16x2(self.h, _dptr(in_dev), _dptr(out_dev), n_pairs))

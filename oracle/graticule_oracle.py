@@ -116,3 +116,60 @@ def histogram(vertical_lines, horizontal_step, logscale, level_fixed_value, leve
             xoff = F(256 * i) if parade else F(1.0)
             out += _draw(vbuf, (1.0, ycoe, xoff, yoff), 2 if (parade and i) else 0)
     return np.array(out, dtype=F).reshape(-1, 2)
+
+
+# ---- rasterising the lists into a picture ----------------------------------------------------------------------------------
+# The reference leaves this to the GPU OBS runs on (GS_LINES with the "Solid" effect, textured quads with DrawGraticule,
+# default source-alpha blending); the build PINS it (csrc/scope_display.hip states the rule) and this is the same rule
+# written independently in numpy float32: pixel centres, major-axis sampling with half-open ends, floor on the minor axis,
+# labels before lines, list order, every covering primitive blended once.
+
+def _quantise(x):
+    x = np.minimum(np.maximum(x, F(0)), F(1))
+    return (x * F(255) + F(0.5)).astype(np.uint32)  # truncation of a non-negative value = floor
+
+
+def _blend(pic, mask, argb):
+    a = F((argb >> 24) & 0xFF) / F(255)
+    src = [F((argb >> 16) & 0xFF) / F(255), F((argb >> 8) & 0xFF) / F(255), F(argb & 0xFF) / F(255), a]
+    ia = F(1) - a
+    for c in range(4):  # picture bytes R, G, B, A
+        d = pic[..., c].astype(np.float32) / F(255)
+        out = _quantise(F(src[c] * a) + d * ia)
+        pic[..., c] = np.where(mask, out, pic[..., c]).astype(np.uint8)
+
+
+def rasterise(picture, labels, lines, argb, strip):
+    """picture uint8 [h, w, 4] (R,G,B,A); labels float32 [n, 8]; lines float32 [2k, 2]; strip uint8 [16, 96]."""
+    pic = np.array(picture, dtype=np.uint8, copy=True)
+    h, w = pic.shape[:2]
+    cx = (np.arange(w, dtype=np.float32) + F(0.5))[None, :]
+    cy = (np.arange(h, dtype=np.float32) + F(0.5))[:, None]
+    px = np.arange(w, dtype=np.float32)[None, :]
+    py = np.arange(h, dtype=np.float32)[:, None]
+    sh, sw = strip.shape
+    for x, y, qw, qh, u0, v0, u1, v1 in np.asarray(labels, dtype=np.float32).reshape(-1, 8):
+        inside = (cx >= x) & (cx < F(x + qw)) & (cy >= y) & (cy < F(y + qh))
+        with np.errstate(all="ignore"):
+            u = u0 + ((cx - x) / qw) * F(u1 - u0)
+            v = v0 + ((cy - y) / qh) * F(v1 - v0)
+            tx = np.clip(np.floor(u * F(sw)), 0, sw - 1).astype(np.int64)
+            ty = np.clip(np.floor(v * F(sh)), 0, sh - 1).astype(np.int64)
+        lit = strip[np.broadcast_to(ty, (h, w)), np.broadcast_to(tx, (h, w))] != 0
+        _blend(pic, inside & lit, argb)
+    segs = np.asarray(lines, dtype=np.float32).reshape(-1, 4)
+    for x0, y0, x1, y1 in segs:
+        dx, dy = F(x1 - x0), F(y1 - y0)
+        with np.errstate(all="ignore"):
+            if abs(dx) >= abs(dy):
+                if dx == 0:
+                    continue
+                along = (cx >= min(x0, x1)) & (cx < max(x0, x1))
+                minor = np.floor(y0 + (cx - x0) * F(dy / dx))
+                hit = along & (minor == py)
+            else:
+                along = (cy >= min(y0, y1)) & (cy < max(y0, y1))
+                minor = np.floor(x0 + (cy - y0) * F(dx / dy))
+                hit = along & (minor == px)
+        _blend(pic, hit, argb)
+    return pic

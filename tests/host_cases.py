@@ -227,24 +227,45 @@ def run_host_checks(host, oracle, w=96, h=40):
     assert winfo.get_width(wvs) == w and winfo.get_height(wvs) == 256
     # three scopes read each staged surface, but its two planes crossed PCIe once each (scope_surface_begin/end)
     assert host.L.scope_host_plane_uploads(roi) == 2 * len(frames) and host.L.scope_host_plane_reuses(roi) == len(frames)
-    # video_render: the display shaders as GPU post-passes, the picture the plugin would have drawn
+    # video_render: the display shaders as GPU post-passes, then the graticule (labels + lines) blended over the picture --
+    # the composited picture the plugin would have drawn, against oracle display + oracle geometry + oracle rasteriser
+    import graticule_oracle as go
+
+    host.L.scope_graticule_label_strip.argtypes = [C.c_void_p]
+    strip = np.zeros((16, 96), dtype=np.uint8)
+    host.L.scope_graticule_label_strip(strip.ctypes.data_as(C.c_void_p))
+    AMBER = 0x80FFBF00
+
+    def vss_picture(zoom=1.0):
+        pic = oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2, zoom)
+        labels, lines = go.vectorscope(2, 1 | 256, 0x0054FF)  # the defaults: amber, I/Q cross (src/vectorscope.c:159-160)
+        if zoom > 1.01:
+            z, ofst = np.float32(zoom), np.float32(127.5) * (np.float32(1.0) - np.float32(zoom))
+            labels = labels.copy()
+            labels[:, 0:2] = labels[:, 0:2] * z + ofst
+            labels[:, 2:4] = labels[:, 2:4] * z
+            lines = lines * z + ofst
+        return go.rasterise(pic, labels, lines, AMBER, strip)
+
     rgb, yuv = frames[-1]
     vinfo.video_render(vss, None)
-    assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2))
-    # the mouse wheel zooms the vectorscope about its centre (vss_mouse_wheel, vectorscope.c:473-483)
+    assert np.array_equal(host.picture(vss, 0), vss_picture())
+    # the mouse wheel zooms the vectorscope about its centre (vss_mouse_wheel, vectorscope.c:473-483), graticule included
     assert vinfo.mouse_wheel  # the table carries it, with the reference's signature (src/vectorscope.c:473)
     vinfo.mouse_wheel(vss, None, 0, 1400)
     zoom = float(np.float32(1.0) * np.exp(np.float32(1400 * 5e-4)).astype(np.float32))
     vinfo.video_render(vss, None)
-    assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2, zoom))
+    assert np.array_equal(host.picture(vss, 0), vss_picture(zoom))
     vinfo.mouse_wheel(vss, None, 0, -100000)  # never below 1
     vinfo.video_render(vss, None)
-    assert np.array_equal(host.picture(vss, 0), oracle.display_vectorscope(oracle.vectorscope(yuv, w), 25, 1, 2))
+    assert np.array_equal(host.picture(vss, 0), vss_picture())
     winfo.video_render(wvs, None)
-    assert np.array_equal(host.picture(wvs, 1), oracle.display_waveform(oracle.waveform(rgb, yuv, w, 0x07), 0x07, 0, 51))
+    want = go.rasterise(oracle.display_waveform(oracle.waveform(rgb, yuv, w, 0x07), 0x07, 0, 51), [], go.waveform(5, 0, 3, w), AMBER, strip)
+    assert np.array_equal(host.picture(wvs, 1), want)
     hinfo.video_render(his, None)
     flt, hi = oracle.histogram(rgb, yuv, w, 0x07, logscale=1)
-    assert np.array_equal(host.picture(his, 2), oracle.display_histogram(flt, hi, 0x07, 0, 200))
+    want = go.rasterise(oracle.display_histogram(flt, hi, 0x07, 0, 200), [], go.histogram(5, 0.0, 1, 0, 0, 0, 3, 200), AMBER, strip)
+    assert np.array_equal(host.picture(his, 2), want)
     assert hinfo.get_width(his) == 256 and hinfo.get_height(his) == 200
     # a waveform switched to luma gets the YUV plane of the same surface
     d = host.L.fake_obs_data_create()

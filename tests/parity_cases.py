@@ -413,6 +413,59 @@ def check_pipeline_tables_stay_valid(ctx, oracle, w, h, depth=2):
         pipe.close()
 
 
+LABEL_STRIP_SHA256 = "5147834c7b7b22bb771bf178679aa7ca44ec2ee5e476e09dbca203072ebcea5d"  # the build's own glyphs are part of the pinned picture
+
+
+def check_graticule(ctx, quick=False):
+    """scope_display_graticule against oracle/graticule_oracle.py's rasteriser on the reference's geometry (vectorscope
+    labels + brackets + skin-tone line / I-Q cross, waveform and histogram scale lines in every display mode), over a
+    random picture so that every blended byte counts; plus the edge cases of the pinned rule."""
+    import hashlib
+
+    import graticule_oracle as go
+    import obs_color_monitor_amd as ocm
+
+    strip = ctx.graticule_label_strip()
+    assert strip.shape == (16, 96) and set(np.unique(strip)) == {0, 1}
+    assert hashlib.sha256(strip.tobytes()).hexdigest() == LABEL_STRIP_SHA256, "the label glyphs changed: the pinned picture changed"
+    rng = np.random.default_rng(5)
+
+    def one(w, h, labels, lines, argb, what):
+        pic = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        got = ctx.display_graticule(pic, labels, lines, argb)
+        want = go.rasterise(pic, labels if labels is not None else [], lines if lines is not None else [], argb, strip)
+        assert_same(got, want, what)
+        return got, pic
+
+    for cs in (1, 2):
+        for flags, argb in ((1, 0x80FFBF00), (2 | 256, 0x8000FF00)):
+            labels, lines = go.vectorscope(cs, flags, 0x0054FF)
+            got, pic = one(256, 256, labels, lines, argb, f"vectorscope graticule cs{cs} flags{flags}")
+            assert (got != pic).any()
+            for zoom in ((1.7,) if quick else (1.02, 1.7, 3.3)):  # scaled about 127.5 like the sprite: parts leave the picture
+                z, ofst = np.float32(zoom), np.float32(127.5) * (np.float32(1) - np.float32(zoom))
+                zl = labels.copy()
+                zl[:, 0:2] = zl[:, 0:2] * z + ofst
+                zl[:, 2:4] = zl[:, 2:4] * z
+                one(256, 256, zl, lines * z + ofst, argb, f"vectorscope graticule cs{cs} zoom {zoom}")
+    for display, ncomp in ((0, 3), (1, 3), (2, 3), (1, 2)) if not quick else ((1, 3), (2, 2)):
+        w = 70
+        ow, oh = ctx.display_size(w, 256, {3: 0x07, 2: 0x50, 1: 0x20}[ncomp], display)
+        for n in ((5,) if quick else (1, 4, 5, 10)):
+            one(ow, oh, None, go.waveform(n, display, ncomp, w), 0x80FFBF00, f"waveform graticule {n} d{display} n{ncomp}")
+        ow, oh = ctx.display_size(256, 120, {3: 0x07, 2: 0x50, 1: 0x20}[ncomp], display)
+        one(ow, oh, None, go.histogram(5, 25.0, 0, 100, 0, display, ncomp, 120), 0x80FFBF00, f"histogram graticule d{display} n{ncomp}")
+    # the rule's corners: nothing to draw, a point, a diagonal (x-major on a tie), steep and shallow, reversed end points,
+    # segments that start and end outside the picture, two segments over one pixel (blended twice), opaque colour
+    edge = np.array([[3, 3], [3, 3], [0, 0], [9, 9], [9, 0], [0, 9], [2.25, 1.5], [2.75, 18.5], [18.5, 7.75], [1.5, 7.25],
+                     [-5, 4.5], [40, 4.5], [4.5, -3], [4.5, 30], [6, 6.5], [12, 6.5], [12, 6.5], [6, 6.5]], dtype=np.float32)
+    one(20, 20, None, edge, 0x80FFBF00, "edge segments")
+    one(20, 20, None, edge, 0xFF102030, "edge segments, opaque")
+    one(20, 20, None, None, 0x80FFBF00, "nothing to draw")
+    with pytest.raises(ocm.ScopeError):
+        ctx.display_graticule(np.zeros((4, 4, 4), np.uint8), None, edge[:3], 0x80FFBF00)  # odd number of vertices
+
+
 def check_display(ctx, oracle, w=70, h=40, quick=False):
     """D1-D3 post-passes against the oracle's restatement of the display shaders, every technique.
     quick: the subset the CPU emulation runs (every technique once); the GPU tests run everything."""

@@ -239,6 +239,10 @@ def test_display_post_passes(emul_ctx, oracle):
     pc.check_display(emul_ctx, oracle, 35, 20, quick=True)
 
 
+def test_graticule_drawn_over_the_picture(emul_ctx):
+    pc.check_graticule(emul_ctx, quick=True)
+
+
 @pytest.mark.parametrize("fold", [0, 1])
 def test_partial_tables_combined_in_kernel_or_by_reduce_kernel(emul_ctx, oracle, fold):
     """slices > 1: partial tables are combined by a reduce kernel or (histogram, few partials) by the last workgroup."""

@@ -537,6 +537,37 @@ def test_display_post_passes(hip_ctx, oracle):
     pc.check_display(hip_ctx, oracle, 1280, 72)
 
 
+def test_graticule_drawn_over_the_picture(hip_ctx):
+    """SURVEY.md 8f rank 4 on the GPU: label quads and line lists of the reference's graticule geometry rasterised into
+    the scope pictures (pinned rule) against the oracle's rasteriser, every display mode, zoomed vectorscope included."""
+    pc.check_graticule(hip_ctx)
+
+
+def test_graticule_device_picture(hip_ctx, oracle):
+    """The picture stays in HBM between the display pass and the graticule pass."""
+    import ctypes as C
+
+    import torch
+
+    import graticule_oracle as go
+
+    rgb, yuv = pc.frames(oracle, 640, 360, 2)
+    vss = oracle.vectorscope(yuv, 640)
+    want = go.rasterise(oracle.display_vectorscope(vss, 25, 1, 2), *go.vectorscope(2, 1 | 256, 0x0054FF), 0x80FFBF00,
+                        hip_ctx.graticule_label_strip())
+    tab = torch.from_numpy(vss.copy()).cuda()
+    pic = torch.empty((256, 256, 4), dtype=torch.uint8, device="cuda")
+    dev = 0x1 | 0x2
+    st = hip_ctx.L.scope_display_vectorscope(hip_ctx.h, C.c_void_p(tab.data_ptr()), 25, 1, 2, dev, C.c_void_p(pic.data_ptr()))
+    assert st == 0
+    labels, lines = go.vectorscope(2, 1 | 256, 0x0054FF)
+    labels, lines = np.ascontiguousarray(labels, np.float32), np.ascontiguousarray(lines, np.float32)
+    st = hip_ctx.L.scope_display_graticule(hip_ctx.h, C.c_void_p(pic.data_ptr()), 256, 256, labels.ctypes.data_as(C.c_void_p), 6,
+                                          lines.ctypes.data_as(C.c_void_p), lines.shape[0], 0x80FFBF00, dev)
+    assert st == 0
+    pc.assert_same(pic.cpu().numpy(), want, "display + graticule on a device picture")
+
+
 def test_table_all_reduce_side_stream_buckets(hip_ctx, oracle):
     """The reducer bench.py uses for N > 1, on a one-rank RCCL group: tables written straight into the wire buffer,
     several steps per collective, collective + unpack on a side stream, a partly filled bucket flushed by drain()."""

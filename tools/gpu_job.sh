@@ -54,6 +54,11 @@ for e in d['entries']: print(e['workload'].ljust(16), 'x%-3d' % e['frames_per_st
   esac
   echo "== stage $s rc=$rc $(( $(date +%s) - t0 ))s" | tee -a $out/job.log
 done
+# the per-dispatch traces of these jobs run to hundreds of MB; gpurun copies at most 64 MiB back: keep the summaries
+find $out -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
+find $out -name "*counter_collection.csv" -size +2M -delete 2>/dev/null
+find $out -name "*.db" -size +2M -delete 2>/dev/null
+du -sh $out | tail -1
 tail -5 $out/smoke.log $out/tests.log 2>/dev/null
 cat $out/bench.json 2>/dev/null
 tail -3 $out/bench.err 2>/dev/null
