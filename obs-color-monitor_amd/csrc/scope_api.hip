@@ -116,17 +116,16 @@ int grow(scope_ctx *ctx, uint8_t **buf, size_t *cap, size_t need)
 	return SCOPE_OK;
 }
 
-/* Accumulation launch, bracketed by events when profiling is on. */
+/* Accumulation launch; with profiling on, the kernel's own begin / end time stamps go into the next pair of events
+ * (the launcher's last argument `tm_`). */
 #define TIMED_LAUNCH(ctx, call)                                                                    \
 	do {                                                                                       \
 		const uint32_t slot_ = 2u * ((ctx)->timed % SCOPE_PROFILE_SLOTS);                  \
-		if ((ctx)->profile)                                                                \
-			HIP_TRY(ctx, hipEventRecord((ctx)->ev[slot_], (ctx)->stream));             \
+		const ScopeTiming timing_ = {(ctx)->ev[slot_], (ctx)->ev[slot_ + 1]};               \
+		const ScopeTiming *tm_ = (ctx)->profile ? &timing_ : NULL;                         \
 		HIP_TRY(ctx, call);                                                                \
-		if ((ctx)->profile) {                                                              \
-			HIP_TRY(ctx, hipEventRecord((ctx)->ev[slot_ + 1], (ctx)->stream));         \
+		if ((ctx)->profile)                                                                \
 			(ctx)->timed++;                                                            \
-		}                                                                                  \
 	} while (0)
 
 size_t round_up(size_t v, size_t a)
@@ -400,7 +399,7 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 			slices = min_slices;
 		const uint32_t mask_block = ctx->tn.vss_sparse ? scope_vss_mask_block(ctx->tn) : 0u;
 		if (slices == 1 && !packed) {
-			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, NULL, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, NULL, ctx->tn, ctx->stream, tm_));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * SCOPE_VSS_BINS);
 			if (!st && mask_block)
@@ -408,7 +407,7 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 			if (st)
 				return st;
 			TIMED_LAUNCH(ctx, scope_launch_vss(fs, slices, fuse, colorspace, ctx->partial, mask_block ? ctx->pmask : NULL,
-							   ctx->tn, ctx->stream));
+							   ctx->tn, ctx->stream, tm_));
 			/* one partial per frame and a packed result: the "reduction" of one table is just the repacking */
 			if (mask_block)
 				HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, dst, nf, slices, mask_block, packed,
@@ -473,13 +472,13 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 			bands = min_bands;
 		}
 		if (bands == 1) {
-			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->num_cu, ctx->tn, ctx->stream, his));
+			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->num_cu, ctx->tn, ctx->stream, his, tm_));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * bands * table);
 			if (st)
 				return st;
 			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, bands, chmask, fuse, colorspace, ctx->partial, ctx->num_cu, ctx->tn, ctx->stream,
-							   his));
+							   his, tm_));
 			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, bands, table, 0, ctx->stream));
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
@@ -523,17 +522,17 @@ int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint
 		if (slices < min_slices)
 			slices = min_slices;
 		if (slices == 1) {
-			TIMED_LAUNCH(ctx, scope_launch_his(fs, 1, chmask, fuse, colorspace, dst, NULL, NULL, ctx->tn, ctx->stream));
+			TIMED_LAUNCH(ctx, scope_launch_his(fs, 1, chmask, fuse, colorspace, dst, NULL, NULL, ctx->tn, ctx->stream, tm_));
 		} else if (ctx->tn.fold) {
 			/* the slices of a frame meet in ctx->his_acc inside the launch; no partial tables, no second kernel */
 			TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, dst, ctx->his_acc, ctx->tickets, ctx->tn,
-							   ctx->stream));
+							   ctx->stream, tm_));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * table);
 			if (st)
 				return st;
 			TIMED_LAUNCH(ctx, scope_launch_his(fs, slices, chmask, fuse, colorspace, (uint32_t *)ctx->partial, NULL, NULL,
-							   ctx->tn, ctx->stream));
+							   ctx->tn, ctx->stream, tm_));
 			HIP_TRY(ctx, scope_launch_sum_reduce((const uint32_t *)ctx->partial, dst, nf, slices, SCOPE_HIS_WORDS,
 							     ctx->stream));
 		}

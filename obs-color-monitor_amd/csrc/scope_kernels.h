@@ -65,6 +65,12 @@ struct ScopeTuning {
 	int nt_loads;        /* 1: non-temporal pixel loads */
 };
 
+/* Optional last argument of the accumulation launchers: two HIP events that receive the kernel's own begin and end time
+ * stamps (hipExtLaunchKernelGGL), for scope_ctx_profile. */
+struct ScopeTiming {
+	hipEvent_t start, stop;
+};
+
 ScopeK0 scope_k0_matrix(int colorspace);
 
 /* Dynamic-LDS opt-in for every instantiation; call once per device before launching. */
@@ -80,7 +86,7 @@ hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *d
  * -- only the 16-bin groups holding a count are written and flagged -- for scope_launch_sat_reduce_sparse.
  * fuse_k0: planes are RGB, U/V computed in-kernel. */
 hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
-			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st);
+			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st, const ScopeTiming *tm = NULL);
 /* Threads per workgroup of the vectorscope launch = bytes per sparse-partial mask; 0: this tuning cannot write masks. */
 uint32_t scope_vss_mask_block(const ScopeTuning &tn);
 
@@ -90,7 +96,8 @@ uint32_t scope_vss_mask_block(const ScopeTuning &tn);
  * (device-scope atomic adds, the last workgroup of a frame moves the sums out) and dst = uint32[n_frames][1024].
  * chmask bit c = count byte c of the texel (bit0 -> slot 2, bit1 -> slot 1, bit2 -> slot 0). */
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint32_t *dst, uint32_t *acc, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st);
+			    uint32_t *dst, uint32_t *acc, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st,
+			    const ScopeTiming *tm = NULL);
 
 /* Capture pre-steps: dst(i, j) = texel at src + j*row_pitch + i*col_step*4, i < cx, j < cy (the caller folds
  * scale and ROI origin into src / row_pitch / col_step).  All pointers and pitches 4-byte aligned. */
@@ -109,7 +116,7 @@ struct ScopeHisSink {
 };
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
 			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st,
-			    const ScopeHisSink *his = NULL);
+			    const ScopeHisSink *his = NULL, const ScopeTiming *tm = NULL);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
  * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */

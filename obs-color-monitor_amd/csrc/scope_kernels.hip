@@ -24,6 +24,7 @@
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (K0 must not be FMA-contracted).
  */
 #include "scope_kernels.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <scope_vec.h>
 
@@ -1345,6 +1346,17 @@ __global__ __launch_bounds__(256) void scope_unpack16_clamp_kernel(const u32 *in
  * ---------------------------------------------------------------------------------------- */
 
 
+/* A launch, optionally with the kernel's own begin / end time stamps delivered into two HIP events
+ * (hipExtLaunchKernelGGL: the stamps come out of the dispatch packet, as rocprofv3's do -- events recorded around a
+ * launch also time the gap the command processor leaves in front of the kernel, 5 % of a 0.3 ms launch). */
+#define SCOPE_LAUNCH(kernel, grid, block, lds, st, tm, ...)                                                        \
+	do {                                                                                                       \
+		if (tm)                                                                                            \
+			hipExtLaunchKernelGGL(kernel, grid, block, lds, st, (tm)->start, (tm)->stop, 0, __VA_ARGS__); \
+		else                                                                                               \
+			hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                             \
+	} while (0)
+
 namespace {
 
 struct Regions {
@@ -1384,6 +1396,7 @@ struct VssArgs {
 	ScopeK0 k0;
 	uint8_t *dst, *pmask;
 	hipStream_t st;
+	const ScopeTiming *tm;
 };
 
 template <int U, bool NT, int MERGE, bool FUSE, int HASH> hipError_t vss_variant(const VssArgs *a)
@@ -1391,9 +1404,9 @@ template <int U, bool NT, int MERGE, bool FUSE, int HASH> hipError_t vss_variant
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_vss_kernel<U, NT, MERGE, FUSE, HASH>,
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)VSS_LDS_BYTES);
-	hipLaunchKernelGGL((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(a->block),
-			   VSS_LDS_BYTES, a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->k0,
-			   a->dst, a->pmask);
+	SCOPE_LAUNCH((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(a->block),
+		     VSS_LDS_BYTES, a->st, a->tm, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->k0,
+		     a->dst, a->pmask);
 	return hipGetLastError();
 }
 
@@ -1433,6 +1446,7 @@ struct HisArgs {
 	ScopeK0 k0;
 	u32 *dst, *acc, *tickets;
 	hipStream_t st;
+	const ScopeTiming *tm;
 };
 
 template <int U, bool NT, bool FUSE> hipError_t his_variant(const HisArgs *a)
@@ -1440,9 +1454,9 @@ template <int U, bool NT, bool FUSE> hipError_t his_variant(const HisArgs *a)
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_his_kernel<U, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
 					   (int)HIS_LDS_BYTES);
-	hipLaunchKernelGGL((scope_his_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->slices), dim3(a->block), HIS_LDS_BYTES,
-			   a->st, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->chmask, a->k0, a->dst, a->acc,
-			   a->tickets);
+	SCOPE_LAUNCH((scope_his_kernel<U, NT, FUSE>), dim3(a->fs->n_frames * a->slices), dim3(a->block), HIS_LDS_BYTES, a->st,
+		     a->tm, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->chmask, a->k0, a->dst, a->acc,
+		     a->tickets);
 	return hipGetLastError();
 }
 template <int U, bool NT> hipError_t his_pick_fuse(int fuse, const HisArgs *a)
@@ -1469,6 +1483,7 @@ struct WvsArgs {
 	uint8_t *dst;
 	ScopeWvsHis his;
 	hipStream_t st;
+	const ScopeTiming *tm;
 };
 
 template <int CH, bool FUSE, bool WIDE, bool HIS> hipError_t wvs_variant(const WvsArgs *a)
@@ -1476,8 +1491,8 @@ template <int CH, bool FUSE, bool WIDE, bool HIS> hipError_t wvs_variant(const W
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE, WIDE, HIS>,
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WVS_LDS_BYTES);
-	hipLaunchKernelGGL((scope_wvs_kernel<CH, FUSE, WIDE, HIS>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, *a->fs,
-			   a->strips, a->bands, a->k0, a->dst, a->his);
+	SCOPE_LAUNCH((scope_wvs_kernel<CH, FUSE, WIDE, HIS>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, a->tm, *a->fs,
+		     a->strips, a->bands, a->k0, a->dst, a->his);
 	return hipGetLastError();
 }
 template <int CH, bool HIS> hipError_t wvs_pick_shape(int fuse, int wide, const WvsArgs *a)
@@ -1582,7 +1597,7 @@ uint32_t scope_vss_mask_block(const ScopeTuning &tn)
 }
 
 hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
-			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st)
+			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st, const ScopeTiming *tm)
 {
 	/* Small launches -- one to a dozen frames, >= 12 workgroups per frame -- give every workgroup well under a megabyte:
 	 * cutting that into 8 lane-group streams leaves runs of a few KiB per stream and the memory system answers
@@ -1595,21 +1610,23 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 	const int unroll = fuse_k0 ? tn.vss_fused_unroll : (tn.vss_unroll > 0 ? tn.vss_unroll : (small ? 2 : 4));
 	if (pmask && !scope_vss_mask_block(tn))
 		return hipErrorInvalidValue;
-	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), split_regions(fs), scope_k0_matrix(colorspace), dst, pmask, st};
+	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), split_regions(fs), scope_k0_matrix(colorspace), dst, pmask, st, tm};
 	return vss_pick(unroll, tn.nt_loads, tn.vss_merge, fuse_k0, tn.vss_hash, &a);
 }
 
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint32_t *dst, uint32_t *acc, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st)
+			    uint32_t *dst, uint32_t *acc, uint32_t *tickets, const ScopeTuning &tn, hipStream_t st,
+			    const ScopeTiming *tm)
 {
 	if (!tickets || slices < 2)
 		acc = NULL;
-	const HisArgs a = {&fs, slices, chmask, scope_block(tn.his_block), split_regions(fs), scope_k0_matrix(colorspace), dst, acc, tickets, st};
+	const HisArgs a = {&fs, slices, chmask, scope_block(tn.his_block), split_regions(fs), scope_k0_matrix(colorspace), dst, acc, tickets, st, tm};
 	return his_pick(tn.his_unroll, tn.nt_loads, fuse_k0, &a);
 }
 
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
-			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st, const ScopeHisSink *his)
+			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st, const ScopeHisSink *his,
+			    const ScopeTiming *tm)
 {
 	const u32 strips = (fs.width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
 	const u32 nch = (chmask & 1u) + ((chmask >> 1) & 1u) + ((chmask >> 2) & 1u);
@@ -1631,7 +1648,7 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 	ScopeWvsHis h = {NULL, NULL, NULL, 0};
 	if (his)
 		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
-	const WvsArgs a = {&fs, strips, bands, lds, grid, scope_k0_matrix(colorspace), dst, h, st};
+	const WvsArgs a = {&fs, strips, bands, lds, grid, scope_k0_matrix(colorspace), dst, h, st, tm};
 	return wvs_pick(chmask, fuse_k0, wide, his != NULL, &a);
 }
 

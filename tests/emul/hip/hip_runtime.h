@@ -209,3 +209,13 @@ static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 
 	emul::launch_ctx<KArgs...> c{kernel, std::tuple<KArgs...>(std::forward<Args>(args)...)};
 	emul::run_grid(grid, block, &emul::launch_ctx<KArgs...>::thread_entry, &c);
 }
+
+/* <hip/hip_ext.h>: the launch that also delivers the kernel's time stamps into two events */
+template <typename... KArgs, typename... Args>
+static inline void hipExtLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+					 hipEvent_t start, hipEvent_t stop, unsigned /*flags*/, Args &&...args)
+{
+	hipEventRecord(start, st);
+	hipLaunchKernelGGL(kernel, grid, block, lds, st, std::forward<Args>(args)...);
+	hipEventRecord(stop, st);
+}

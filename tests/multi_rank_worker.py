@@ -86,6 +86,23 @@ def main():
         whole[:, a:b] = slab
     assert sorted((a, b) for a, b, _ in slabs)[0][0] == 0 and max(b for _, b, _ in slabs) == w2
     assert np.array_equal(whole, o.waveform(rgb, yuv, w2, 0x07)), "column-tiled waveform != whole frame"
+    # BASELINE config 4's geometry: a 7680-pixel-wide frame (a few rows of it: the emulator is slow) in row tiles through
+    # the packed wire format bench.py's config4 leg uses, and the waveform of the same frame by column slab
+    w4, h4 = 7680, 12
+    rgb = o.fill_frame(w4, h4, 2, 404)
+    yuv = o.rgb_to_yuv(rgb, w4, 2)
+    r0, r1 = tile_rows(h4, rank, world)
+    red4 = TableAllReduce(ctx, 65536, "cpu", "sat_u8")
+    tile = torch.from_numpy(np.ascontiguousarray(yuv[r0:r1])).unsqueeze(0)
+    batch = ctx.make_device_batch(tile, tile.shape[2], w4, r1 - r0, planes_are_rgb=False)
+    ctx.vectorscope_batch_dev(batch, red4.wire_buffer(), packed16=True)
+    red4.submit_packed()
+    got = red4.drain()
+    assert np.array_equal(got.numpy().reshape(256, 256), o.vectorscope(yuv, w4)), "7680-wide row tiles != whole frame"
+    c0, c1 = tile_cols(w4, rank, world)
+    assert (c1 - c0) % 64 == 0 and c1 - c0 == w4 // world
+    mine, st = ctx.waveform(rgb=np.ascontiguousarray(rgb[:, 4 * c0:4 * c1]), yuv=None, width=c1 - c0, components=0x07)
+    assert st == 0 and np.array_equal(mine, o.waveform(rgb, yuv, w4, 0x07)[:, c0:c1]), "7680-wide column slab != whole frame's columns"
     # a flat frame saturates on every rank: clamped partials 255 + 255 must still give 255
     assert wants[0].max() == 255
     dist.barrier()
