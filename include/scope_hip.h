@@ -114,10 +114,6 @@ int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
  *   "fold" 0|1   the slices of a histogram frame meet inside the launch (atomics + last arrival) | partial tables + a second kernel
  *   "vss.sparse" 0|1   vectorscope partial tables hold only the 16-bin groups that are not empty
  *   "nt" 0|1     streaming (non-temporal) loads
- *   "host.register" 0|1   pin the caller's host planes in place (hipHostRegister) the first time the synchronous entry
- *                points see them and keep the last 8 ranges pinned: the plugin maps the same three staging surfaces over
- *                and over (CM_SURFACE_QUEUE_SIZE, src/common.h:46).  Opt-in (default 0): the planes must stay mapped
- *                until the option is switched off again or the context is destroyed (both unpin everything)
  *   "slices"     workgroups per frame (0 = automatic) */
 int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value);
 const char *scope_strerror(int status);

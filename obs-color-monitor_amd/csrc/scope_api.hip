@@ -19,7 +19,6 @@
 #include <string.h>
 
 #define SCOPE_PROFILE_SLOTS 512u
-#define SCOPE_HOST_REG_SLOTS 8
 
 struct scope_ctx {
 	int device;
@@ -57,20 +56,6 @@ struct scope_ctx {
 		uint32_t his_chmask;
 		uint32_t his_counts[SCOPE_HIS_WORDS];
 	} surf;
-	/* "host.register": host planes handed to the synchronous entry points are pinned in place (hipHostRegister) the
-	 * first time they are seen and stay pinned, least recently used out first: the plugin maps the same three staging
-	 * surfaces over and over (CM_SURFACE_QUEUE_SIZE, src/common.h:46), and a pinned source turns the 33 MB upload from
-	 * a staged pageable copy into one DMA.  Opt-in: the memory must stay mapped until scope_ctx_destroy or until the
-	 * option is switched off (both unpin everything). */
-	int host_register;
-	struct {
-		const uint8_t *base; /* NULL = free */
-		size_t bytes;
-		bool pinned; /* false: registration was refused, do not try again every frame */
-		uint64_t stamp;
-	} reg[SCOPE_HOST_REG_SLOTS];
-	uint64_t reg_clock;
-	uint32_t reg_pins, reg_hits;
 	uint32_t *tickets; /* SCOPE_MAX_FRAMES arrival counters of the in-launch combine; zero between launches */
 	ScopeTuning tn;
 	int slices_override;
@@ -143,47 +128,6 @@ int check_geometry(scope_ctx *ctx, uint32_t linesize, uint32_t width, uint32_t h
 	return SCOPE_OK;
 }
 
-void host_unregister_all(scope_ctx *ctx)
-{
-	for (int i = 0; i < SCOPE_HOST_REG_SLOTS; i++) {
-		if (ctx->reg[i].base && ctx->reg[i].pinned)
-			(void)hipHostUnregister((void *)ctx->reg[i].base);
-		ctx->reg[i].base = NULL;
-	}
-}
-
-/* Pins [plane, plane + bytes) in place unless it already lies inside a pinned range.  Never fails the call: a plane
- * that cannot be pinned is simply uploaded as pageable memory, as before. */
-void host_register(scope_ctx *ctx, const uint8_t *plane, size_t bytes)
-{
-	if (!ctx->host_register || !plane || !bytes)
-		return;
-	ctx->reg_clock++;
-	int victim = -1; /* a free slot, else the least recently used one */
-	for (int i = 0; i < SCOPE_HOST_REG_SLOTS; i++) {
-		if (ctx->reg[i].base && plane >= ctx->reg[i].base && plane + bytes <= ctx->reg[i].base + ctx->reg[i].bytes) {
-			ctx->reg[i].stamp = ctx->reg_clock;
-			ctx->reg_hits++;
-			return;
-		}
-		const uint64_t age_i = ctx->reg[i].base ? ctx->reg[i].stamp : 0;
-		if (victim < 0 || age_i < (ctx->reg[victim].base ? ctx->reg[victim].stamp : 0))
-			victim = i;
-	}
-	if (ctx->reg[victim].base && ctx->reg[victim].pinned) {
-		(void)hipStreamSynchronize(ctx->stream); /* a copy from the range may still be queued */
-		(void)hipHostUnregister((void *)ctx->reg[victim].base);
-	}
-	ctx->reg[victim].base = plane;
-	ctx->reg[victim].bytes = bytes;
-	ctx->reg[victim].stamp = ctx->reg_clock;
-	ctx->reg[victim].pinned = hipHostRegister((void *)plane, bytes, hipHostRegisterDefault) == hipSuccess;
-	if (ctx->reg[victim].pinned)
-		ctx->reg_pins++;
-	else
-		(void)hipGetLastError(); /* refused (already pinned by the caller, a device mapping, ...): remembered as such */
-}
-
 /* Puts up to SCOPE_MAX_FRAMES planes into HBM (no-op for device planes) and describes them. */
 int stage_planes(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
 		 uint32_t height, uint32_t flags, ScopeFrameSet *fs)
@@ -225,7 +169,6 @@ int stage_planes(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 			int st2 = grow(ctx, &ctx->surf.dev[slot], &ctx->surf.dev_bytes[slot], plane_bytes);
 			if (st2)
 				return st2;
-			host_register(ctx, planes[0], (size_t)linesize * (height - 1) + (size_t)width * 4);
 			HIP_TRY(ctx, hipMemcpy2DAsync(ctx->surf.dev[slot], pitch, planes[0], linesize, (size_t)width * 4, height,
 						      hipMemcpyHostToDevice, ctx->stream));
 			ctx->surf.host[slot] = planes[0];
@@ -242,7 +185,6 @@ int stage_planes(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 		return st;
 	for (uint32_t i = 0; i < n; i++) {
 		uint8_t *d = ctx->stage_in + plane_bytes * i;
-		host_register(ctx, planes[i], (size_t)linesize * (height - 1) + (size_t)width * 4);
 		HIP_TRY(ctx, hipMemcpy2DAsync(d, pitch, planes[i], linesize, (size_t)width * 4, height, hipMemcpyHostToDevice,
 					      ctx->stream));
 		fs->plane[i] = d;
@@ -714,7 +656,6 @@ void scope_ctx_destroy(scope_ctx *ctx)
 		(void)hipFree(ctx->stage_in);
 	if (ctx->stage_out)
 		(void)hipFree(ctx->stage_out);
-	host_unregister_all(ctx);
 	if (ctx->tickets)
 		(void)hipFree(ctx->tickets);
 	if (ctx->his_acc)
@@ -802,22 +743,6 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.fold = value != 0;
 	else if (!strcmp(key, "vss.sparse"))
 		ctx->tn.vss_sparse = value != 0;
-	else if (!strcmp(key, "host.register")) {
-		if (!value && ctx->host_register) {
-			(void)hipSetDevice(ctx->device);
-			(void)hipStreamSynchronize(ctx->stream);
-			host_unregister_all(ctx);
-		}
-		ctx->host_register = value != 0;
-	}
-	else if (!strcmp(key, "wvs.per_cu"))
-		ctx->tn.wvs_per_cu = value;
-	else if (!strcmp(key, "wvs.persist"))
-		ctx->tn.wvs_persist = value != 0;
-	else if (!strcmp(key, "wvs.wide"))
-		ctx->tn.wvs_wide = value != 0;
-	else if (!strcmp(key, "slices"))
-		ctx->slices_override = value;
 	else
 		return fail(ctx, SCOPE_EINVAL, key, hipSuccess);
 	return SCOPE_OK;

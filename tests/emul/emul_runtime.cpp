@@ -175,16 +175,3 @@ hipError_t hipHostFree(void *p)
 	free(p);
 	return hipSuccess;
 }
-
-/* pinning is a no-op here; the calls are counted so that the LRU logic of "host.register" can be tested */
-int emul_host_registered = 0;
-hipError_t hipHostRegister(void *, size_t, unsigned)
-{
-	emul_host_registered++;
-	return hipSuccess;
-}
-hipError_t hipHostUnregister(void *)
-{
-	emul_host_registered--;
-	return hipSuccess;
-}

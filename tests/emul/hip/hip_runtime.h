@@ -96,9 +96,6 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
 hipError_t hipHostFree(void *p);
-enum { hipHostRegisterDefault = 0 };
-hipError_t hipHostRegister(void *p, size_t n, unsigned flags);
-hipError_t hipHostUnregister(void *p);
 hipError_t hipGetLastError(void);
 const char *hipGetErrorString(hipError_t e);
 

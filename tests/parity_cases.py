@@ -11,7 +11,7 @@ DISTS = {1: "uniform", 2: "concentrated", 3: "flat", 4: "bars", 5: "alpha_holes"
 COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
 
 
-DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 2, "vss.hash": 0, "vss.groups": -1, "his.unroll": 1, "wvs.wide": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "host.register": 0, "vss.block": 0, "his.block": 0,
+DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 2, "vss.hash": 0, "vss.groups": -1, "his.unroll": 1, "wvs.wide": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.block": 0, "his.block": 0,
             "nt": 1, "slices": 0}
 
 
@@ -247,27 +247,6 @@ def check_surface_fanout(ctx, oracle, w, h, linesize=None):
     with pytest.raises(ocm.ScopeError):  # one geometry per surface
         ctx.histogram_counts(rgb=other, yuv=None, width=w + 1, components=0x07)
     assert ctx.surface_end() == (1, 0)
-
-
-def check_host_register(ctx, oracle, w, h):
-    """"host.register": host planes pinned in place on first sight, at most 8 ranges (LRU); results unchanged, planes
-    of every pitch, more distinct planes than slots, the option switched off again (everything unpinned)."""
-    planes = [frames(oracle, w, h, 1 + i % 5, linesize=(None if i % 2 else 4 * w + 64), seed=600 + i) for i in range(11)]
-    with options(ctx, **{"host.register": 1}):
-        for rep in range(3):  # 11 planes x 2 > 8 slots: the LRU turns over; repeats hit or re-pin
-            for rgb, yuv in planes:
-                got, st = ctx.vectorscope(yuv=yuv, width=w)
-                assert st == 0
-                assert_same(got, oracle.vectorscope(yuv, w), "vectorscope from a pinned plane")
-                cnt, st = ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=0x07)
-                assert_same(cnt, oracle.histogram_counts(rgb, yuv, w, 0x07), "histogram from a pinned plane")
-        rgb, yuv = planes[0]
-        ctx.surface_begin()
-        wv, st = ctx.waveform(rgb=rgb, yuv=yuv, width=w, components=0x07)
-        assert_same(wv, oracle.waveform(rgb, yuv, w, 0x07), "dock waveform from a pinned plane")
-        assert ctx.surface_end() == (1, 0)
-    got, st = ctx.vectorscope(yuv=planes[3][1], width=w)  # unpinned again
-    assert_same(got, oracle.vectorscope(planes[3][1], w), "vectorscope after host.register was switched off")
 
 
 def check_waveform_histogram(ctx, oracle, w, h, dist, linesize=None, colorspace=2):

@@ -227,10 +227,6 @@ def test_waveform_histogram_one_pass(emul_ctx, oracle, w, h, dist):
         pc.check_waveform_histogram(emul_ctx, oracle, w, h, dist)
 
 
-def test_host_planes_pinned_in_place(emul_ctx, oracle):
-    pc.check_host_register(emul_ctx, oracle, 70, 20)
-
-
 def test_surface_waveform_feeds_histogram(emul_ctx, oracle):
     pc.check_surface_waveform_feeds_histogram(emul_ctx, oracle, 70, 36)
 

@@ -197,11 +197,6 @@ def test_waveform_histogram_batch_device(hip_ctx, oracle):
                                f"batch counts {hc:#x} f{f}")
 
 
-def test_host_planes_pinned_in_place(hip_ctx, oracle):
-    pc.check_host_register(hip_ctx, oracle, 640, 360)
-    pc.check_host_register(hip_ctx, oracle, 1279, 301)
-
-
 def test_surface_waveform_feeds_histogram(hip_ctx, oracle):
     pc.check_surface_waveform_feeds_histogram(hip_ctx, oracle, 640, 360)
     pc.check_surface_waveform_feeds_histogram(hip_ctx, oracle, 1279, 301)

@@ -233,41 +233,6 @@ def main():
             emit(dict(tag="host_call", scope=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1),
                       gpix=round(W * H / (ms * 1e-3) / 1e9, 2), note="pageable host plane in, table out, synchronous"))
 
-        # the same with the caller's planes pinned in place ("host.register": the plugin maps the same surfaces again and again)
-        ctx.set_option("host.register", 1)
-        for name, fn in (("vectorscope", lambda: ctx.vectorscope(yuv=host_yuv, width=W)),
-                         ("waveform_rgb", lambda: ctx.waveform(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07)),
-                         ("histogram_rgb", lambda: ctx.histogram(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07))):
-            for _ in range(3):
-                fn()
-            t0 = time.perf_counter()
-            reps = 20
-            for _ in range(reps):
-                fn()
-            ms = (time.perf_counter() - t0) / reps * 1e3
-            emit(dict(tag="host_call_registered", scope=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1),
-                      gpix=round(W * H / (ms * 1e-3) / 1e9, 2), gbytes_per_s=round(4 * W * H / (ms * 1e-3) / 1e9, 1),
-                      note="host plane pinned in place by the library (host.register=1), table out, synchronous"))
-
-        def dock_once(begin):
-            if begin is not None:
-                ctx.surface_begin(fuse_k0=begin)
-            ctx.vectorscope(rgb=host_rgb, yuv=host_yuv, width=W)
-            ctx.waveform(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07)
-            ctx.histogram(rgb=host_rgb, yuv=host_yuv, width=W, components=0x07)
-            if begin is not None:
-                ctx.surface_end()
-        for name, begin in (("registered planes, begin/end: two uploads, histogram from the waveform pass", False),
-                            ("registered planes, begin(FUSE_K0): one upload", True)):
-            for _ in range(3):
-                dock_once(begin)
-            t0 = time.perf_counter()
-            for _ in range(20):
-                dock_once(begin)
-            ms = (time.perf_counter() - t0) / 20 * 1e3
-            emit(dict(tag="host_dock_registered", how=name, ms_per_frame=round(ms, 3), fps=round(1e3 / ms, 1)))
-        ctx.set_option("host.register", 0)
-
         # the dock: three scopes on ONE staged surface (RGB + YUV planes), per frame
         def dock():
             ctx.vectorscope(rgb=host_rgb, yuv=host_yuv, width=W)
