@@ -743,6 +743,14 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.fold = value != 0;
 	else if (!strcmp(key, "vss.sparse"))
 		ctx->tn.vss_sparse = value != 0;
+	else if (!strcmp(key, "wvs.per_cu"))
+		ctx->tn.wvs_per_cu = value;
+	else if (!strcmp(key, "wvs.persist"))
+		ctx->tn.wvs_persist = value != 0;
+	else if (!strcmp(key, "wvs.wide"))
+		ctx->tn.wvs_wide = value != 0;
+	else if (!strcmp(key, "slices"))
+		ctx->slices_override = value;
 	else
 		return fail(ctx, SCOPE_EINVAL, key, hipSuccess);
 	return SCOPE_OK;
