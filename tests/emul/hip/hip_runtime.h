@@ -47,6 +47,10 @@ struct alignas(8) uint2 {
 struct alignas(16) uint4 {
 	uint32_t x, y, z, w;
 };
+static inline uint2 make_uint2(uint32_t x, uint32_t y)
+{
+	return uint2{x, y};
+}
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w)
 {
 	return uint4{x, y, z, w};

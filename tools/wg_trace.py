@@ -21,6 +21,9 @@ for n in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("8"
     c.sync()
     res = []
     for rep in range(5):
+        if os.environ.get("WG_TRACE_BACK_TO_BACK"):  # the last of a train of launches: what a stream of calls sees
+            for _ in range(20):
+                c.vectorscope_batch_dev(b, out, sync=False)
         c.vectorscope_batch_dev(b, out, sync=True)
         buf = (ctypes.c_ulonglong * 4096)()
         assert c.L.scope_debug_read(buf) == 0
@@ -30,6 +33,9 @@ for n in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("8"
         us = (t - t0) / 100.0   # 100 MHz
         res.append((us[:, 0].max(), np.median(us[:, 1]), us[:, 1].min(), us[:, 1].max(), us[:, 2].max(), np.percentile(us[:, 1], 10), np.percentile(us[:, 1], 90)))
     ends = us[:, 1]  # last launch: when each workgroup left its pixel loop
+    starts = us[:, 0]
+    print("   by XCD (workgroup id mod 8), mean START [us]:", " ".join(f"{starts[x::8].mean():.1f}" for x in range(8)),
+          " loop duration:", " ".join(f"{(ends[x::8] - starts[x::8]).mean():.1f}" for x in range(8)))
     print("   by XCD (workgroup id mod 8), mean end [us]:", " ".join(f"{ends[x::8].mean():.1f}" for x in range(8)))
     sl = max(1, 256 // n)
     print(f"   by slice of its frame (id mod {sl}), mean end [us]:", " ".join(f"{ends[x::sl].mean():.1f}" for x in range(min(sl, 8))))
