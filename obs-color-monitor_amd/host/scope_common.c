@@ -13,7 +13,10 @@
 #include <stdlib.h>
 #include <string.h>
 
-static scope_ctx *g_gpu;
+/* Two contexts: the pipeline threads share one (scope_surface_begin keeps it locked for the 1-2 ms a 4K surface takes to
+ * cross PCIe), the render thread's display passes have their own, so OBS's render thread never waits for a "color-monitor"
+ * thread -- in the reference it never waits for the CPU loops either. */
+static scope_ctx *g_gpu, *g_gpu_render;
 static pthread_mutex_t g_gpu_mutex = PTHREAD_MUTEX_INITIALIZER;
 
 int cm_gpu_open(int device)
@@ -22,6 +25,10 @@ int cm_gpu_open(int device)
 	int st = SCOPE_OK;
 	if (!g_gpu) {
 		st = scope_ctx_create(device, &g_gpu);
+		if (st == SCOPE_OK && (st = scope_ctx_create(device, &g_gpu_render)) != SCOPE_OK) {
+			scope_ctx_destroy(g_gpu);
+			g_gpu = NULL;
+		}
 		if (st != SCOPE_OK)
 			blog(LOG_ERROR, "[obs-color-monitor] scope_ctx_create(%d) failed: %s", device, scope_strerror(st));
 	}
@@ -33,13 +40,19 @@ void cm_gpu_close(void)
 {
 	pthread_mutex_lock(&g_gpu_mutex);
 	scope_ctx_destroy(g_gpu);
-	g_gpu = NULL;
+	scope_ctx_destroy(g_gpu_render);
+	g_gpu = g_gpu_render = NULL;
 	pthread_mutex_unlock(&g_gpu_mutex);
 }
 
 scope_ctx *cm_gpu(void)
 {
 	return g_gpu;
+}
+
+scope_ctx *cm_gpu_render(void)
+{
+	return g_gpu_render;
 }
 
 /* src/common.c:335-373: build the surface descriptor from the slot's flags and call the scope */

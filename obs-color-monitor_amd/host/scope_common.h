@@ -135,8 +135,11 @@ bool cm_render_target(struct cm_source *src, const uint8_t *target_rgb, uint32_t
 /* Blocks until every staged surface has been through the callback (test/bench helper). */
 void cm_drain(struct cm_source *src);
 
-/* The shared GPU context of this module (one scope_ctx per process, like one OBS graphics context). */
+/* The GPU contexts of this module: cm_gpu() for the pipeline threads' scope calls, cm_gpu_render() for the render thread's
+ * display passes (a context is locked per call, and from scope_surface_begin to _end: the render thread must not queue up
+ * behind a surface upload). */
 scope_ctx *cm_gpu(void);
+scope_ctx *cm_gpu_render(void);
 int cm_gpu_open(int device);
 void cm_gpu_close(void);
 

@@ -23,7 +23,7 @@ static const struct scope_surface_data *as_scope(const struct cm_surface_data *s
 static void log_failure(const char *what, int st)
 {
 	if (st != SCOPE_OK)
-		blog(LOG_ERROR, "[obs-color-monitor] %s failed: %s (%s)", what, scope_strerror(st), scope_last_error(cm_gpu()));
+		blog(LOG_ERROR, "[obs-color-monitor] %s failed: %s", what, scope_strerror(st));
 }
 
 /* The display shaders (D1-D3) run as GPU post-passes; the picture lands where the plugin would have
@@ -149,7 +149,7 @@ static void vss_render(void *data, gs_effect_t *effect)
 		return;
 	PROFILE_START(PROF_VSS_RENDER);
 	PROFILE_START(PROF_DRAW);
-	const int st = scope_display_vectorscope_zoom(cm_gpu(), src->tex_buf[r_tex_buf], src->intensity, src->color_type,
+	const int st = scope_display_vectorscope_zoom(cm_gpu_render(), src->tex_buf[r_tex_buf], src->intensity, src->color_type,
 						      src->tex_cs[r_tex_buf], src->zoom, 0, rgba);
 	PROFILE_END(PROF_DRAW);
 	log_failure("scope_display_vectorscope", st);
@@ -173,7 +173,7 @@ static void vss_render(void *data, gs_effect_t *effect)
 			}
 		}
 		log_failure("scope_display_graticule",
-			    scope_display_graticule(cm_gpu(), rgba, VS_SIZE, VS_SIZE, (const struct scope_graticule_label *)labels,
+			    scope_display_graticule(cm_gpu_render(), rgba, VS_SIZE, VS_SIZE, (const struct scope_graticule_label *)labels,
 						    SCOPE_VSS_LABELS, (const struct scope_graticule_vertex *)lines, n, src->graticule_color, 0));
 	}
 	PROFILE_END(PROF_DRAW_GRATICULE);
@@ -347,7 +347,7 @@ static void wvs_render(void *data, gs_effect_t *effect)
 		return;
 	PROFILE_START(PROF_WVS_RENDER);
 	PROFILE_START(PROF_DRAW);
-	const int st = scope_display_waveform(cm_gpu(), src->tex_buf[r], src->tex_buf_width[r], src->components, src->display,
+	const int st = scope_display_waveform(cm_gpu_render(), src->tex_buf[r], src->tex_buf_width[r], src->components, src->display,
 					      src->intensity, 0, rgba);
 	PROFILE_END(PROF_DRAW);
 	log_failure("scope_display_waveform", st);
@@ -362,7 +362,7 @@ static void wvs_render(void *data, gs_effect_t *effect)
 		if (n > max)
 			n = max;
 		log_failure("scope_display_graticule",
-			    scope_display_graticule(cm_gpu(), rgba, w, h, NULL, 0, (const struct scope_graticule_vertex *)lines, n,
+			    scope_display_graticule(cm_gpu_render(), rgba, w, h, NULL, 0, (const struct scope_graticule_vertex *)lines, n,
 						    0x80FFBF00 /* amber, :311 */, 0));
 	}
 	PROFILE_END(PROF_DRAW_GRATICULE);
@@ -559,7 +559,7 @@ static void his_render(void *data, gs_effect_t *effect)
 		return;
 	PROFILE_START(PROF_HIS_RENDER);
 	PROFILE_START(PROF_DRAW);
-	const int st = scope_display_histogram(cm_gpu(), (const float *)src->tex_buf[r], src->hi_max[r], src->components,
+	const int st = scope_display_histogram(cm_gpu_render(), (const float *)src->tex_buf[r], src->hi_max[r], src->components,
 					       src->display, (uint32_t)src->level_height, 0, rgba);
 	PROFILE_END(PROF_DRAW);
 	log_failure("scope_display_histogram", st);
@@ -576,7 +576,7 @@ static void his_render(void *data, gs_effect_t *effect)
 			n = max;
 		if (n)
 			log_failure("scope_display_graticule",
-				    scope_display_graticule(cm_gpu(), rgba, w, h, NULL, 0, (const struct scope_graticule_vertex *)lines, n,
+				    scope_display_graticule(cm_gpu_render(), rgba, w, h, NULL, 0, (const struct scope_graticule_vertex *)lines, n,
 							    0x80FFBF00 /* amber, :495 */, 0));
 	}
 	PROFILE_END(PROF_HIS_RENDER);
