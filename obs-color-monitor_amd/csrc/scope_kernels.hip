@@ -1601,7 +1601,7 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 {
 	/* Small launches -- one to a dozen frames, >= 12 workgroups per frame -- give every workgroup well under a megabyte:
 	 * cutting that into 8 lane-group streams leaves runs of a few KiB per stream and the memory system answers
-	 * 10-15 % slower (12 frames: 0.49 -> 0.59 of peak, 3 frames 0.36 -> 0.41; profiles/round2/latency_r2e.jsonl).
+	 * 10-15 % slower (12 frames: 0.49 -> 0.59 of peak, 3 frames 0.36 -> 0.41; profiles/round2/latency_r2e.txt).
 	 * There the slice is walked as ONE stream, two loads per lane in flight; the big batches keep 8 streams x 4. */
 	const bool small = slices >= 12;
 	u32 glog2 = tn.vss_groups_log2 < 0 ? (small ? 0u : 3u) : (u32)tn.vss_groups_log2;
