@@ -10,9 +10,11 @@ Frames are uniform-random RGB pushed through the K0 kernel, i.e. the staged Y'Cb
 vss_draw_vectorscope reads.  Every step goes through the C-ABI of libscope_hip.so (no CPU path exists in the product).
 
 The timed region is EXACTLY K steps between barrier + synchronize (-> `value`).  Because K steps of 0.3 ms are over
-before a clock or a utilisation sampler notices, the same steps then run on for at least `--min-seconds` (1 s) more:
-`sustained` carries that measurement and the accumulation kernel's average duration (HIP events on its stream, the
-figure rocprofv3 --kernel-trace --stats reports for the same command) is taken over both.
+before a clock or a utilisation sampler notices, the same steps then run on for at least `--min-seconds` (1 s) more
+(-> `sustained`).  The accumulation kernel's average duration (-> `roofline`) comes from a third leg of the same steps
+in which every launch carries its own begin/end HIP events on its stream (hipExtLaunchKernelGGL: the figure rocprofv3
+--kernel-trace --stats reports for the same command); it is a separate leg because reading events costs the host a
+few microseconds per launch, which a one-frame step would feel.
 
 Besides the headline the default one-GPU run measures, briefly and in the same process (`--no-extras` skips them):
   variants   the other workloads of BASELINE.json at the same batch: vectorscope with K0 fused (config 2, variant ii),

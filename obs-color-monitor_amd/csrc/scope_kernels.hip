@@ -122,22 +122,32 @@ __device__ __forceinline__ u32 vss_bin(u32 px)
 	return scope_perm(0u, px, 0x0c02000cu);
 }
 
+/* One row of the matrix in 2^-24 fixed point: f[0] R + f[1] G + f[2] B + f[3] (mod 2^32), texel bytes B, G, R, A.
+ * Four instructions, the masked blue byte `b` is shared by the rows: two byte multiplies, a multiply-add, a 3-way add. */
+__device__ __forceinline__ u32 scope_k0_row(u32 px, int b, const int (&f)[4])
+{
+	return (u32)(scope_mad24(f[2], b, f[3]) + scope_mul24_byte1(px, f[1]) + scope_mul24_byte2(px, f[0]));
+}
+__device__ __forceinline__ u32 scope_k0_row_y(u32 px, u32 b, const int (&f)[4])
+{
+	return scope_umad24((u32)f[2], b, (u32)f[3]) + scope_umul24_byte1(px, (u32)f[1]) + scope_umul24_byte2(px, (u32)f[0]);
+}
+
 /* worst: running per-half minimum of the fractions' upper 16 bits.  VSSKEY: the result is the vectorscope's bin key
  * (0, U, V, 0) instead of the texel (U, Y, V, 255) -- the same single v_perm_b32 with another selector. */
 template <bool VSSKEY>
 __device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool need_uv, bool need_y, u32 &worst)
 {
-	const int b = (int)(px & 0xffu), g = (int)((px >> 8) & 0xffu), r = (int)((px >> 16) & 0xffu);
+	const u32 b = px & 0xffu;
 	u32 out = 0xff000000u;
 	if (need_uv) {
-		const u32 eu = (u32)scope_mad24(k.fu[0], r, scope_mad24(k.fu[1], g, scope_mad24(k.fu[2], b, k.fu[3])));
-		const u32 ev = (u32)scope_mad24(k.fv[0], r, scope_mad24(k.fv[1], g, scope_mad24(k.fv[2], b, k.fv[3])));
+		const u32 eu = scope_k0_row(px, (int)b, k.fu);
+		const u32 ev = scope_k0_row(px, (int)b, k.fv);
 		worst = scope_pk_min_u16(worst, scope_perm(ev, eu, 0x06050201u));
 		out = scope_perm(ev, eu, VSSKEY ? 0x0c07030cu : 0x0d070c03u); /* 0, U, V, 0 or U, 0, V, 255 */
 	}
 	if (need_y) {
-		const u32 ey = scope_umad24((u32)k.fy[0], (u32)r,
-					    scope_umad24((u32)k.fy[1], (u32)g, scope_umad24((u32)k.fy[2], (u32)b, (u32)k.fy[3])));
+		const u32 ey = scope_k0_row_y(px, b, k.fy);
 		worst = scope_pk_min_u16(worst, scope_perm(ey, ey, 0x06050201u));
 		out = scope_perm(ey, out, 0x03020700u);
 	}
@@ -389,7 +399,10 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
  *                                                      chroma cluster then share their banks: -17 % on
  *                                                      concentrated chroma, +1..5 % elsewhere)
  * With HASH 0 sixteen consecutive rows start on sixteen different multiples of eight words, so a chroma cluster
- * of 16 x 16 bins is spread over all banks.
+ * of 16 x 16 bins is spread over all banks.  (Round 2 also tried getting that spread from a row pitch of 136 words,
+ * with the LDS address from one multiply-add and the pixel travelling as (address, increment): five VALU
+ * instructions per pixel instead of six, yet 1-2 % slower on every kind of content -- the adds of a cell then issue
+ * back to back instead of between the address arithmetic of their neighbours.  Not kept.)
  *
  * A pixel's bin travels as a KEY = u << 8 | v << 16 (vss_bin: one v_perm_b32 from the texel, or straight from the
  * fixed-point sums when K0 is fused).  Equal keys <=> equal bins; the bin index u + 256*(255 - v) is never
@@ -414,7 +427,7 @@ template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u
 	else
 		byte = scope_bitop3<0x78>(t, key >> 11, 0x1e0u) & 0x1fffcu; /* t ^ (v << 5 & 0x1e0); key >> 11 = v << 5 | u >> 3 */
 	/* half u & 1 = bit 8 of the key; bits 4..7 are zero, so the shift count is 0 or 16 */
-	atomicAdd((u32 *)((uint8_t *)tab + byte), n << ((key >> 4) & 31u));
+	scope_lds_add_at(tab, byte, n << ((key >> 4) & 31u));
 }
 
 /* Flat content (screen capture, graphics, letterbox, a paused scene): almost every pixel of a lane's
@@ -605,6 +618,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 							       u32 xbyte_b, u32 glog2, ScopeK0 k0, uint8_t *dst, uint8_t *pmask)
 {
 	u32 *tab = scope_lds;
+	scope_lds_is_at_zero(tab);
 	const u32 unit = blockIdx.x;
 	const u32 frame = unit / slices;
 	const u32 slice = unit - frame * slices;
@@ -1382,8 +1396,8 @@ Regions split_regions(const ScopeFrameSet &fs)
 	return r;
 }
 
-const u32 VSS_LDS_BYTES = VSS_WORDS * 4u;
 const u32 HIS_LDS_BYTES = HIS_WORDS * 4u;
+const u32 VSS_LDS_BYTES = VSS_WORDS * 4u;
 const u32 WVS_HIS_LDS_BYTES = 768u * 4u; /* the histogram totals of one unit */
 const u32 WVS_LDS_BYTES = 3u * WVS_CH_WORDS * 4u + WVS_HIS_LDS_BYTES;
 

@@ -85,6 +85,41 @@ template <unsigned TT> __device__ __forceinline__ unsigned scope_bitop3(unsigned
 	return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
 }
 
+/* ds_add_u32 of n at byte offset `byte` of the kernel's dynamic LDS block.  The address is built from the offset alone:
+ * through a (tab + offset) pointer hipcc adds the block's LDS address -- the literal 0, resolved too late to fold --
+ * with a v_add_u32 in front of every atomic, one VALU instruction per pixel in the vectorscope.  Only for kernels whose
+ * dynamic block starts at LDS address 0, i.e. that declare no static __shared__ (scope_lds_is_at_zero traps otherwise). */
+typedef __attribute__((address_space(3))) unsigned scope_lds_word;
+__device__ __forceinline__ void scope_lds_add_at(unsigned *tab, unsigned byte, unsigned n)
+{
+	(void)tab;
+	__hip_atomic_fetch_add((scope_lds_word *)(__UINTPTR_TYPE__)byte, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void scope_lds_is_at_zero(unsigned *tab)
+{
+	if ((unsigned)(__UINTPTR_TYPE__)(scope_lds_word *)tab != 0u)
+		__builtin_trap();
+}
+
+/* Byte B of x times a 24-bit factor, in ONE instruction: the SDWA form of v_mul_*_u24/i24 takes the byte straight out of
+ * the register.  hipcc finds this form for some shapes of the surrounding code and not for others (then it is a shift,
+ * a mask and a multiply: +4 VALU instructions per texel in the fused kernels), hence the inline asm.  The factor is
+ * wave-uniform (a kernel argument or a constant): SDWA encodes no literal, so it travels in an SGPR. */
+#define SCOPE_MUL24_BYTE(name, insn, type, sel)                                                                             \
+	__device__ __forceinline__ type name(unsigned x, type factor)                                                      \
+	{                                                                                                                    \
+		type r;                                                                                                      \
+		asm(insn " %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel " src1_sel:DWORD"                    \
+		    : "=v"(r)                                                                                                \
+		    : "v"(x), "s"(factor));                                                                                  \
+		return r;                                                                                                    \
+	}
+SCOPE_MUL24_BYTE(scope_mul24_byte1, "v_mul_i32_i24_sdwa", int, "BYTE_1")
+SCOPE_MUL24_BYTE(scope_mul24_byte2, "v_mul_i32_i24_sdwa", int, "BYTE_2")
+SCOPE_MUL24_BYTE(scope_umul24_byte1, "v_mul_u32_u24_sdwa", unsigned, "BYTE_1")
+SCOPE_MUL24_BYTE(scope_umul24_byte2, "v_mul_u32_u24_sdwa", unsigned, "BYTE_2")
+#undef SCOPE_MUL24_BYTE
+
 /* Every VMEM operation of this wave (loads, stores, atomics without return) has been acknowledged.  Inline asm:
  * hipcc (ROCm 7.2) drops a builtin wait when its own scoreboard says nothing is outstanding (MI355X_MICROARCH.md). */
 __device__ __forceinline__ void scope_drain_vmem()

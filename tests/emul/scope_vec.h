@@ -92,6 +92,31 @@ static inline void scope_drain_vmem()
 {
 }
 
+static inline int scope_mul24_byte1(unsigned x, int f)
+{
+	return (int)((x >> 8) & 0xffu) * f;
+}
+static inline int scope_mul24_byte2(unsigned x, int f)
+{
+	return (int)((x >> 16) & 0xffu) * f;
+}
+static inline unsigned scope_umul24_byte1(unsigned x, unsigned f)
+{
+	return ((x >> 8) & 0xffu) * f;
+}
+static inline unsigned scope_umul24_byte2(unsigned x, unsigned f)
+{
+	return ((x >> 16) & 0xffu) * f;
+}
+/* the emulated LDS block is an ordinary array: byte offset -> word */
+static inline void scope_lds_add_at(unsigned *tab, unsigned byte, unsigned n)
+{
+	__atomic_fetch_add(tab + (byte >> 2), n, __ATOMIC_RELAXED);
+}
+static inline void scope_lds_is_at_zero(unsigned *)
+{
+}
+
 static inline unsigned scope_wave_sum(unsigned x)
 {
 	return x;

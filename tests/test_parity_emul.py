@@ -48,9 +48,11 @@ def test_vectorscope_saturation_and_epochs(emul_ctx, oracle):
 
 
 @pytest.mark.parametrize("cs", [1, 2])
-def test_vectorscope_fused_k0(emul_ctx, oracle, cs):
-    pc.check_vectorscope(emul_ctx, oracle, 70, 9, 1, None, fuse=True, colorspace=cs)
-    pc.check_vectorscope(emul_ctx, oracle, 64, 8, 4, None, fuse=True, colorspace=cs)
+@pytest.mark.parametrize("hash_", [0, 1])
+def test_vectorscope_fused_k0(emul_ctx, oracle, cs, hash_):
+    with pc.options(emul_ctx, **{"vss.hash": hash_}):
+        pc.check_vectorscope(emul_ctx, oracle, 70, 9, 1, None, fuse=True, colorspace=cs)
+        pc.check_vectorscope(emul_ctx, oracle, 64, 8, 4, None, fuse=True, colorspace=cs)
 
 
 @pytest.mark.parametrize("comp", pc.COMPONENTS)

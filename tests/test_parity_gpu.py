@@ -266,6 +266,19 @@ def test_fused_k0(hip_ctx, oracle, cs):
     pc.check_histogram_counts(hip_ctx, oracle, 640, 360, 1, 0x70, None, fuse=True, colorspace=cs)
 
 
+@pytest.mark.parametrize("cs", [1, 2])
+@pytest.mark.parametrize("hash_", [0, 1])
+def test_fused_vectorscope_all_colours(hip_ctx, oracle, cs, hash_):
+    """All 2^24 colours through the vectorscope's own fused K0 (fixed point with its fp32 fallback): 64 slices see 262144 colours each, so no bin of a partial saturates early."""
+    v = np.arange(1 << 24, dtype=np.uint32) | np.uint32(0xFF000000)
+    rgb = v.view(np.uint8).reshape(4096, 4096 * 4)
+    want = oracle.vectorscope(oracle.rgb_to_yuv(rgb, 4096, cs), 4096)
+    with pc.options(hip_ctx, **{"vss.hash": hash_}):
+        got, st = hip_ctx.vectorscope(rgb=rgb, width=4096, colorspace=cs, fuse_k0=True)
+    assert st == 0
+    pc.assert_same(got, want, f"fused vectorscope, all colours, cs{cs} hash{hash_}")
+
+
 @pytest.mark.parametrize("logscale,fixed,ratio", [(0, 0, 0), (1, 0, 0), (0, 100, 0), (1, 0, 250), (0, 0, 1), (1, 5, 9)])
 def test_histogram_level_pass(hip_ctx, oracle, logscale, fixed, ratio):
     pc.check_histogram_full(hip_ctx, oracle, 640, 360, 2, 0x07, logscale, fixed, ratio)

@@ -240,6 +240,76 @@ static int placement_main()
 	return 0;
 }
 
+// Round 2, second look: is it the position in the allocation sequence (= where in VRAM the driver put the buffer) that
+// decides?  (1) 24 allocations in a row; (2) free the first twelve and allocate twelve new ones -- do the new ones take
+// over the freed (fast) region and its speed?  (3) everything freed, ONE allocation of 16 x that size read window by
+// window.  Interleaved reading only (placement_main showed that the access order does not matter).
+static float placement_read(const uint32_t *p, uint64_t n16, uint32_t *sink)
+{
+	return run_pp<4, true, 0>((const v4 *)p, n16, sink, 256, 1024, 20);
+}
+
+static int placement2_main()
+{
+	const uint64_t bytes = 32ull * 3840 * 2160 * 4;
+	const uint64_t n16 = bytes / 16;
+	const int NB = 24;
+	uint32_t *buf[NB], *sink;
+	size_t fr = 0, tot = 0;
+	hipMalloc((void **)&sink, 64);
+	for (int i = 0; i < NB; i++) {
+		if (hipMalloc((void **)&buf[i], bytes) != hipSuccess)
+			return 1;
+		hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf[i], bytes / 4);
+	}
+	hipDeviceSynchronize();
+	for (int i = 0; i < 300; i++)
+		hipLaunchKernelGGL((read_kernel<4, true>), dim3(256), dim3(1024), 0, 0, (const v4 *)buf[0], n16, sink);
+	hipDeviceSynchronize();
+	hipMemGetInfo(&fr, &tot);
+	printf("# (1) %d allocations of %.2f GB in a row (free now %.1f of %.1f GB)\n", NB, bytes / 1e9, fr / 1e9, tot / 1e9);
+	for (int i = 0; i < NB; i++) {
+		printf("alloc %2d at %p  %7.1f GB/s\n", i, (void *)buf[i], bytes / (placement_read(buf[i], n16, sink) * 1e-3) / 1e9);
+		fflush(stdout);
+	}
+	printf("# (2) the first twelve freed, twelve new ones allocated\n");
+	for (int i = 0; i < 12; i++)
+		hipFree(buf[i]);
+	for (int i = 0; i < 12; i++) {
+		if (hipMalloc((void **)&buf[i], bytes) != hipSuccess)
+			return 1;
+		hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf[i], bytes / 4);
+	}
+	hipDeviceSynchronize();
+	for (int i = 0; i < 12; i++) {
+		printf("new   %2d at %p  %7.1f GB/s\n", i, (void *)buf[i], bytes / (placement_read(buf[i], n16, sink) * 1e-3) / 1e9);
+		fflush(stdout);
+	}
+	for (int i = 12; i < NB; i += 4)
+		printf("old   %2d at %p  %7.1f GB/s\n", i, (void *)buf[i], bytes / (placement_read(buf[i], n16, sink) * 1e-3) / 1e9);
+	for (int i = 0; i < NB; i++)
+		hipFree(buf[i]);
+	printf("# (3) everything freed; one allocation of 16 x %.2f GB, read window by window\n", bytes / 1e9);
+	uint32_t *big;
+	if (hipMalloc((void **)&big, bytes * 16) != hipSuccess)
+		return 1;
+	hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, big, bytes * 16 / 4);
+	hipDeviceSynchronize();
+	for (int i = 0; i < 16; i++) {
+		const uint32_t *w = big + (uint64_t)i * (bytes / 4);
+		printf("window %2d at %p  %7.1f GB/s\n", i, (const void *)w, bytes / (placement_read(w, n16, sink) * 1e-3) / 1e9);
+		fflush(stdout);
+	}
+	printf("# (4) the same process, a second allocation of one buffer size\n");
+	uint32_t *late;
+	if (hipMalloc((void **)&late, bytes) != hipSuccess)
+		return 1;
+	hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, late, bytes / 4);
+	hipDeviceSynchronize();
+	printf("late      at %p  %7.1f GB/s\n", (void *)late, bytes / (placement_read(late, n16, sink) * 1e-3) / 1e9);
+	return 0;
+}
+
 // Round 2: what does ONE 4K frame (33 MB) cost when nothing but the read is done?  The yardstick for the one- and
 // three-frame launches of the scopes (tools/latency_probe.py): launches back to back over a pool of 24 distinct frames.
 template <typename K> static float run_small(K launch, int reps)
@@ -298,6 +368,8 @@ int main(int argc, char **argv)
 {
 	if (argc > 1 && !strcmp(argv[1], "placement"))
 		return placement_main();
+	if (argc > 1 && !strcmp(argv[1], "placement2"))
+		return placement2_main();
 	if (argc > 1 && !strcmp(argv[1], "small"))
 		return small_main();
 	const uint64_t bytes = 32ull * 3840 * 2160 * 4;
