@@ -401,6 +401,14 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 		uint32_t bands = pick_slices(ctx, nf, strips);
 		if (bands > 16)
 			bands = 16;
+		/* A launch that would need row bands to fill the chip (one 4K frame: 60 strips) takes 16-column strips instead
+		 * when that gives one round of units (240): no partial tables, no second kernel -- 20.6 -> 15.1 us per 4K
+		 * frame.  Two rounds of narrow units lose to row bands (two 4K frames: 27.1 vs 24.7 us).  Vector shape only. */
+		const int narrow = ctx->tn.wvs_strip != 64 &&
+				   (ctx->tn.wvs_strip == 16 || (bands > 1 && nf * scope_wvs_strips(width, 1) <= (uint32_t)ctx->num_cu)) &&
+				   scope_wvs_vector_shape(fs, dst, ctx->tn);
+		if (narrow)
+			bands = 1;
 		/* the partial tables are combined 16 bytes at a time */
 		if (bands > 1 && ((table & 15u) || (((uintptr_t)dst) & 15u)))
 			bands = 1;
@@ -414,13 +422,14 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 			bands = min_bands;
 		}
 		if (bands == 1) {
-			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->num_cu, ctx->tn, ctx->stream, his, tm_));
+			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, 1, chmask, fuse, colorspace, dst, ctx->num_cu, ctx->tn, ctx->stream, his, tm_,
+							   narrow));
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * bands * table);
 			if (st)
 				return st;
 			TIMED_LAUNCH(ctx, scope_launch_wvs(fs, bands, chmask, fuse, colorspace, ctx->partial, ctx->num_cu, ctx->tn, ctx->stream,
-							   his, tm_));
+							   his, tm_, narrow));
 			HIP_TRY(ctx, scope_launch_sat_reduce(ctx->partial, dst, nf, bands, table, 0, ctx->stream));
 		}
 		if (!(flags & SCOPE_IN_DEVICE) && f0 + nf < n)
@@ -634,6 +643,7 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.vss_groups_log2 = -1; /* auto: 8 lane-group streams for batches, one stream for launches of a few frames */
 	ctx->tn.his_unroll = 1;
 	ctx->tn.wvs_wide = 1;
+	ctx->tn.wvs_strip = 0;
 	ctx->tn.wvs_persist = 1;
 	ctx->tn.wvs_per_cu = 1;
 	ctx->tn.fold = 1;
@@ -749,6 +759,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.wvs_persist = value != 0;
 	else if (!strcmp(key, "wvs.wide"))
 		ctx->tn.wvs_wide = value != 0;
+	else if (!strcmp(key, "wvs.strip"))
+		ctx->tn.wvs_strip = value;
 	else if (!strcmp(key, "slices"))
 		ctx->slices_override = value;
 	else

@@ -62,6 +62,7 @@ struct ScopeTuning {
 			      * loads in flight per CU, which is what the HBM likes best (+5 % for 1-2 channels) */
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
 	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */
+	int wvs_strip;       /* 0: 16-column strips for launches that would otherwise need row bands, 64 elsewhere; 64 / 16: always */
 	int nt_loads;        /* 1: non-temporal pixel loads */
 };
 
@@ -116,7 +117,11 @@ struct ScopeHisSink {
 };
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
 			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st,
-			    const ScopeHisSink *his = NULL, const ScopeTiming *tm = NULL);
+			    const ScopeHisSink *his = NULL, const ScopeTiming *tm = NULL, int narrow = 0);
+/* narrow != 0: strips of 16 columns instead of 64 -- four times the units, for launches of one or two frames, which
+ * then need no row bands and no partial tables (vector shape only: scope_wvs_vector_shape must hold for fs and dst). */
+bool scope_wvs_vector_shape(const ScopeFrameSet &fs, const uint8_t *dst, const ScopeTuning &tn);
+uint32_t scope_wvs_strips(uint32_t width, int narrow);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
  * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */

@@ -816,6 +816,14 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
 #ifndef WVS_U
 #define WVS_U 2 /* row pairs per wave per batch; two batches in flight (measured: 2 beats 4 by 4 %, 1 loses 17 %) */
 #endif
+/* Strip widths (SW).  64 columns is the batch shape.  A launch of one or two frames has too few 64-column strips to
+ * fill the chip (3840 / 64 = 60) and used to be cut into row bands whose dense partial tables a second kernel summed
+ * (1.85 x the algorithmic traffic).  With SW = 16 a 4K frame is 240 units and needs neither: a wave then reads EIGHT
+ * rows of 64 bytes at a time, and row r of the eight counts in replica r & 3 of the strip's table, which makes the
+ * LDS side -- word value*32 + (lane & 31), 32 different banks per half wave -- the very same as for SW = 64; the
+ * flush adds the four replicas up. */
+#define WVS_NARROW 16
+#define WVS_NARROW_U 4 /* a unit is only ~140 KB per workgroup: deeper batches, fewer round trips */
 
 /* Counter of (value, column c of the strip): 16-bit half (c & 1) of word value*32 + (c >> 1).
  *
@@ -846,13 +854,14 @@ struct WvsUnit {
 	const uint8_t *rows; /* first row of the band (always a readable address) */
 	u32 frame, band, strip;
 	u32 nrows;  /* rows in the band */
-	u32 npairs; /* row pairs = nrows / 2; an odd last row is handled apart */
+	u32 npairs; /* row groups = nrows / (rows per wave instruction: 2, or 8 for narrow strips); the rows left over are handled apart */
 	u32 slots;  /* batches per wave, rounded up to an even number >= 2 (slots past the data load nothing useful) */
 };
 
-__device__ __forceinline__ WvsUnit wvs_unit(const ScopeFrameSet &fs, u32 unit, u32 total, u32 strips, u32 bands,
+template <int SW> __device__ __forceinline__ WvsUnit wvs_unit(const ScopeFrameSet &fs, u32 unit, u32 total, u32 strips, u32 bands,
 					    u32 nwaves)
 {
+	constexpr u32 RW = 128u / SW, U = SW == WVS_NARROW ? WVS_NARROW_U : WVS_U;
 	WvsUnit u;
 	if (unit >= total) { /* past the end: two empty slots */
 		u.rows = fs.plane[0];
@@ -860,6 +869,11 @@ __device__ __forceinline__ WvsUnit wvs_unit(const ScopeFrameSet &fs, u32 unit, u
 		u.slots = 2;
 		return u;
 	}
+	/* Narrow strips read half a cache line per row: the workgroup that reads the other half should sit on the same
+	 * XCD (same L2) and run at the same time.  Workgroups b and b + 8 do (observed placement: XCD = b % 8; a matter of
+	 * speed only), so they take neighbouring strips. */
+	if (SW == WVS_NARROW && unit < (total & ~15u))
+		unit = (unit & ~15u) + ((unit & 7u) << 1) + ((unit >> 3) & 1u);
 	const u32 per_frame = strips * bands;
 	u.frame = unit / per_frame;
 	const u32 rem = unit - u.frame * per_frame;
@@ -868,8 +882,8 @@ __device__ __forceinline__ WvsUnit wvs_unit(const ScopeFrameSet &fs, u32 unit, u
 	const u32 r0 = scope_slice_begin(fs.height, u.band, bands);
 	u.nrows = scope_slice_begin(fs.height, u.band + 1, bands) - r0;
 	u.rows = fs.plane[u.frame] + (size_t)r0 * fs.linesize;
-	u.npairs = u.nrows >> 1;
-	const u32 nbatch = (u.npairs + WVS_U - 1) / WVS_U;
+	u.npairs = u.nrows / RW;
+	const u32 nbatch = (u.npairs + U - 1) / U;
 	u.slots = max(2u, ((nbatch + nwaves - 1) / nwaves + 1u) & ~1u);
 	return u;
 }
@@ -894,11 +908,14 @@ struct ScopeWvsHis {
 	u32 chmask;   /* channels the caller wants counted (a subset of CH); the others stay zero */
 };
 
-template <int CH, bool FUSE, bool WIDE, bool HIS>
+template <int CH, bool FUSE, bool WIDE, bool HIS, int SW>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, ScopeK0 k0,
 							       uint8_t *dst, ScopeWvsHis his)
 {
-	constexpr int U = WVS_U;
+	static_assert(SW == 64 || (SW == WVS_NARROW && WIDE), "narrow strips exist in the vector shape only");
+	constexpr int U = SW == WVS_NARROW ? WVS_NARROW_U : WVS_U;
+	constexpr u32 LR = SW / 2u;   /* lanes per row (two texels each) */
+	constexpr u32 RW = 64u / LR;  /* rows per wave instruction */
 	constexpr u32 slot0 = 0, slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1), nch = slot2 + ((CH >> 2) & 1);
 	constexpr bool need_uv = (CH & 5) != 0, need_y = (CH & 2) != 0;
 
@@ -906,21 +923,23 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 	const u32 W = fs.width;
 	const u32 total = fs.n_frames * strips * bands;
 	const u32 lane = threadIdx.x & 63u;
-	const u32 pair = lane & 31u;  /* columns 2*pair, 2*pair+1 of the strip */
-	const u32 second = lane >> 5; /* which row of the row pair */
+	const u32 pair = lane & (LR - 1u); /* columns 2*pair, 2*pair+1 of the strip */
+	const u32 second = lane / LR;      /* which row of the row group */
 	const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const u32 nwaves = blockDim.x >> 6;
-	const u32 wbyte = pair << 2;
+	/* table column of the lane: the strip's column pair for SW = 64; for narrow strips replica (row & 3) of it, which
+	 * is again lane & 31 -- each half wave covers one 32-word value group whatever the strip width */
+	const u32 wbyte = (lane & 31u) << 2;
 	const u32 second_off = second * fs.linesize;
-	const size_t pair_bytes = (size_t)2u * fs.linesize;
+	const size_t pair_bytes = (size_t)RW * fs.linesize;
 
 	/* ---- issue side: where the wave's load stream is ------------------------------------------ */
 	u32 unit_i = blockIdx.x, slot_i = 0;
-	WvsUnit ui = wvs_unit(fs, unit_i, total, strips, bands, nwaves);
+	WvsUnit ui = wvs_unit<SW>(fs, unit_i, total, strips, bands, nwaves);
 	u32 lo0 = 0, lo1 = 0; /* per-lane byte offsets inside a row pair of the issue-side unit */
 #define WVS_LANE_OFFSETS()                                                                                    \
 	do {                                                                                                  \
-		const u32 xs_ = ui.strip * SCOPE_WVS_STRIP, x0_ = xs_ + 2u * pair;                            \
+		const u32 xs_ = ui.strip * (u32)SW, x0_ = xs_ + 2u * pair;                                    \
 		lo0 = ((x0_ < W) ? x0_ : xs_) * 4u + second_off;                                              \
 		lo1 = ((x0_ + 1u < W) ? x0_ + 1u : xs_) * 4u + second_off;                                    \
 	} while (0)
@@ -936,7 +955,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 		if (slot_i == ui.slots) {                                                                     \
 			unit_i += gridDim.x;                                                                  \
 			slot_i = 0;                                                                           \
-			ui = wvs_unit(fs, unit_i, total, strips, bands, nwaves);                              \
+			ui = wvs_unit<SW>(fs, unit_i, total, strips, bands, nwaves);                          \
 			WVS_LANE_OFFSETS();                                                                   \
 		}                                                                                             \
 		const u32 first_ = (wave + slot_i * nwaves) * (u32)U;                                         \
@@ -980,8 +999,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 	 * with the first slot pair peeled the compiler can count them (vmcnt(11..8) instead of (7..4)) and the
 	 * wave does not wait for the table write-out before it goes on binning. */
 	auto run_unit = [&](const u32 unit_b, auto steady) {
-		const WvsUnit ub = wvs_unit(fs, unit_b, total, strips, bands, nwaves);
-		const u32 xs = ub.strip * SCOPE_WVS_STRIP; /* always < W */
+		const WvsUnit ub = wvs_unit<SW>(fs, unit_b, total, strips, bands, nwaves);
+		const u32 xs = ub.strip * (u32)SW; /* always < W */
 		const u32 x0 = xs + 2u * pair;
 		const bool live0 = x0 < W, live1 = x0 + 1u < W;
 
@@ -1004,9 +1023,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 			WVS_BIN(vb, okb);
 			WVS_ISSUE(vb, okb);
 		}
-		/* an odd last row of the band: first half of wave 0 */
-		if ((ub.nrows & 1u) && wave == 0 && second == 0) {
-			const uint8_t *p = ub.rows + (size_t)(ub.nrows - 1u) * fs.linesize;
+		/* the rows a band has beyond whole row groups (an odd last row; up to seven for narrow strips): wave 0 */
+		const u32 left = ub.nrows - ub.npairs * RW;
+		if (left && wave == 0 && second < left) {
+			const uint8_t *p = ub.rows + (size_t)(ub.npairs * RW + second) * fs.linesize;
 			u32 p0 = *(const u32 *)(p + (live0 ? x0 : xs) * 4u), p1 = *(const u32 *)(p + (live1 ? x0 + 1u : xs) * 4u);
 			if (FUSE) {
 				p0 = scope_k0_texel(p0, k0, need_uv, need_y);
@@ -1065,7 +1085,52 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 			if (CH & 4)
 				scope_row16_add(&hsum[2u * 256u + value], real ? n[2] : 0u);
 		};
-		if (WIDE) {
+		if (SW == WVS_NARROW) {
+			/* Narrow strip: 256 values x 4 column groups = one (value, group) per thread.  The sixteen lanes of a
+			 * DPP row take four consecutive values x four groups and read the four replicas in rotated order --
+			 * lane (rho, g) reads replica (rho + j) & 3 at step j -- so at every step the sixteen lanes cover all 32
+			 * banks.  The replica counts of a column add up to at most the band's rows (< 65536): the packed
+			 * 16-bit halves cannot carry. */
+			const u32 groups = (min(W - xs, (u32)SW)) >> 2;
+			const u32 g4 = threadIdx.x & 3u, rho = (threadIdx.x >> 2) & 3u;
+			const u32 value = ((threadIdx.x >> 4) << 2) + rho;
+			const u32 g = min(g4, groups - 1u);
+			uint2 acc[3] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+#pragma unroll
+			for (u32 j = 0; j < 4; j++) {
+				const u32 w = (value << 5) + (((rho + j) & 3u) << 3) + 2u * g;
+				if (CH & 1) {
+					const uint2 c = *(const uint2 *)&tab[slot0 * WVS_CH_WORDS + w];
+					acc[0].x += c.x;
+					acc[0].y += c.y;
+				}
+				if (CH & 2) {
+					const uint2 c = *(const uint2 *)&tab[slot1 * WVS_CH_WORDS + w];
+					acc[1].x += c.x;
+					acc[1].y += c.y;
+				}
+				if (CH & 4) {
+					const uint2 c = *(const uint2 *)&tab[slot2 * WVS_CH_WORDS + w];
+					acc[2].x += c.x;
+					acc[2].y += c.y;
+				}
+			}
+			u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+			for (u32 c = 0; c < 3; c++) {
+				if (!((CH >> c) & 1))
+					continue;
+				o[0] |= min(acc[c].x & 0xffffu, 255u) << (8u * c);
+				o[1] |= min(acc[c].x >> 16, 255u) << (8u * c);
+				o[2] |= min(acc[c].y & 0xffffu, 255u) << (8u * c);
+				o[3] |= min(acc[c].y >> 16, 255u) << (8u * c);
+				if (HIS && g4 < groups) /* lanes past the right edge repeat a column group */
+					atomicAdd(&hsum[c * 256u + value],
+						  (acc[c].x & 0xffffu) + (acc[c].x >> 16) + (acc[c].y & 0xffffu) + (acc[c].y >> 16));
+			}
+			const scope_v4 t = {o[0], o[1], o[2], o[3]};
+			__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
+		} else if (WIDE) {
 			/* width % 4 == 0 and a 16-byte aligned table: a fixed number of unconditional vector stores per
 			 * lane (lanes past the right edge repeat the strip's last column group), so the waits of the
 			 * next unit's first batch can be counted exactly and do not include these stores. */
@@ -1500,20 +1565,23 @@ struct WvsArgs {
 	const ScopeTiming *tm;
 };
 
-template <int CH, bool FUSE, bool WIDE, bool HIS> hipError_t wvs_variant(const WvsArgs *a)
+template <int CH, bool FUSE, bool WIDE, bool HIS, int SW> hipError_t wvs_variant(const WvsArgs *a)
 {
 	if (!a)
-		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE, WIDE, HIS>,
+		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE, WIDE, HIS, SW>,
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WVS_LDS_BYTES);
-	SCOPE_LAUNCH((scope_wvs_kernel<CH, FUSE, WIDE, HIS>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, a->tm, *a->fs,
+	SCOPE_LAUNCH((scope_wvs_kernel<CH, FUSE, WIDE, HIS, SW>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, a->tm, *a->fs,
 		     a->strips, a->bands, a->k0, a->dst, a->his);
 	return hipGetLastError();
 }
+/* wide: 0 scalar shape, 1 vector shape, 2 vector shape with narrow strips */
 template <int CH, bool HIS> hipError_t wvs_pick_shape(int fuse, int wide, const WvsArgs *a)
 {
+	if (wide == 2)
+		return fuse ? wvs_variant<CH, true, true, HIS, WVS_NARROW>(a) : wvs_variant<CH, false, true, HIS, WVS_NARROW>(a);
 	if (fuse)
-		return wide ? wvs_variant<CH, true, true, HIS>(a) : wvs_variant<CH, true, false, HIS>(a);
-	return wide ? wvs_variant<CH, false, true, HIS>(a) : wvs_variant<CH, false, false, HIS>(a);
+		return wide ? wvs_variant<CH, true, true, HIS, 64>(a) : wvs_variant<CH, true, false, HIS, 64>(a);
+	return wide ? wvs_variant<CH, false, true, HIS, 64>(a) : wvs_variant<CH, false, false, HIS, 64>(a);
 }
 template <bool HIS> hipError_t wvs_pick_ch(u32 chmask, int fuse, int wide, const WvsArgs *a)
 {
@@ -1555,9 +1623,9 @@ hipError_t scope_kernels_init(void)
 					e = his_pick(unroll, nt, fuse, NULL);
 			}
 	for (u32 chmask = 1; chmask <= 7; chmask++)
-		for (int shape = 0; shape < 8; shape++)
+		for (int shape = 0; shape < 12; shape++)
 			if (e == hipSuccess)
-				e = wvs_pick(chmask, shape & 1, (shape >> 1) & 1, shape >> 2, NULL);
+				e = wvs_pick(chmask, shape & 1, (shape >> 1) % 3, shape / 6, NULL);
 	return e;
 }
 
@@ -1638,19 +1706,36 @@ hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t c
 	return his_pick(tn.his_unroll, tn.nt_loads, fuse_k0, &a);
 }
 
+bool scope_wvs_vector_shape(const ScopeFrameSet &fs, const uint8_t *dst, const ScopeTuning &tn)
+{
+	/* The vector path (8-byte texel-pair loads, 16-byte table stores) needs width % 4 == 0, 8-byte aligned
+	 * rows and a 16-byte aligned table; anything else takes the 4-byte path. */
+	bool wide = tn.wvs_wide && (fs.width & 3u) == 0 && (fs.linesize & 7u) == 0 && (((size_t)dst) & 15u) == 0;
+	for (u32 f = 0; wide && f < fs.n_frames; f++)
+		wide = (((size_t)fs.plane[f]) & 7u) == 0;
+	return wide;
+}
+
+uint32_t scope_wvs_strips(uint32_t width, int narrow)
+{
+	const u32 sw = narrow ? (u32)WVS_NARROW : SCOPE_WVS_STRIP;
+	return (width + sw - 1u) / sw;
+}
+
 hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t chmask, int fuse_k0, int colorspace,
 			    uint8_t *dst, uint32_t num_cu, const ScopeTuning &tn, hipStream_t st, const ScopeHisSink *his,
-			    const ScopeTiming *tm)
+			    const ScopeTiming *tm, int narrow)
 {
-	const u32 strips = (fs.width + SCOPE_WVS_STRIP - 1) / SCOPE_WVS_STRIP;
+	const u32 strips = scope_wvs_strips(fs.width, narrow);
 	const u32 nch = (chmask & 1u) + ((chmask >> 1) & 1u) + ((chmask >> 2) & 1u);
 	if (nch == 0)
 		return hipErrorInvalidValue; /* the C-ABI zero-fills such tables itself */
-	/* The vector path (8-byte texel-pair loads, 16-byte table stores) needs width % 4 == 0, 8-byte aligned
-	 * rows and a 16-byte aligned table; anything else takes the 4-byte path. */
-	int wide = tn.wvs_wide && (fs.width & 3u) == 0 && (fs.linesize & 7u) == 0 && (((size_t)dst) & 15u) == 0;
-	for (u32 f = 0; wide && f < fs.n_frames; f++)
-		wide = (((size_t)fs.plane[f]) & 7u) == 0;
+	int wide = scope_wvs_vector_shape(fs, dst, tn) ? 1 : 0;
+	if (narrow) {
+		if (!wide)
+			return hipErrorInvalidValue; /* narrow strips exist in the vector shape only: the caller checks */
+		wide = 2;
+	}
 	/* persistent workgroups: as many as are resident at once (LDS- or thread-limited), each walks units */
 	const u32 lds = nch * WVS_CH_WORDS * 4u + (his ? WVS_HIS_LDS_BYTES : 0u);
 	u32 per_cu = max(1u, min((u32)(SCOPE_CU_LDS_BYTES / lds), (u32)(2048u / SCOPE_BLOCK)));
@@ -1658,7 +1743,12 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 		per_cu = (u32)tn.wvs_per_cu;
 	const u32 resident = per_cu * max(1u, num_cu);
 	const u32 total = fs.n_frames * strips * bands;
-	const u32 grid = (tn.wvs_persist && total > resident) ? resident : total;
+	u32 grid = (tn.wvs_persist && total > resident) ? resident : total;
+	if (narrow && total > resident) {
+		/* equal rounds for every workgroup, in whole blocks of 16 (the XCD pairing of wvs_unit) */
+		const u32 rounds = (total + resident - 1u) / resident;
+		grid = min(resident, (((total + rounds - 1u) / rounds) + 15u) & ~15u);
+	}
 	ScopeWvsHis h = {NULL, NULL, NULL, 0};
 	if (his)
 		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};

@@ -67,7 +67,7 @@ def test_waveform_geometry(emul_ctx, oracle, w, h, ls):
 
 def test_waveform_saturation_and_bands(emul_ctx, oracle):
     pc.check_waveform(emul_ctx, oracle, 64, 600, 3, 0x07)  # every column saturates at 255
-    with pc.options(emul_ctx, slices=5):  # five row bands -> partial tables + saturating reduce
+    with pc.options(emul_ctx, slices=5, **{"wvs.strip": 64}):  # five row bands -> partial tables + saturating reduce
         pc.check_waveform(emul_ctx, oracle, 64, 600, 2, 0x70)
         pc.check_waveform(emul_ctx, oracle, 66, 40, 1, 0x07)  # width % 4 != 0: single band fallback
     with pc.options(emul_ctx, **{"wvs.wide": 0}):
@@ -94,6 +94,39 @@ def test_waveform_unit_walk(emul_ctx, oracle, persist):
         pc.check_waveform(emul_ctx, oracle, 64, 150, 14, 0x07)  # more batches than one slot pair per wave
         with pc.options(emul_ctx, slices=3):
             pc.check_waveform(emul_ctx, oracle, 66, 50, 7, 0x05)  # bands of different heights
+
+
+@pytest.mark.parametrize("w,h,ls", [(64, 36, None), (72, 9, None), (20, 7, 96), (4, 1, None), (132, 8, None), (320, 17, 1296)])
+def test_waveform_narrow_strips_geometry(emul_ctx, oracle, w, h, ls):
+    """16-column strips (the shape of one- and two-frame launches): eight rows per wave instruction into four table
+    replicas, ragged last strips, 1..7 rows left over, more than 16 units (the XCD pairing of neighbouring strips)."""
+    with pc.options(emul_ctx, **{"wvs.strip": 16}):
+        pc.check_waveform(emul_ctx, oracle, w, h, 1, 0x07, ls)
+
+
+@pytest.mark.parametrize("comp", pc.COMPONENTS)
+def test_waveform_narrow_strips_components(emul_ctx, oracle, comp):
+    with pc.options(emul_ctx, **{"wvs.strip": 16}):
+        pc.check_waveform(emul_ctx, oracle, 72, 19, 5, comp)
+
+
+def test_waveform_narrow_strips_saturation_walk_fused(emul_ctx, oracle):
+    with pc.options(emul_ctx, **{"wvs.strip": 16}):
+        pc.check_waveform(emul_ctx, oracle, 64, 600, 3, 0x07)  # every column saturates; replicas add up beyond 255
+        pc.check_waveform(emul_ctx, oracle, 16, 150, 14, 0x05)  # more batches than one slot pair per wave
+        pc.check_waveform(emul_ctx, oracle, 72, 9, 1, 0x20, None, fuse=True, colorspace=1)
+        pc.check_waveform(emul_ctx, oracle, 72, 9, 1, 0x50, None, fuse=True, colorspace=2)
+        with pc.options(emul_ctx, **{"wvs.persist": 0}):
+            pc.check_waveform(emul_ctx, oracle, 132, 21, 9, 0x20)
+    with pc.options(emul_ctx, slices=4):  # what would be four row bands becomes narrow strips, on its own
+        pc.check_waveform(emul_ctx, oracle, 64, 100, 2, 0x70)
+        pc.check_waveform_histogram(emul_ctx, oracle, 72, 36, 5)
+
+
+@pytest.mark.parametrize("w,h,dist", [(72, 36, 5), (132, 21, 2)])
+def test_waveform_histogram_one_pass_narrow_strips(emul_ctx, oracle, w, h, dist):
+    with pc.options(emul_ctx, **{"wvs.strip": 16}):
+        pc.check_waveform_histogram(emul_ctx, oracle, w, h, dist)
 
 
 def test_waveform_fused_k0(emul_ctx, oracle):

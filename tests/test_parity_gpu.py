@@ -167,6 +167,41 @@ def test_one_and_three_frame_launches_4k(hip_ctx, oracle):
             pc.assert_same(wvs[f].cpu().numpy().reshape(256, w, 4), oracle.waveform(rgbs[f], None, w, 0x07), f"wvs n{n} f{f}")
 
 
+@pytest.mark.parametrize("strip", [16, 64])
+def test_waveform_strip_widths(hip_ctx, oracle, strip):
+    """Both shapes a small launch can take -- 16-column strips (eight rows per wave instruction into four table
+    replicas, no partial tables) and 64-column strips cut into row bands (partial tables + saturating reduce) -- on
+    ragged last strips, left-over rows, padded pitches, saturating columns, fused K0, every component mask, with the
+    histogram riding on the pass, and for one, two and three 4K frames per launch."""
+    import torch
+
+    with pc.options(hip_ctx, **{"wvs.strip": strip}):
+        for comp in pc.COMPONENTS:
+            pc.check_waveform(hip_ctx, oracle, 328, 77, 5, comp)
+        pc.check_waveform(hip_ctx, oracle, 1924, 1083, 1, 0x07, 1924 * 4 + 64)
+        pc.check_waveform(hip_ctx, oracle, 640, 1500, 3, 0x07)  # flat: every column saturates
+        pc.check_waveform(hip_ctx, oracle, 4, 5, 1, 0x70)
+        pc.check_waveform(hip_ctx, oracle, 1280, 720, 2, 0x70, None, fuse=True, colorspace=1)
+        pc.check_waveform_histogram(hip_ctx, oracle, 1280, 723, 5)
+        pc.check_waveform(hip_ctx, oracle, 3840, 2160, 5, 0x07)
+        pc.check_waveform(hip_ctx, oracle, 3840, 2160, 2, 0x20)
+        w, h = 3840, 2160
+        rgbs = [oracle.fill_frame(w, h, d, 60 + d) for d in (1, 5, 2)]
+        tr = torch.from_numpy(np.stack(rgbs)).cuda()
+        for n in (1, 2, 3):
+            br = hip_ctx.make_device_batch(tr[:n], 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+            wvs = torch.empty((n, 256 * w * 4), dtype=torch.uint8, device="cuda")
+            cnt = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
+            for rep in range(2):
+                wvs.fill_(0xEE)
+                cnt.fill_(-1)
+                hip_ctx.waveform_histogram_batch_dev(br, 0x07, 0x07, wvs, cnt)
+                for f in range(n):
+                    pc.assert_same(wvs[f].cpu().numpy().reshape(256, w, 4), oracle.waveform(rgbs[f], None, w, 0x07), f"wvs strip{strip} n{n} f{f}")
+                    pc.assert_same(cnt[f].cpu().numpy().view(np.uint32).reshape(256, 4),
+                                   oracle.histogram_counts(rgbs[f], None, w, 0x07), f"his strip{strip} n{n} f{f}")
+
+
 @pytest.mark.parametrize("w,h,dist", [(640, 360, 5), (70, 9, 1), (1279, 300, 2), (330, 77, 3), (3840, 2160, 5)])
 def test_waveform_histogram_one_pass(hip_ctx, oracle, w, h, dist):
     """K2 + K3 from one read of the plane (the histogram is added up from the waveform's per-column counters at

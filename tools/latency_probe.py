@@ -63,7 +63,7 @@ def main():
         for nf in [int(x) for x in args.frames.split(",")]:
             groups = pool // nf
             for scope, optset in [(sc, os_) for sc in args.scopes.split(",") for os_ in sets]:
-                if optset and not any(kv.split(".")[0] in ("slices", "nt", {"vectorscope": "vss", "vectorscope_rgb": "vss", "histogram": "his", "waveform": "wvs"}[scope], "fold")
+                if optset and not any(kv.split("=")[0].split(".")[0] in ("slices", "nt", {"vectorscope": "vss", "vectorscope_rgb": "vss", "histogram": "his", "waveform": "wvs"}[scope], "fold")
                                       for kv in optset):
                     continue  # this option set does not concern this scope
                 for kv in optset:
