@@ -112,6 +112,7 @@ int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
  *   "vss.block" / "his.block" 0|64..1024   threads per workgroup (0 = 1024)
  *   "wvs.wide" 0|1, "wvs.persist" 0|1, "wvs.per_cu" 0|1|2   waveform load shape / persistent walk / workgroups per CU
  *   "wvs.strip" 0|16|64      waveform strip width: 16 columns for launches that would otherwise need row bands (0), or fixed
+ *   "wvs.deep" 0|1           batches: more loads in flight across each unit's table flush
  *   "fold" 0|1   the slices of a histogram frame meet inside the launch (atomics + last arrival) | partial tables + a second kernel
  *   "vss.sparse" 0|1   vectorscope partial tables hold only the 16-bin groups that are not empty
  *   "nt" 0|1     streaming (non-temporal) loads

@@ -644,6 +644,7 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.his_unroll = 1;
 	ctx->tn.wvs_wide = 1;
 	ctx->tn.wvs_strip = 0;
+	ctx->tn.wvs_deep = 1;
 	ctx->tn.wvs_persist = 1;
 	ctx->tn.wvs_per_cu = 1;
 	ctx->tn.fold = 1;
@@ -761,6 +762,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.wvs_wide = value != 0;
 	else if (!strcmp(key, "wvs.strip"))
 		ctx->tn.wvs_strip = value;
+	else if (!strcmp(key, "wvs.deep"))
+		ctx->tn.wvs_deep = value != 0;
 	else if (!strcmp(key, "slices"))
 		ctx->slices_override = value;
 	else

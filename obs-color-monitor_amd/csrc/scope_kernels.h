@@ -62,6 +62,7 @@ struct ScopeTuning {
 			      * loads in flight per CU, which is what the HBM likes best (+5 % for 1-2 channels) */
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
 	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */
+	int wvs_deep;        /* 1: batches keep WVS_DEEP_SETS more loads in flight across each unit's flush */
 	int wvs_strip;       /* 0: 16-column strips for launches that would otherwise need row bands, 64 elsewhere; 64 / 16: always */
 	int nt_loads;        /* 1: non-temporal pixel loads */
 };

@@ -822,6 +822,9 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
  * rows of 64 bytes at a time, and row r of the eight counts in replica r & 3 of the strip's table, which makes the
  * LDS side -- word value*32 + (lane & 31), 32 different banks per half wave -- the very same as for SW = 64; the
  * flush adds the four replicas up. */
+#ifndef WVS_DEEP_SETS
+#define WVS_DEEP_SETS 4 /* batches issued ahead of a flush on top of the two of the steady state (DEEP) */
+#endif
 #define WVS_NARROW 16
 #define WVS_NARROW_U 4 /* a unit is only ~140 KB per workgroup: deeper batches, fewer round trips */
 
@@ -908,7 +911,17 @@ struct ScopeWvsHis {
 	u32 chmask;   /* channels the caller wants counted (a subset of CH); the others stay zero */
 };
 
-template <int CH, bool FUSE, bool WIDE, bool HIS, int SW>
+/* DEEP (batches: every unit has the same, sufficiently many, slots): a unit's flush -- barrier, 96 KiB of LDS read, 64 KiB
+ * stored, zero-fill, barrier -- takes the workgroup 3-4 us, and the two batches of the steady state (32 KiB per CU, the
+ * depth HBM likes best) have arrived after one: the CU's share of the memory pipeline then idles for the rest (measured
+ * with the flush compiled out: 5.08 instead of 6.08 us per 4K frame, of which the table's bytes explain 0.6).  So
+ * WVS_DEEP_SETS more batches of the next unit are issued just before the flush, into register sets of their own, and
+ * binned first thing after it without re-issuing: the queue is deep across the flush and decays to two again.
+ * Same-process A/B, 64 x 4K RGB: 6078 -> 6210 GB/s on noise, 6171 -> 6215 on natural content; two extra sets do the
+ * same as four, six and eight lose (6033, 5894).  What is left of the flush (measured by compiling parts of it out):
+ * its LDS reads, packing and stores 2.3 %, its two barriers 2.2 %, the zero-fill 0.8 % -- the table's own bytes are
+ * a tenth of the traffic and stay. */
+template <int CH, bool FUSE, bool WIDE, bool HIS, int SW, bool DEEP>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, ScopeK0 k0,
 							       uint8_t *dst, ScopeWvsHis his)
 {
@@ -947,6 +960,9 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 
 	u32 va[U][2], vb[U][2];
 	bool oka[U], okb[U];
+	constexpr int NX = DEEP ? WVS_DEEP_SETS : 1;
+	u32 vx[NX][U][2];
+	bool okx[NX][U];
 
 	/* Unconditional loads keep the vmcnt bookkeeping exact (see scope_stream); a slot past the data reads
 	 * the 8 bytes at the band's first texel with every lane, i.e. one cache line. */
@@ -1011,17 +1027,28 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 
 		u32 sl = 0;
 		if (decltype(steady)::value) {
+			if (DEEP) { /* slots 2 .. 2 + NX - 1 of this unit, issued before the previous flush (rows commute) */
+#pragma unroll
+				for (int e = 0; e < NX; e++)
+					WVS_BIN(vx[e], okx[e]);
+				sl = NX;
+			}
 			WVS_BIN(va, oka);
 			WVS_ISSUE(va, oka);
 			WVS_BIN(vb, okb);
 			WVS_ISSUE(vb, okb);
-			sl = 2;
+			sl += 2;
 		}
 		for (; sl < ub.slots; sl += 2) {
 			WVS_BIN(va, oka);
 			WVS_ISSUE(va, oka);
 			WVS_BIN(vb, okb);
 			WVS_ISSUE(vb, okb);
+		}
+		if (DEEP) { /* va, vb hold slots 0, 1 of the next unit; these are its slots 2 .. */
+#pragma unroll
+			for (int e = 0; e < NX; e++)
+				WVS_ISSUE(vx[e], okx[e]);
 		}
 		/* the rows a band has beyond whole row groups (an odd last row; up to seven for narrow strips): wave 0 */
 		const u32 left = ub.nrows - ub.npairs * RW;
@@ -1565,23 +1592,26 @@ struct WvsArgs {
 	const ScopeTiming *tm;
 };
 
-template <int CH, bool FUSE, bool WIDE, bool HIS, int SW> hipError_t wvs_variant(const WvsArgs *a)
+template <int CH, bool FUSE, bool WIDE, bool HIS, int SW, bool DEEP> hipError_t wvs_variant(const WvsArgs *a)
 {
 	if (!a)
-		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE, WIDE, HIS, SW>,
+		return hipFuncSetAttribute((const void *)scope_wvs_kernel<CH, FUSE, WIDE, HIS, SW, DEEP>,
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WVS_LDS_BYTES);
-	SCOPE_LAUNCH((scope_wvs_kernel<CH, FUSE, WIDE, HIS, SW>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, a->tm, *a->fs,
-		     a->strips, a->bands, a->k0, a->dst, a->his);
+	SCOPE_LAUNCH((scope_wvs_kernel<CH, FUSE, WIDE, HIS, SW, DEEP>), dim3(a->grid), dim3(SCOPE_BLOCK), a->lds, a->st, a->tm,
+		     *a->fs, a->strips, a->bands, a->k0, a->dst, a->his);
 	return hipGetLastError();
 }
-/* wide: 0 scalar shape, 1 vector shape, 2 vector shape with narrow strips */
+/* wide: 0 scalar shape, 1 vector shape, 2 vector shape with narrow strips, 3 vector shape with the deep queue across flushes */
 template <int CH, bool HIS> hipError_t wvs_pick_shape(int fuse, int wide, const WvsArgs *a)
 {
+	if (wide == 3 && !fuse) /* the fused-K0 forms are short of VALU issue slots, not of loads: they lose 3 % with it */
+		return wvs_variant<CH, false, true, HIS, 64, true>(a);
 	if (wide == 2)
-		return fuse ? wvs_variant<CH, true, true, HIS, WVS_NARROW>(a) : wvs_variant<CH, false, true, HIS, WVS_NARROW>(a);
+		return fuse ? wvs_variant<CH, true, true, HIS, WVS_NARROW, false>(a)
+			    : wvs_variant<CH, false, true, HIS, WVS_NARROW, false>(a);
 	if (fuse)
-		return wide ? wvs_variant<CH, true, true, HIS, 64>(a) : wvs_variant<CH, true, false, HIS, 64>(a);
-	return wide ? wvs_variant<CH, false, true, HIS, 64>(a) : wvs_variant<CH, false, false, HIS, 64>(a);
+		return wide ? wvs_variant<CH, true, true, HIS, 64, false>(a) : wvs_variant<CH, true, false, HIS, 64, false>(a);
+	return wide ? wvs_variant<CH, false, true, HIS, 64, false>(a) : wvs_variant<CH, false, false, HIS, 64, false>(a);
 }
 template <bool HIS> hipError_t wvs_pick_ch(u32 chmask, int fuse, int wide, const WvsArgs *a)
 {
@@ -1623,9 +1653,9 @@ hipError_t scope_kernels_init(void)
 					e = his_pick(unroll, nt, fuse, NULL);
 			}
 	for (u32 chmask = 1; chmask <= 7; chmask++)
-		for (int shape = 0; shape < 12; shape++)
+		for (int shape = 0; shape < 16; shape++)
 			if (e == hipSuccess)
-				e = wvs_pick(chmask, shape & 1, (shape >> 1) % 3, shape / 6, NULL);
+				e = wvs_pick(chmask, shape & 1, (shape >> 1) & 3, shape >> 3, NULL);
 	return e;
 }
 
@@ -1748,6 +1778,13 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 		/* equal rounds for every workgroup, in whole blocks of 16 (the XCD pairing of wvs_unit) */
 		const u32 rounds = (total + resident - 1u) / resident;
 		grid = min(resident, (((total + rounds - 1u) / rounds) + 15u) & ~15u);
+	}
+	/* the deep queue across flushes: batches only -- every unit the same, with enough slots, several units per workgroup */
+	if (wide == 1 && !fuse_k0 && tn.wvs_deep && bands == 1 && total > grid) {
+		const u32 nbatch = ((fs.height >> 1) + WVS_U - 1) / WVS_U, nwaves = SCOPE_BLOCK / 64;
+		const u32 slots = max(2u, ((nbatch + nwaves - 1) / nwaves + 1u) & ~1u);
+		if (slots >= (u32)WVS_DEEP_SETS + 2u)
+			wide = 3;
 	}
 	ScopeWvsHis h = {NULL, NULL, NULL, 0};
 	if (his)

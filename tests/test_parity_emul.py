@@ -129,6 +129,16 @@ def test_waveform_histogram_one_pass_narrow_strips(emul_ctx, oracle, w, h, dist)
         pc.check_waveform_histogram(emul_ctx, oracle, w, h, dist)
 
 
+def test_waveform_deep_queue_across_flushes(emul_ctx, oracle):
+    """Batches whose workgroups walk several units keep extra loads in flight across each flush (register sets of
+    their own, binned first thing after the flush): more units than workgroups, at least six slots per wave."""
+    pc.check_waveform(emul_ctx, oracle, 512, 265, 5, 0x07)  # 8 units on 6 workgroups, an odd last row
+    pc.check_waveform(emul_ctx, oracle, 448, 300, 1, 0x20, 448 * 4 + 64)  # 7 units: one workgroup walks two
+    pc.check_waveform_histogram(emul_ctx, oracle, 512, 264, 2)
+    with pc.options(emul_ctx, **{"wvs.deep": 0}):
+        pc.check_waveform(emul_ctx, oracle, 512, 265, 5, 0x07)
+
+
 def test_waveform_fused_k0(emul_ctx, oracle):
     pc.check_waveform(emul_ctx, oracle, 70, 9, 1, 0x20, None, fuse=True, colorspace=1)
     pc.check_waveform(emul_ctx, oracle, 70, 9, 1, 0x50, None, fuse=True, colorspace=2)
