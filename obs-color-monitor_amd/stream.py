@@ -76,7 +76,9 @@ def stream_leg(torch, np, ctx, oracle, seconds=2.0, sources=16, depth=3, dist_ki
             out[name] = {
                 "fps": round(fps, 1), "frames": frames, "seconds": round(elapsed, 3),
                 "gpix_per_s": round(fps * W * H / 1e9, 2), "h2d_gbytes_per_s": round(fps * W * H * 4 / 1e9, 2),
-                "latency_ms_mean": round(1e3 * sum(lat) / len(lat), 3), "latency_ms_max": round(1e3 * max(lat), 3),
+                "latency_ms_mean": round(1e3 * sum(lat) / len(lat), 3),
+                "latency_ms_p99": round(1e3 * sorted(lat)[min(len(lat) - 1, (99 * len(lat)) // 100)], 3),
+                "latency_ms_max": round(1e3 * max(lat), 3),
             }
         out["paced_240fps"]["meets_240fps"] = out["paced_240fps"]["fps"] >= 239.5
         out["parity"] = (f"bit-exact vs oracle on {checked} sampled frames (parity unpinned)" if parity else "MISMATCH")
