@@ -21,6 +21,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def locked_make(directory, *targets):
+    """`make` under a file lock: pytest-xdist workers (and a concurrent build()) must not write one .so at once."""
+    import fcntl
+
+    with open(os.path.join(directory, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", directory, *targets])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
@@ -35,7 +44,7 @@ def oracle():
 @pytest.fixture(scope="session")
 def emul_lib():
     d = os.path.join(ROOT, "tests", "emul")
-    subprocess.check_call(["make", "-s", "-C", d, "libscope_emul.so"])
+    locked_make(d, "libscope_emul.so")
     return os.path.join(d, "libscope_emul.so")
 
 
@@ -54,8 +63,8 @@ def hip_ctx():
 
     assert torch.cuda.is_available(), "-m gpu tests need a GPU"
     # normally a no-op (build() ran and the .so travelled with the tree); hipcc exists on the GPU box too
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "obs-color-monitor_amd", "csrc")])
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "obs-color-monitor_amd", "host")])
+    locked_make(os.path.join(ROOT, "obs-color-monitor_amd", "csrc"))
+    locked_make(os.path.join(ROOT, "obs-color-monitor_amd", "host"))
     import obs_color_monitor_amd as ocm
 
     ctx = ocm.ScopeContext(0)  # raises if libscope_hip.so is missing: no fallback

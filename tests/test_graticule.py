@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def G():
     d = os.path.join(ROOT, "tests", "emul")
-    subprocess.check_call(["make", "-s", "-C", d, "libscope_host_emul.so"])
+    from conftest import locked_make
+
+    locked_make(d, "libscope_host_emul.so")
     L = C.CDLL(os.path.join(d, "libscope_host_emul.so"))
     f32p = C.POINTER(C.c_float)
     L.scope_graticule_vectorscope.restype = C.c_uint32

@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_host_mirror_on_emulated_kernels(emul_lib, oracle):
     d = os.path.join(ROOT, "tests", "emul")
-    subprocess.check_call(["make", "-s", "-C", d, "libscope_host_emul.so"])
+    from conftest import locked_make
+
+    locked_make(d, "libscope_host_emul.so")
     host = hc.Host(os.path.join(d, "libscope_host_emul.so"))
     try:
         hc.run_host_checks(host, oracle)
