@@ -125,6 +125,17 @@ class Workload:
         return ok
 
 
+def agree(torch, dist, keep_going):
+    """Loops that run 'for so many seconds' must run the SAME number of steps on every rank -- a step holds a collective, and
+    a rank that enqueues one more than its peers waits for ever.  So the clock of no single rank decides: the loop goes on
+    while ANY rank wants to (one tiny all-reduce per chunk of steps, which also drains the stream)."""
+    if dist is None:
+        return keep_going
+    t = torch.tensor([1 if keep_going else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item())
+
+
 def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=None):
     """settle -> warm-up -> EXACTLY `steps` steps between (barrier +) synchronize -> at least min_s more of the same ->
     a short leg with the accumulation kernel bracketed by HIP events (the bracket costs a few microseconds of stream time
@@ -132,7 +143,7 @@ def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=Non
     Returns (elapsed of the K steps, sustained dict, bracketed kernel launches, their summed ms)."""
     t_end = time.perf_counter() + settle_s
     i = 0
-    while time.perf_counter() < t_end:
+    while agree(torch, dist, time.perf_counter() < t_end):
         for _ in range(8):
             step(i)
             i += 1
@@ -158,7 +169,7 @@ def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=Non
         for j in range(chunk):
             step(s_steps + j)
         s_steps += chunk
-        if time.perf_counter() - t1 >= min_s:
+        if not agree(torch, dist, time.perf_counter() - t1 < min_s):
             break
     host_s = time.perf_counter() - t1
     e1.record(stream)
@@ -569,19 +580,21 @@ def config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream, frames=16, s
         step()
     torch.cuda.synchronize()
     dist.barrier()
+    # every rank runs the SAME number of steps (a step holds a collective): fixed chunks, and the ranks agree after each
+    # whether to go on; the agreement drains the stream, so the chunk is long (tens of milliseconds) against that pause
     t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(10):
+    steps, chunk = 0, 40
+    while True:
+        for _ in range(chunk):
             step()
-        steps += 10
+        steps += chunk
+        if not agree(torch, dist, time.perf_counter() - t0 < seconds):
+            break
     torch.cuda.synchronize()
     dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    st = torch.tensor([steps], dtype=torch.int64, device="cuda")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    dist.all_reduce(st, op=dist.ReduceOp.MIN)
-    ms = float(el.item()) / int(st.item()) * 1e3
+    ms = float(el.item()) / steps * 1e3
     lat = []
     for _ in range(30):
         dist.barrier()
