@@ -826,7 +826,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
 #define WVS_DEEP_SETS 4 /* batches issued ahead of a flush on top of the two of the steady state (DEEP) */
 #endif
 #define WVS_NARROW 16
-#define WVS_NARROW_U 4 /* a unit is only ~140 KB per workgroup: deeper batches, fewer round trips */
+#ifndef WVS_NARROW_U
+#define WVS_NARROW_U 1 /* row groups per wave per batch.  A unit is 270 groups on 16 waves = 17 each, and a wave's batches are
+			* rounded up to an even number: 18 at 1, 20 at 2, 24 at 4 -- 14.1 / 14.4 / 15.1 us per 4K frame (6: 15.4, 9: 16.3) */
+#endif
 
 /* Counter of (value, column c of the strip): 16-bit half (c & 1) of word value*32 + (c >> 1).
  *
