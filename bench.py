@@ -186,6 +186,35 @@ def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=Non
     return elapsed, sustained, launches, kernel_ms
 
 
+def place_pool(torch, ctx, frames, probe, candidates):
+    """WHERE a frame pool lies in HBM decides a few per cent of every streaming kernel's rate, and the first pools a
+    process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt: 6300-6490 GB/s for the first
+    against 6800-6860 for the ten that follow, same frames, same kernel, same process).  A host that
+    keeps a long-lived pool can afford to look: allocate `candidates` copies, time the accumulation kernel on each
+    (its own begin/end stamps), keep the fastest and give the rest back.  Untimed set-up, rank-local, no collective.
+    Returns (the pool to use, kernel microseconds per candidate, index kept)."""
+    pools, us = [frames], []
+    for k in range(candidates):
+        if k:
+            pools.append(frames.clone())
+        fn = probe(pools[k])
+        for _ in range(12):
+            fn()
+        ctx.sync()
+        ctx.profile(True)
+        for _ in range(24):
+            fn()
+        ctx.sync()
+        nl, ms = ctx.kernel_ms()
+        ctx.profile(False)
+        us.append(round(ms / max(nl, 1) * 1e3, 2))
+    best = min(range(candidates), key=lambda k: us[k])
+    keep = pools[best]
+    del pools
+    torch.cuda.empty_cache()
+    return keep, us, best
+
+
 def roofline(wl, algo_bytes, launches, kernel_ms, ms_per_step, traffic):
     kern_avg_ms = kernel_ms / launches if launches else float("nan")
     achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches else float("nan")
@@ -250,6 +279,8 @@ def main():
     ap.add_argument("--workload", default="vectorscope",
                     choices=["vectorscope", "vectorscope_rgb", "waveform", "histogram", "three_scope", "stream"])
     ap.add_argument("--components", type=lambda s: int(s, 0), default=0x07)
+    ap.add_argument("--placement-candidates", type=int, default=6,
+                    help="frame pools allocated and probed before the fastest is kept (1 = take the first, as round 1 did)")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "ramp", "natural", "screen"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
@@ -330,6 +361,27 @@ def main():
     wl = args.workload
     rgb, yuv = make_frames(torch, ctx, pool, w, h, args.dist, 0x9E3779B9 + rank)
     torch.cuda.synchronize()
+    placement = None
+    if args.placement_candidates > 1:
+        pn = min(pool, 64)  # the probe reads the whole pool (one launch takes at most 64 frames)
+        ptab = torch.empty((pn, 65536), dtype=torch.uint8, device="cuda")
+
+        def probe_yuv(t):
+            b = ctx.make_device_batch(t[:pn], 4 * w, w, h, planes_are_rgb=False)
+            return lambda: ctx.vectorscope_batch_dev(b, ptab, sync=False)
+
+        def probe_rgb(t):
+            b = ctx.make_device_batch(t[:pn], 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+            return lambda: ctx.histogram_counts_batch_dev(b, 0x07, ptab.view(-1)[:pn * 4096], sync=False)
+
+        yuv, us_y, ky = place_pool(torch, ctx, yuv, probe_yuv, args.placement_candidates)
+        rgb, us_r, kr = place_pool(torch, ctx, rgb, probe_rgb, args.placement_candidates)
+        placement = {"candidates": args.placement_candidates,
+                     "yuv_pool_vectorscope_kernel_us": us_y, "yuv_pool_kept": ky,
+                     "rgb_pool_histogram_kernel_us": us_r, "rgb_pool_kept": kr,
+                     "what": "copies of the frame pool allocated one after the other, the accumulation kernel timed on each "
+                             "(own begin/end stamps), the fastest kept, the others freed: untimed set-up (DESIGN.md section 5)"}
+        del ptab
     work = Workload(torch, ctx, wl, rgb, yuv, w, h, n, args.components)
     table_bytes = work.tbytes
 
@@ -467,6 +519,7 @@ def main():
             "height": h,
             "input_distribution": args.dist,
             "partition": "one frame batch per GPU" if world == 1 else f"{world} row tiles of {w}x{h} + RCCL sum of tables",
+            "frame_pool_placement": placement,
             "reduce": reduce_path,
             "device": info["name"],
             "compute_units": info["compute_units"],
