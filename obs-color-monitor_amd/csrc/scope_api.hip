@@ -334,6 +334,13 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 			return st;
 		uint8_t *dst = dev_out + (size_t)f0 * table;
 		uint32_t slices = pick_slices(ctx, nf, 1);
+		/* ONE frame over staged planes: five eighths of the CUs (160 slices on 256) beat all of them -- 16.2 against
+		 * 17.1 us per 4K call on noise, 15.0 against 15.8 on natural content, 152 and 168 in between
+		 * (profiles/round2/latency_vss_slices_g11.jsonl): the pixel loop is latency-bound either way, and fewer slices
+		 * are fewer partial tables to write out and to add up.  With K0 fused the loop is VALU-bound and wants every CU
+		 * (256: 18.2 us, 160: 20.2); two and more frames are flat around the full chip. */
+		if (ctx->slices_override <= 0 && nf == 1 && !fuse && slices > 16)
+			slices = (slices * 5u / 8u + 15u) & ~15u;
 		const uint32_t min_slices = min_slices_for_span(fs.linesize, height);
 		if (min_slices == 0)
 			return fail(ctx, SCOPE_EINVAL, "pitch * height too large", hipSuccess);
