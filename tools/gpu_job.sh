@@ -30,17 +30,18 @@ for s in $stages; do
     pmc)   # PMC passes on their own (no --stats / sys-trace), per the MI355X guide
            for d in ${PMC_DISTS:-uniform natural}; do
              (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY \
-                --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq_$d -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --settle-seconds 0.2 --no-cpu --dist $d $BENCH_EXTRA) > $out/pmc_sq_$d.log 2>&1
+                --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq_$d -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --settle-seconds 0.2 --no-cpu --placement-candidates 1 --dist $d $BENCH_EXTRA) > $out/pmc_sq_$d.log 2>&1
              (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE \
-                --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq2_$d -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --settle-seconds 0.2 --no-cpu --dist $d $BENCH_EXTRA) > $out/pmc_sq2_$d.log 2>&1
+                --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq2_$d -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --settle-seconds 0.2 --no-cpu --placement-candidates 1 --dist $d $BENCH_EXTRA) > $out/pmc_sq2_$d.log 2>&1
            done; rc=$?
            python tools/pmc_summary.py $out/pmc_sq_* $out/pmc_sq2_* > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt ;;
-    traffic) # HBM bytes per step: FETCH_SIZE and WRITE_SIZE in separate PMC passes (TCC slots), kernel trace only
+    traffic) # HBM bytes per step: FETCH_SIZE and WRITE_SIZE in separate PMC passes (TCC slots), kernel trace only; the frame pool is
+           # taken as it comes (--placement-candidates 1): the placement probe's launches would be averaged into the step
            for spec in ${PMC_WORKLOADS:-vectorscope:64 vectorscope_rgb:64 waveform:64 histogram:64 three_scope:64 vectorscope:1 vectorscope:3 vectorscope_rgb:1 histogram:1 waveform:1 three_scope:1}; do
              wl=${spec%%:*}; fr=${spec##*:}
              for c in FETCH_SIZE WRITE_SIZE; do
                (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_${wl}_x${fr}_$c -o p -- \
-                  python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --settle-seconds 0.1 --min-seconds 0.05 --no-cpu --no-extras --workload $wl --frames $fr $BENCH_EXTRA) > $out/pmc_${wl}_x${fr}_$c.log 2>&1
+                  python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --settle-seconds 0.1 --min-seconds 0.05 --no-cpu --no-extras --placement-candidates 1 --workload $wl --frames $fr $BENCH_EXTRA) > $out/pmc_${wl}_x${fr}_$c.log 2>&1
              done
            done; rc=$?
            python tools/pmc_traffic_json.py $out $tag > $out/pmc_traffic.json 2> $out/pmc_traffic.err; cat $out/pmc_traffic.err
