@@ -474,6 +474,10 @@ int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint
 			return st;
 		uint32_t *dst = (uint32_t *)(dev_out + (size_t)f0 * table);
 		uint32_t slices = pick_slices(ctx, nf, 1);
+		/* ONE frame: three quarters of the CUs with two loads per lane per batch (scope_launch_his) -- 13.8 against
+		 * 14.6 us per 4K call (profiles/round2/latency_histogram_g14.jsonl); three and more frames want the full chip */
+		if (ctx->slices_override <= 0 && nf == 1 && !fuse && slices > 16)
+			slices = (slices * 3u / 4u + 15u) & ~15u;
 		const uint32_t min_slices = min_slices_for_span(fs.linesize, height);
 		if (min_slices == 0)
 			return fail(ctx, SCOPE_EINVAL, "pitch * height too large", hipSuccess);
@@ -648,7 +652,7 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.vss_fused_unroll = 2;
 	ctx->tn.vss_hash = 0;
 	ctx->tn.vss_groups_log2 = -1; /* auto: 8 lane-group streams for batches, one stream for launches of a few frames */
-	ctx->tn.his_unroll = 1;
+	ctx->tn.his_unroll = 0; /* auto: 1 load per lane per batch, 2 for one-frame launches */
 	ctx->tn.wvs_wide = 1;
 	ctx->tn.wvs_strip = 0;
 	ctx->tn.wvs_deep = 1;

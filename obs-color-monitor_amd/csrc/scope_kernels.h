@@ -53,7 +53,7 @@ struct ScopeTuning {
 	int vss_fused_unroll; /* the same for the fused-K0 form (VALU-bound: a shallower pipeline is enough) */
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3; -1 = by launch size */
-	int his_unroll;      /* 1, 2 or 4; more bytes in flight than ~32 KiB per CU LOWER the achieved bandwidth */
+	int his_unroll;      /* 1, 2 or 4; 0 = by launch size.  More bytes in flight than ~32 KiB per CU LOWER the achieved bandwidth of a batch */
 	int vss_block, his_block; /* threads per workgroup (0 = SCOPE_BLOCK) */
 	int fold;            /* 1: the slices of a histogram frame are combined inside the launch (atomics + last arrival); 0: partial
 			      * tables + scope_launch_sum_reduce */

@@ -1750,7 +1750,10 @@ hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t c
 	if (!tickets || slices < 2)
 		acc = NULL;
 	const HisArgs a = {&fs, slices, chmask, scope_block(tn.his_block), split_regions(fs), scope_k0_matrix(colorspace), dst, acc, tickets, st, tm};
-	return his_pick(tn.his_unroll, tn.nt_loads, fuse_k0, &a);
+	/* one 16-byte load per lane per batch keeps ~32 KiB per CU in flight, what HBM likes best in a batch; a one-frame
+	 * launch (>= 100 slices per frame: a workgroup has ~170 KB to read in all) is about round trips: two */
+	const int unroll = tn.his_unroll > 0 ? tn.his_unroll : ((slices >= 100 && !fuse_k0) ? 2 : 1);
+	return his_pick(unroll, tn.nt_loads, fuse_k0, &a);
 }
 
 bool scope_wvs_vector_shape(const ScopeFrameSet &fs, const uint8_t *dst, const ScopeTuning &tn)
