@@ -55,8 +55,8 @@ WORKLOAD_TEXT = {
     "vectorscope_rgb": "vectorscope with fused K0 over RGB planes",
     "waveform": "waveform per-column 256-bin (K2)",
     "histogram": "histogram 3x256 u32 (K3)",
-    "three_scope": "vectorscope (fused K0) + waveform + histogram of every frame: two kernels, the histogram rides on the "
-                   "waveform's pass",
+    "three_scope": "vectorscope (fused K0) + waveform + histogram of every frame (scope_three_scopes_batch): batches in two "
+                   "passes with the histogram riding on the waveform's; one-frame launches read the plane once",
 }
 KERNEL = {"vectorscope": "scope_vss_kernel", "vectorscope_rgb": "scope_vss_kernel", "waveform": "scope_wvs_kernel",
           "histogram": "scope_his_kernel", "three_scope": "scope_vss_kernel + scope_wvs_kernel"}
@@ -102,8 +102,8 @@ class Workload:
         elif wl == "histogram":
             ctx.histogram_counts_batch_dev(b, self.comp, self.tables[buf], sync=False)
         else:
-            ctx.vectorscope_batch_dev(b, self.vss[buf], sync=False)
-            ctx.waveform_histogram_batch_dev(b, self.comp, self.comp, self.wvs[buf], self.his[buf], sync=False)
+            # one C-ABI call: small launches read the planes once (scope_dock_kernel), batches take two passes
+            ctx.three_scopes_batch_dev(b, self.comp, self.comp, self.vss[buf], self.wvs[buf], self.his[buf], sync=False)
         self.last = (i % self.groups, buf)
 
     def check(self, o, rgb, yuv, np, frames=None):

@@ -656,6 +656,7 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.wvs_wide = 1;
 	ctx->tn.wvs_strip = 0;
 	ctx->tn.wvs_deep = 1;
+	ctx->tn.dock = 1;
 	ctx->tn.wvs_persist = 1;
 	ctx->tn.wvs_per_cu = 1;
 	ctx->tn.fold = 1;
@@ -775,6 +776,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.wvs_strip = value;
 	else if (!strcmp(key, "wvs.deep"))
 		ctx->tn.wvs_deep = value != 0;
+	else if (!strcmp(key, "dock"))
+		ctx->tn.dock = value != 0;
 	else if (!strcmp(key, "slices"))
 		ctx->slices_override = value;
 	else
@@ -1113,6 +1116,57 @@ int scope_waveform_histogram_batch(scope_ctx *ctx, const struct scope_batch *b, 
 	if (st)
 		return st;
 	return scope_histogram_counts_batch(ctx, b, his_components, flags, his_counts);
+}
+
+int scope_three_scopes_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t wvs_components, uint32_t his_components,
+			     uint32_t flags, uint8_t *vss_out, uint8_t *wvs_out, uint32_t *his_counts)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if (!b || !vss_out || !wvs_out || !his_counts || !b->planes || b->n_frames == 0)
+		return fail(ctx, SCOPE_EINVAL, "NULL or empty batch", hipSuccess);
+	if (!b->planes_are_rgb)
+		return fail(ctx, SCOPE_EINVAL, "scope_three_scopes_batch takes RGB planes (the vectorscope goes through the fused K0)", hipSuccess);
+	if (flags & SCOPE_OUT_PACKED16)
+		return fail(ctx, SCOPE_EINVAL, "SCOPE_OUT_PACKED16 is a vectorscope-only flag", hipSuccess);
+	for (uint32_t i = 0; i < b->n_frames; i++)
+		if (!b->planes[i])
+			return SCOPE_ENODATA;
+	const uint32_t cw = channel_mask(wvs_components), ch = channel_mask(his_components);
+	const bool rgb_kind = (wvs_components & 0x07u) != 0 && (his_components & 0x07u) != 0;
+	const uint32_t dev = SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE;
+	/* One read for all three: device-resident planes and tables, RGB channels for waveform and histogram (the histogram a
+	 * subset of the waveform's), and a launch small enough for one round of 16-column strips -- the dock's one frame. */
+	if (rgb_kind && (ch & ~cw) == 0 && (flags & dev) == dev && b->width && b->height && b->n_frames <= SCOPE_MAX_FRAMES &&
+	    ctx->tn.dock) {
+		int stc = check_geometry(ctx, b->linesize, b->width, b->height);
+		if (stc)
+			return stc;
+		ScopeFrameSet fs;
+		stc = stage_planes(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, flags, &fs);
+		if (stc)
+			return stc;
+		if (scope_dock_fits(fs, wvs_out, (uint32_t)ctx->num_cu, ctx->tn)) {
+			const uint32_t nf = b->n_frames, strips = scope_wvs_strips(b->width, 1), mask_block = SCOPE_BLOCK;
+			stc = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * strips * SCOPE_VSS_BINS);
+			if (!stc)
+				stc = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)nf * strips * mask_block);
+			if (stc)
+				return stc;
+			const ScopeHisSink sink = {ctx->his_acc, ctx->tickets, his_counts, ch};
+			TIMED_LAUNCH(ctx, scope_launch_dock(fs, cw, b->colorspace, wvs_out, &sink, ctx->partial, ctx->pmask, ctx->stream, tm_));
+			HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, vss_out, nf, strips, mask_block, 0, ctx->stream));
+			if (!(flags & SCOPE_ASYNC))
+				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			return SCOPE_OK;
+		}
+	}
+	/* everything else: the vectorscope's pass, then the waveform's with the histogram riding on it */
+	st = scope_vectorscope_batch(ctx, b, flags, vss_out);
+	if (st)
+		return st;
+	return scope_waveform_histogram_batch(ctx, b, wvs_components, his_components, flags, wvs_out, his_counts);
 }
 
 void scope_histogram_level(uint8_t *tex_buf, uint32_t *hi_max, uint32_t width, uint32_t height, uint32_t components,

@@ -63,6 +63,7 @@ struct ScopeTuning {
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
 	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */
 	int wvs_deep;        /* 1: batches keep WVS_DEEP_SETS more loads in flight across each unit's flush */
+	int dock;            /* 1: scope_three_scopes_batch reads small launches once (scope_dock_kernel); 0: always two passes */
 	int wvs_strip;       /* 0: 16-column strips for launches that would otherwise need row bands, 64 elsewhere; 64 / 16: always */
 	int nt_loads;        /* 1: non-temporal pixel loads */
 };
@@ -123,6 +124,16 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
  * then need no row bands and no partial tables (vector shape only: scope_wvs_vector_shape must hold for fs and dst). */
 bool scope_wvs_vector_shape(const ScopeFrameSet &fs, const uint8_t *dst, const ScopeTuning &tn);
 uint32_t scope_wvs_strips(uint32_t width, int narrow);
+
+/* The dock's three scopes of every frame from ONE read of its RGB plane (src/roi.c:329-341): the strip's texels stay in
+ * registers and are walked twice -- waveform (+ the histogram riding on its flush, his != NULL) into wvs_dst =
+ * uint8[n_frames][256][width][4], then the vectorscope through the fused K0 into sparse partial tables, one per 16-column
+ * strip: vss_part / vss_mask as scope_launch_vss writes them with slices = scope_wvs_strips(width, 1) and 1024 mask bytes
+ * per slice, for scope_launch_sat_reduce_sparse.  Only where scope_dock_fits says so (vector shape, one round of strips on
+ * the chip, at most 2176 rows); chmask selects the waveform's RGB channels. */
+bool scope_dock_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, uint32_t num_cu, const ScopeTuning &tn);
+hipError_t scope_launch_dock(const ScopeFrameSet &fs, uint32_t chmask, int colorspace, uint8_t *wvs_dst, const ScopeHisSink *his,
+			     uint8_t *vss_part, uint8_t *vss_mask, hipStream_t st, const ScopeTiming *tm = NULL);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
  * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */

@@ -1237,6 +1237,212 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 #undef WVS_LANE_OFFSETS
 }
 
+/* ------------------------------------------------------------------------------------------
+ * The dock's three scopes of ONE frame from ONE read (src/roi.c:329-341 hands one staged surface to every registered
+ * scope; the reference walks it three times).
+ *
+ * All three tables do not fit one LDS (vectorscope 128 KiB + waveform 96 KiB > 160 KiB), and re-reading the frame
+ * costs a second pass over HBM.  But the pixels of a narrow strip fit the REGISTER FILE: a 4K frame in 16-column strips
+ * is 240 units of 16 x 2160 texels = 138 KB, i.e. 17 eight-byte loads per lane of a 1024-thread workgroup = 34 VGPRs.
+ * So a workgroup loads its strip once, with everything in flight at once, and then walks the registers twice:
+ *   1. waveform counters (four replicas, as scope_wvs_kernel<..., 16>) -> flush, the histogram's totals riding on it;
+ *   2. the same LDS, zeroed again, as the vectorscope's 16-bit table: K0 in fixed point on the texel pairs, absorb
+ *      mode by wave vote -> a sparse partial table, which scope_sat_reduce_sparse_kernel adds up over the strips.
+ * Lane -> texels: pair = lane & 7 (columns 2 pair, 2 pair + 1 of the strip), rslot = lane >> 3 picks one of EIGHT
+ * row ranges that lie H/8 rows apart -- a wave instruction touches eight distant image regions, which keeps
+ * neighbouring pixels' equal chroma from meeting in one LDS instruction (scope_stream's lane groups do the same) -- and
+ * replica rslot & 3 of the waveform table.  One strip holds at most 16 * 4080 = 65 280 texels: the vectorscope's 16-bit
+ * counters need no clamp pass.  Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables).
+ * ---------------------------------------------------------------------------------------- */
+#define DOCK_G 17 /* loads per lane: 16 waves x 17 x 8 row ranges cover 2176 rows */
+
+template <int CH, bool HIS>
+__global__ __launch_bounds__(SCOPE_BLOCK) void scope_dock_kernel(ScopeFrameSet fs, u32 strips, ScopeK0 k0, uint8_t *wvs_dst,
+								ScopeWvsHis his, uint8_t *vss_part, uint8_t *vss_mask)
+{
+	constexpr u32 slot0 = 0, slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1), nch = slot2 + ((CH >> 2) & 1);
+	u32 *tab = scope_lds;
+	scope_lds_is_at_zero(tab);
+	const u32 W = fs.width, H = fs.height;
+	const u32 lane = threadIdx.x & 63u;
+	const u32 pair = lane & 7u, rslot = lane >> 3;
+	const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const u32 nwaves = blockDim.x >> 6;
+	const u32 wbyte = (lane & 31u) << 2; /* replica (rslot & 3) x column pair, as scope_wvs_kernel<..., 16> */
+
+	u32 unit = blockIdx.x;
+	const u32 total = fs.n_frames * strips;
+	if (unit < (total & ~15u)) /* workgroups b and b + 8 share an XCD: neighbouring strips, the two halves of a cache line */
+		unit = (unit & ~15u) + ((unit & 7u) << 1) + ((unit >> 3) & 1u);
+	const u32 frame = unit / strips, strip = unit - frame * strips;
+	const u32 xs = strip * 16u, x0 = xs + 2u * pair;
+	const bool live = x0 < W; /* W % 4 == 0: both texels of the pair or none */
+	const uint8_t *plane = fs.plane[frame];
+
+	/* rows of this lane: rslot * rps + i, i = wave, wave + nwaves, ... < rps */
+	const u32 rps = (H + 7u) >> 3;
+	const u32 row0 = rslot * rps;
+	u32 px[DOCK_G][2];
+#pragma unroll
+	for (int g = 0; g < DOCK_G; g++) {
+		const u32 i = wave + (u32)g * nwaves;
+		const u32 row = row0 + i;
+		const bool ok = live && i < rps && row < H;
+		const scope_u2 t = scope_load_row2_nt(plane, ok ? row * fs.linesize + x0 * 4u : 0u);
+		px[g][0] = t.x;
+		px[g][1] = t.y;
+	}
+	auto valid = [&](int g) {
+		const u32 i = wave + (u32)g * nwaves;
+		return live && i < rps && row0 + i < H;
+	};
+
+	/* ---- 1. waveform (+ histogram) ---------------------------------------------------------------------------------- */
+	const uint4 zero = make_uint4(0, 0, 0, 0);
+	/* the histogram's per-strip totals live BEHIND the vectorscope table, so that they survive into the second phase: their
+	 * way to the frame's accumulator (device atomics, then the arrival ticket) is started after the waveform's flush and
+	 * only waited for at the very end of the kernel, with the vectorscope phase in between */
+	u32 *hsum = tab + VSS_WORDS;
+	for (u32 i = threadIdx.x * 4; i < nch * WVS_CH_WORDS; i += blockDim.x * 4)
+		*(uint4 *)&tab[i] = zero;
+	if (HIS && threadIdx.x < 192u)
+		*(uint4 *)&hsum[threadIdx.x * 4] = zero;
+	__syncthreads();
+#pragma unroll
+	for (int g = 0; g < DOCK_G; g++) {
+		if (!valid(g))
+			continue;
+		const u32 p0 = px[g][0], p1 = px[g][1];
+		if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
+			wvs_count<CH>(tab, p0, wbyte, 1u);
+		if ((p1 >> 24) != 0)
+			wvs_count<CH>(tab, p1, wbyte, 65536u);
+	}
+	__syncthreads();
+	{
+		/* the narrow-strip flush of scope_wvs_kernel: one (value, column group) per thread, replicas read in rotated order */
+		uint8_t *table = wvs_dst + (size_t)frame * ((size_t)SCOPE_WVS_ROWS * W * 4);
+		const u32 groups = (min(W - xs, 16u)) >> 2;
+		const u32 g4 = threadIdx.x & 3u, rho = (threadIdx.x >> 2) & 3u;
+		const u32 value = ((threadIdx.x >> 4) << 2) + rho;
+		const u32 g = min(g4, groups - 1u);
+		uint2 acc[3] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+#pragma unroll
+		for (u32 j = 0; j < 4; j++) {
+			const u32 w = (value << 5) + (((rho + j) & 3u) << 3) + 2u * g;
+			if (CH & 1) {
+				const uint2 c = *(const uint2 *)&tab[slot0 * WVS_CH_WORDS + w];
+				acc[0].x += c.x;
+				acc[0].y += c.y;
+			}
+			if (CH & 2) {
+				const uint2 c = *(const uint2 *)&tab[slot1 * WVS_CH_WORDS + w];
+				acc[1].x += c.x;
+				acc[1].y += c.y;
+			}
+			if (CH & 4) {
+				const uint2 c = *(const uint2 *)&tab[slot2 * WVS_CH_WORDS + w];
+				acc[2].x += c.x;
+				acc[2].y += c.y;
+			}
+		}
+		u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (u32 c = 0; c < 3; c++) {
+			if (!((CH >> c) & 1))
+				continue;
+			o[0] |= min(acc[c].x & 0xffffu, 255u) << (8u * c);
+			o[1] |= min(acc[c].x >> 16, 255u) << (8u * c);
+			o[2] |= min(acc[c].y & 0xffffu, 255u) << (8u * c);
+			o[3] |= min(acc[c].y >> 16, 255u) << (8u * c);
+			if (HIS && g4 < groups)
+				atomicAdd(&hsum[c * 256u + value],
+					  (acc[c].x & 0xffffu) + (acc[c].x >> 16) + (acc[c].y & 0xffffu) + (acc[c].y >> 16));
+		}
+		const scope_v4 t = {o[0], o[1], o[2], o[3]};
+		__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
+		__syncthreads();
+		if (HIS) { /* fire and forget; scope_last_arrival at the end of the kernel waits for them */
+			u32 *acc_g = his.acc + (size_t)frame * SCOPE_HIS_WORDS;
+			for (u32 t2 = threadIdx.x; t2 < 768u; t2 += blockDim.x) {
+				const u32 byte = t2 >> 8;
+				const u32 v = hsum[t2];
+				if (v && ((CH & his.chmask) >> byte) & 1u)
+					__hip_atomic_fetch_add(&acc_g[(2u - byte) * 256u + (t2 & 255u)], v, __ATOMIC_RELAXED,
+							       __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+
+	/* ---- 2. vectorscope: the same registers through K0 ------------------------------------------------------------- */
+	for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4)
+		*(uint4 *)&tab[i] = zero;
+	__syncthreads();
+	VssLane st = {0xffffffffu, 0};
+	bool absorb = false; /* wave-uniform */
+#pragma unroll
+	for (int g = 0; g < DOCK_G; g++) {
+		u32 key[2] = {px[g][0], px[g][1]};
+		scope_k0_cell<2, true>(key, k0, true, false); /* wave votes inside: every lane goes through, valid or not */
+		const bool ok = valid(g);
+		if ((g & 3) == 0) /* content is coherent: the verdict holds for four loads */
+			absorb = __popcll(__ballot(!ok || key[0] == key[1])) >= 48;
+		if (!ok)
+			continue;
+		if (absorb) {
+			bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
+			if (!(e0 | e1)) {
+				if (st.count)
+					vss_add<0>(tab, st.colour, st.count);
+				st.colour = key[0];
+				st.count = 0;
+				e0 = true;
+				e1 = key[1] == key[0];
+			}
+			st.count += (u32)e0 + (u32)e1;
+			if (!e0)
+				vss_add<0>(tab, key[0], 1);
+			if (!e1)
+				vss_add<0>(tab, key[1], 1);
+		} else {
+			vss_add<0>(tab, key[0], 1);
+			vss_add<0>(tab, key[1], 1);
+		}
+	}
+	vss_flush_lane<0>(tab, st);
+	__syncthreads();
+	{
+		/* the sparse partial of scope_vss_kernel, slice = strip */
+		uint4 *outs = (uint4 *)vss_part + ((size_t)frame * 256u * strips + strip) * 16u;
+		u32 wrote = 0, k = 0;
+		for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
+			const u32 row = 255u - (g >> 4);
+			const u32 w0 = (row << 7) + (((g & 15u) << 3) ^ ((row & 15u) << 3));
+			const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
+			if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0) {
+				const scope_v4 t = {vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
+						    vss_clamp_pair(hi.z, hi.w)};
+				__builtin_nontemporal_store(t, (scope_v4 *)outs + ((size_t)(g >> 4) * strips * 16u + (g & 15u)));
+				wrote |= 1u << k;
+			}
+		}
+		vss_mask[(((size_t)frame * (blockDim.x >> 4) + (threadIdx.x >> 4)) * strips + strip) * 16u + (threadIdx.x & 15u)] =
+			(uint8_t)wrote;
+	}
+	if (HIS) {
+		u32 *acc_g = his.acc + (size_t)frame * SCOPE_HIS_WORDS;
+		if (scope_last_arrival(&his.tickets[frame], strips, &hsum[0])) {
+			for (u32 t2 = threadIdx.x; t2 < SCOPE_HIS_WORDS; t2 += blockDim.x) {
+				const u32 val = t2 >> 2, slot = t2 & 3u;
+				his.out[(size_t)frame * SCOPE_HIS_WORDS + t2] =
+					__hip_atomic_exchange(&acc_g[slot * 256u + val], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (threadIdx.x == 0)
+				__hip_atomic_store(&his.tickets[frame], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
 /* Capture-side pre-steps: point-sampled 1/scale down-scale and ROI crop in one pass (cm_render_target,
  * src/common.c:249-250,272-282).  `src` points at the first sampled texel, `row_pitch` is the distance in
  * bytes between sampled rows and `col_step` the distance in texels between sampled columns.  A lane
@@ -1654,6 +1860,45 @@ hipError_t wvs_pick(u32 chmask, int fuse, int wide, int with_his, const WvsArgs 
 	return with_his ? wvs_pick_ch<true>(chmask, fuse, wide, a) : wvs_pick_ch<false>(chmask, fuse, wide, a);
 }
 
+struct DockArgs {
+	const ScopeFrameSet *fs;
+	u32 strips;
+	ScopeK0 k0;
+	uint8_t *wvs_dst;
+	ScopeWvsHis his;
+	uint8_t *vss_part, *vss_mask;
+	hipStream_t st;
+	const ScopeTiming *tm;
+};
+template <int CH, bool HIS> hipError_t dock_variant(const DockArgs *a)
+{
+	if (!a)
+		return hipFuncSetAttribute((const void *)scope_dock_kernel<CH, HIS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+					   (int)(VSS_LDS_BYTES + WVS_HIS_LDS_BYTES));
+	SCOPE_LAUNCH((scope_dock_kernel<CH, HIS>), dim3(a->fs->n_frames * a->strips), dim3(SCOPE_BLOCK), VSS_LDS_BYTES + WVS_HIS_LDS_BYTES, a->st,
+		     a->tm, *a->fs, a->strips, a->k0, a->wvs_dst, a->his, a->vss_part, a->vss_mask);
+	return hipGetLastError();
+}
+template <bool HIS> hipError_t dock_pick_ch(u32 chmask, const DockArgs *a)
+{
+	switch (chmask & 7u) {
+	case 1:
+		return dock_variant<1, HIS>(a);
+	case 2:
+		return dock_variant<2, HIS>(a);
+	case 3:
+		return dock_variant<3, HIS>(a);
+	case 4:
+		return dock_variant<4, HIS>(a);
+	case 5:
+		return dock_variant<5, HIS>(a);
+	case 6:
+		return dock_variant<6, HIS>(a);
+	default:
+		return dock_variant<7, HIS>(a);
+	}
+}
+
 } // namespace
 
 hipError_t scope_kernels_init(void)
@@ -1673,6 +1918,12 @@ hipError_t scope_kernels_init(void)
 		for (int shape = 0; shape < 16; shape++)
 			if (e == hipSuccess)
 				e = wvs_pick(chmask, shape & 1, (shape >> 1) & 3, shape >> 3, NULL);
+	for (u32 chmask = 1; chmask <= 7; chmask++) {
+		if (e == hipSuccess)
+			e = dock_pick_ch<false>(chmask, NULL);
+		if (e == hipSuccess)
+			e = dock_pick_ch<true>(chmask, NULL);
+	}
 	return e;
 }
 
@@ -1811,6 +2062,25 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
 	const WvsArgs a = {&fs, strips, bands, lds, grid, scope_k0_matrix(colorspace), dst, h, st, tm};
 	return wvs_pick(chmask, fuse_k0, wide, his != NULL, &a);
+}
+
+bool scope_dock_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, uint32_t num_cu, const ScopeTuning &tn)
+{
+	const u32 strips = scope_wvs_strips(fs.width, 1);
+	return scope_wvs_vector_shape(fs, wvs_dst, tn) && fs.height <= 8u * DOCK_G * (SCOPE_BLOCK / 64) && fs.n_frames * strips <= num_cu &&
+	       strips <= 256u && (u64)fs.height * fs.linesize < (1ull << 31);
+}
+
+hipError_t scope_launch_dock(const ScopeFrameSet &fs, uint32_t chmask, int colorspace, uint8_t *wvs_dst, const ScopeHisSink *his,
+			     uint8_t *vss_part, uint8_t *vss_mask, hipStream_t st, const ScopeTiming *tm)
+{
+	if ((chmask & 7u) == 0)
+		return hipErrorInvalidValue;
+	ScopeWvsHis h = {NULL, NULL, NULL, 0};
+	if (his)
+		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
+	const DockArgs a = {&fs, scope_wvs_strips(fs.width, 1), scope_k0_matrix(colorspace), wvs_dst, h, vss_part, vss_mask, st, tm};
+	return his ? dock_pick_ch<true>(chmask, &a) : dock_pick_ch<false>(chmask, &a);
 }
 
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,

@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "scope_convert_rgb_yuv",
     "scope_vectorscope", "scope_waveform", "scope_histogram_counts", "scope_histogram", "scope_histogram_level",
     "scope_vectorscope_batch", "scope_waveform_batch", "scope_histogram_counts_batch",
-    "scope_waveform_histogram", "scope_waveform_histogram_batch",
+    "scope_waveform_histogram", "scope_waveform_histogram_batch", "scope_three_scopes_batch",
     "scope_table_widen_u8_u32", "scope_table_clamp_u32_u8",
     "scope_table_pack_u8_u16x2", "scope_table_unpack_clamp_u16x2_u8",
     "scope_ctx_profile", "scope_ctx_kernel_ms",
@@ -127,6 +127,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_histogram_counts_batch": (i32, [vp, C.POINTER(Batch), u32, u32, vp]),
         "scope_waveform_histogram": (i32, [vp, C.POINTER(SurfaceData), u32, u32, u32, vp, vp]),
         "scope_waveform_histogram_batch": (i32, [vp, C.POINTER(Batch), u32, u32, u32, vp, vp]),
+        "scope_three_scopes_batch": (i32, [vp, C.POINTER(Batch), u32, u32, u32, vp, vp, vp]),
         "scope_table_widen_u8_u32": (i32, [vp, vp, vp, u64]),
         "scope_table_clamp_u32_u8": (i32, [vp, vp, vp, u64]),
         "scope_table_pack_u8_u16x2": (i32, [vp, vp, vp, u64]),
@@ -306,6 +307,25 @@ class ScopeContext:
         self._check(self.L.scope_waveform_histogram_batch(self.h, C.byref(batch), wvs_components, his_components,
                                                           IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC),
                                                           _dptr(wvs_dev), _dptr(his_dev)))
+
+    def three_scopes_batch_dev(self, batch, wvs_components, his_components, vss_dev, wvs_dev, his_dev, sync=True):
+        """The dock's three scopes of every frame of a batch of RGB planes; small launches read the planes once."""
+        self._check(self.L.scope_three_scopes_batch(self.h, C.byref(batch), wvs_components, his_components,
+                                                    IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC),
+                                                    _dptr(vss_dev), _dptr(wvs_dev), _dptr(his_dev)))
+
+    def three_scopes(self, rgb, width, wvs_components=COMP_RGB, his_components=COMP_RGB, colorspace=2):
+        """Host planes in, host tables out (one frame): (vectorscope, waveform, histogram counts, status)."""
+        rgb = np.ascontiguousarray(rgb)
+        h, linesize = rgb.shape
+        ptrs = (C.c_void_p * 1)(rgb.ctypes.data)
+        b = Batch(C.cast(ptrs, C.POINTER(C.c_void_p)), 1, linesize, width, h, 1, colorspace)
+        vss = np.full((256, 256), 0xEE, dtype=np.uint8)
+        wvs = np.full((256, width, 4), 0xEE, dtype=np.uint8)
+        his = np.full((256, 4), 0xEEEEEEEE, dtype=np.uint32)
+        st = self.L.scope_three_scopes_batch(self.h, C.byref(b), wvs_components, his_components, 0,
+                                             vss.ctypes.data, wvs.ctypes.data, his.ctypes.data)
+        return vss, wvs, his, st
 
     def histogram(self, rgb=None, yuv=None, width=0, components=COMP_RGB, logscale=0, level_fixed=0, level_ratio=0,
                   colorspace=2, fuse_k0=False, hi_max_in=(0, 0, 0)):

@@ -11,7 +11,7 @@ DISTS = {1: "uniform", 2: "concentrated", 3: "flat", 4: "bars", 5: "alpha_holes"
 COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
 
 
-DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 2, "vss.hash": 0, "vss.groups": -1, "his.unroll": 0, "wvs.wide": 1, "wvs.strip": 0, "wvs.deep": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.block": 0, "his.block": 0,
+DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 2, "vss.hash": 0, "vss.groups": -1, "his.unroll": 0, "wvs.wide": 1, "wvs.strip": 0, "wvs.deep": 1, "dock": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.block": 0, "his.block": 0,
             "nt": 1, "slices": 0}
 
 
@@ -471,3 +471,37 @@ def check_display(ctx, oracle, w=70, h=40, quick=False):
                             oracle.display_histogram(flt, hi, comp, display, lh), f"D3 c{comp:#x} d{display} h{lh}")
             assert_same(ctx.display_histogram(flt_log, hi_log, comp, display, 77),
                         oracle.display_histogram(flt_log, hi_log, comp, display, 77), f"D3 log c{comp:#x} d{display}")
+
+
+def check_three_scopes_host(ctx, oracle, w, h, dist, wc=0x07, hc=0x07, linesize=None, colorspace=2):
+    """scope_three_scopes_batch with host planes and tables (the two-pass form): the three tables of the separate scopes."""
+    rgb, yuv = frames(oracle, w, h, dist, linesize, colorspace=colorspace)
+    vss, wvs, his, st = ctx.three_scopes(rgb, w, wc, hc, colorspace)
+    assert st == 0
+    assert_same(vss, oracle.vectorscope(yuv, w), f"three scopes: vectorscope {w}x{h} d{dist}")
+    assert_same(wvs, oracle.waveform(rgb, yuv, w, wc), f"three scopes: waveform {wc:#x} {w}x{h} d{dist}")
+    assert_same(his, oracle.histogram_counts(rgb, yuv, w, hc), f"three scopes: histogram {hc:#x} {w}x{h} d{dist}")
+
+
+def check_three_scopes_dev(ctx, oracle, to_dev, to_host, w, h, dists, wc=0x07, hc=0x07, linesize=None, colorspace=2, reps=2):
+    """Device-resident planes and tables (to_dev / to_host as in check_device_path): small launches go through
+    scope_dock_kernel (one read, the strip's texels in registers); every frame's three tables against the oracle, `reps`
+    times (tickets and accumulators come back to zero)."""
+    import numpy as np
+
+    pairs = [frames(oracle, w, h, d, linesize, seed=300 + d, colorspace=colorspace) for d in dists]
+    n = len(pairs)
+    ls = pairs[0][0].shape[1]
+    hr, addr = to_dev(np.concatenate([p[0].reshape(-1) for p in pairs]))
+    b = ctx._batch([addr + i * h * ls for i in range(n)], ls, w, h, True, colorspace)
+    hv, av = to_dev(np.full(n * 65536, 0xEE, np.uint8))
+    hw, aw = to_dev(np.full(n * 256 * w * 4, 0xEE, np.uint8))
+    hh, ah = to_dev(np.full(n * 4096, 0xEE, np.uint8))
+    for rep in range(reps):
+        ctx.three_scopes_batch_dev(b, wc, hc, av, aw, ah)
+        vss, wvs, his = to_host(hv).reshape(n, 256, 256), to_host(hw).reshape(n, 256, w, 4), to_host(hh).view(np.uint32).reshape(n, 256, 4)
+        for f, (rgb, yuv) in enumerate(pairs):
+            tag = f"{w}x{h} d{dists[f]} f{f} rep{rep}"
+            assert_same(vss[f], oracle.vectorscope(yuv, w), "dock vectorscope " + tag)
+            assert_same(wvs[f], oracle.waveform(rgb, yuv, w, wc), f"dock waveform {wc:#x} " + tag)
+            assert_same(his[f], oracle.histogram_counts(rgb, yuv, w, hc), f"dock histogram {hc:#x} " + tag)

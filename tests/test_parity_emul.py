@@ -139,6 +139,25 @@ def test_waveform_deep_queue_across_flushes(emul_ctx, oracle):
         pc.check_waveform(emul_ctx, oracle, 512, 265, 5, 0x07)
 
 
+@pytest.mark.parametrize("dock", [1, 0])
+def test_three_scopes_one_read(emul_ctx, oracle, dock):
+    """scope_dock_kernel: one read of the plane for waveform + histogram + vectorscope (the emulated chip has 6 CUs, so
+    up to six 16-column strips qualify); dock=0 is the two-pass form of the same entry point."""
+    with pc.options(emul_ctx, dock=dock):
+        dev = lambda *a, **k: pc.check_three_scopes_dev(emul_ctx, oracle, _np_dev, lambda hnd: hnd, *a, **k)  # noqa: E731
+        dev(72, 19, [5])                                  # 5 strips, the last one 8 columns wide, row ranges of 3 rows
+        dev(64, 150, [3], reps=1)                         # flat: waveform columns saturate, absorb mode in the vectorscope
+        dev(36, 7, [1], 0x05, 0x04, 36 * 4 + 8, 1)        # fewer rows than row ranges, padded pitch, BT.601
+        dev(16, 9, [1, 2], 0x02, 0x02, reps=1)            # two frames in one launch
+        dev(100, 5, [1], reps=1)                          # 7 strips on 6 CUs: two passes
+
+
+def test_three_scopes_host_planes(emul_ctx, oracle):
+    pc.check_three_scopes_host(emul_ctx, oracle, 72, 19, 5)
+    pc.check_three_scopes_host(emul_ctx, oracle, 70, 9, 1, 0x05, 0x04, colorspace=1)
+    pc.check_three_scopes_host(emul_ctx, oracle, 64, 36, 2, 0x07, 0x70)  # histogram of another plane kind: its own pass
+
+
 def test_waveform_fused_k0(emul_ctx, oracle):
     pc.check_waveform(emul_ctx, oracle, 70, 9, 1, 0x20, None, fuse=True, colorspace=1)
     pc.check_waveform(emul_ctx, oracle, 70, 9, 1, 0x50, None, fuse=True, colorspace=2)

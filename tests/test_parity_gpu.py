@@ -167,6 +167,34 @@ def test_one_and_three_frame_launches_4k(hip_ctx, oracle):
             pc.assert_same(wvs[f].cpu().numpy().reshape(256, w, 4), oracle.waveform(rgbs[f], None, w, 0x07), f"wvs n{n} f{f}")
 
 
+@pytest.mark.parametrize("dock", [1, 0])
+def test_three_scopes_one_read(hip_ctx, oracle, dock):
+    """scope_three_scopes_batch: the dock's three scopes of a frame.  Small device-resident launches read the plane ONCE
+    (scope_dock_kernel: the strip's texels stay in registers, waveform + histogram first, the vectorscope through the fused
+    K0 second); dock=0 forces the two-pass form.  Both against the oracle: 4K on every content kind, ragged last strips,
+    heights that leave row ranges partly empty, padded pitches, BT.601, every RGB mask, two small frames in one launch,
+    a frame too tall for the registers (falls back), host planes."""
+    to_dev, to_host = _torch_dev()
+
+    def dev(*a, **k):
+        pc.check_three_scopes_dev(hip_ctx, oracle, to_dev, to_host, *a, **k)
+
+    with pc.options(hip_ctx, dock=dock):
+        dev(3840, 2160, [1])
+        dev(3840, 2160, [5], 0x02, 0x02)
+        for d in (2, 3, 4):
+            dev(1920, 1080, [d], reps=1)
+        dev(1924, 1083, [1], 0x07, 0x05, 1924 * 4 + 64, colorspace=1)
+        for comp in (0x01, 0x02, 0x03, 0x04, 0x05, 0x06):
+            dev(328, 77, [5], comp, comp, reps=1)
+        dev(1280, 720, [1, 5])       # two frames, 160 strips
+        dev(4, 5, [1])
+        dev(64, 2300, [1], reps=1)   # more than 2176 rows: two passes
+        dev(330, 77, [5], reps=1)    # width % 4 != 0: two passes
+        dev(3840, 2160, [1, 2, 5], reps=1)  # 720 strips: two passes
+        pc.check_three_scopes_host(hip_ctx, oracle, 640, 360, 5)
+
+
 @pytest.mark.parametrize("strip", [16, 64])
 def test_waveform_strip_widths(hip_ctx, oracle, strip):
     """Both shapes a small launch can take -- 16-column strips (eight rows per wave instruction into four table

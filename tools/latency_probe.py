@@ -63,7 +63,7 @@ def main():
         for nf in [int(x) for x in args.frames.split(",")]:
             groups = pool // nf
             for scope, optset in [(sc, os_) for sc in args.scopes.split(",") for os_ in sets]:
-                if optset and not any(kv.split("=")[0].split(".")[0] in ("slices", "nt", {"vectorscope": "vss", "vectorscope_rgb": "vss", "histogram": "his", "waveform": "wvs"}[scope], "fold")
+                if optset and not any(kv.split("=")[0].split(".")[0] in ("slices", "nt", {"vectorscope": "vss", "vectorscope_rgb": "vss", "histogram": "his", "waveform": "wvs", "three_scope": "dock"}[scope], "fold", "dock")
                                       for kv in optset):
                     continue  # this option set does not concern this scope
                 for kv in optset:
@@ -74,13 +74,19 @@ def main():
                     tbytes, algo = 65536, 4 * W * H + 65536
                 else:
                     batches = [ctx.make_device_batch(rgb[i * nf:(i + 1) * nf], 4 * W, W, H, planes_are_rgb=True, colorspace=2) for i in range(groups)]
-                    tbytes = {"vectorscope_rgb": 65536, "histogram": 4096, "waveform": 256 * W * 4}[scope]
+                    tbytes = {"vectorscope_rgb": 65536, "histogram": 4096, "waveform": 256 * W * 4, "three_scope": 65536}[scope]
                     algo = 4 * W * H + tbytes
                 tabs = torch.empty((groups, nf, tbytes), dtype=torch.uint8, device="cuda")
+                if scope == "three_scope":  # the dock's three scopes (scope_three_scopes_batch); the vectorscope table is checked
+                    algo = 4 * W * H + 65536 + 256 * W * 4 + 4096
+                    wtab = torch.empty((2, nf, 256 * W * 4), dtype=torch.uint8, device="cuda")
+                    htab = torch.empty((2, nf, 1024), dtype=torch.int32, device="cuda")
 
                 def call(i):
                     g = i % groups
-                    if scope.startswith("vectorscope"):
+                    if scope == "three_scope":
+                        ctx.three_scopes_batch_dev(batches[g], 0x07, 0x07, tabs[g], wtab[i & 1], htab[i & 1], sync=False)
+                    elif scope.startswith("vectorscope"):
                         ctx.vectorscope_batch_dev(batches[g], tabs[g], sync=False)
                     elif scope == "histogram":
                         ctx.histogram_counts_batch_dev(batches[g], 0x07, tabs[g], sync=False)
@@ -117,7 +123,7 @@ def main():
                 call(0)
                 ctx.sync()
                 got = tabs[0, 0].cpu().numpy()
-                if scope.startswith("vectorscope"):
+                if scope.startswith("vectorscope") or scope == "three_scope":
                     ok = np.array_equal(got.reshape(256, 256), o.vectorscope(host_yuv0, W))
                 elif scope == "histogram":
                     ok = np.array_equal(got.view(np.uint32).reshape(256, 4), o.histogram_counts(host_rgb0, host_yuv0, W, 0x07))

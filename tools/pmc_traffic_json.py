@@ -61,6 +61,8 @@ def main():
             continue
         fetch, write = counters(fd, "FETCH_SIZE"), counters(wd, "WRITE_SIZE")
         lead = LEAD[wl]
+        if wl == "three_scope" and "scope_dock_kernel" in fetch:  # small launches: one kernel reads the planes once
+            lead = "scope_dock_kernel"
         if lead not in fetch or lead not in write:
             continue
         steps_f, steps_w = fetch[lead][1], write[lead][1]
