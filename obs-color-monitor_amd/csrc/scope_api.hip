@@ -453,6 +453,40 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 	return SCOPE_OK;
 }
 
+/* The dock's three scopes from ONE read of device-resident RGB planes (scope_dock_kernel): 1 = done (enqueued, and waited
+ * for unless SCOPE_ASYNC), 0 = this launch does not qualify (the caller runs the separate passes), < 0 = error.
+ * cw / ch: the waveform's and the histogram's RGB channel masks, ch a subset of cw. */
+int run_dock(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width, uint32_t height,
+	     uint32_t cw, uint32_t ch, int colorspace, uint32_t flags, uint8_t *vss_out, uint8_t *wvs_out, uint32_t *his_counts)
+{
+	const uint32_t dev = SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE;
+	if (!ctx->tn.dock || (flags & dev) != dev || (flags & SCOPE_OUT_PACKED16) || !cw || (ch & ~cw) || !width || !height ||
+	    n == 0 || n > SCOPE_MAX_FRAMES)
+		return 0;
+	int st = check_geometry(ctx, linesize, width, height);
+	if (st)
+		return st;
+	ScopeFrameSet fs;
+	st = stage_planes(ctx, planes, n, linesize, width, height, flags, &fs);
+	if (st)
+		return st;
+	if (!scope_dock_fits(fs, wvs_out, (uint32_t)ctx->num_cu, ctx->tn))
+		return 0;
+	const uint32_t strips = scope_wvs_strips(width, 1), mask_block = SCOPE_BLOCK;
+	st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)n * strips * SCOPE_VSS_BINS);
+	if (!st)
+		st = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)n * strips * mask_block);
+	if (st)
+		return st;
+	const ScopeHisSink sink = {ctx->his_acc, ctx->tickets, his_counts, ch};
+	TIMED_LAUNCH(ctx, scope_launch_dock(fs, cw, colorspace, wvs_out, his_counts ? &sink : NULL, ctx->partial, ctx->pmask, ctx->stream,
+					    tm_));
+	HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, vss_out, n, strips, mask_block, 0, ctx->stream));
+	if (!(flags & SCOPE_ASYNC))
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return 1;
+}
+
 int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width,
 		  uint32_t height, uint32_t chmask, int fuse, int colorspace, uint32_t flags, uint32_t *counts)
 {
@@ -1133,34 +1167,13 @@ int scope_three_scopes_batch(scope_ctx *ctx, const struct scope_batch *b, uint32
 	for (uint32_t i = 0; i < b->n_frames; i++)
 		if (!b->planes[i])
 			return SCOPE_ENODATA;
-	const uint32_t cw = channel_mask(wvs_components), ch = channel_mask(his_components);
-	const bool rgb_kind = (wvs_components & 0x07u) != 0 && (his_components & 0x07u) != 0;
-	const uint32_t dev = SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE;
 	/* One read for all three: device-resident planes and tables, RGB channels for waveform and histogram (the histogram a
 	 * subset of the waveform's), and a launch small enough for one round of 16-column strips -- the dock's one frame. */
-	if (rgb_kind && (ch & ~cw) == 0 && (flags & dev) == dev && b->width && b->height && b->n_frames <= SCOPE_MAX_FRAMES &&
-	    ctx->tn.dock) {
-		int stc = check_geometry(ctx, b->linesize, b->width, b->height);
-		if (stc)
-			return stc;
-		ScopeFrameSet fs;
-		stc = stage_planes(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, flags, &fs);
-		if (stc)
-			return stc;
-		if (scope_dock_fits(fs, wvs_out, (uint32_t)ctx->num_cu, ctx->tn)) {
-			const uint32_t nf = b->n_frames, strips = scope_wvs_strips(b->width, 1), mask_block = SCOPE_BLOCK;
-			stc = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * strips * SCOPE_VSS_BINS);
-			if (!stc)
-				stc = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)nf * strips * mask_block);
-			if (stc)
-				return stc;
-			const ScopeHisSink sink = {ctx->his_acc, ctx->tickets, his_counts, ch};
-			TIMED_LAUNCH(ctx, scope_launch_dock(fs, cw, b->colorspace, wvs_out, &sink, ctx->partial, ctx->pmask, ctx->stream, tm_));
-			HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, vss_out, nf, strips, mask_block, 0, ctx->stream));
-			if (!(flags & SCOPE_ASYNC))
-				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-			return SCOPE_OK;
-		}
+	if ((wvs_components & 0x07u) != 0 && (his_components & 0x07u) != 0) {
+		const int done = run_dock(ctx, b->planes, b->n_frames, b->linesize, b->width, b->height, channel_mask(wvs_components),
+					  channel_mask(his_components), b->colorspace, flags, vss_out, wvs_out, his_counts);
+		if (done)
+			return done < 0 ? done : SCOPE_OK;
 	}
 	/* everything else: the vectorscope's pass, then the waveform's with the histogram riding on it */
 	st = scope_vectorscope_batch(ctx, b, flags, vss_out);
@@ -1597,13 +1610,23 @@ int pipe_enqueue(scope_pipe *p, scope_pipe_slot *s, const uint8_t *rgb_host, uin
 		plane[0] = s->dev_stage;
 		pitch = (uint32_t)p->stage_pitch;
 	}
-	if (p->vss_bytes) {
+	bool his_done = false, all_done = false;
+	if (p->vss_bytes && p->wvs_bytes && (p->cfg.wvs_components & 0x07u) && (!p->his_bytes || (p->cfg.his_components & 0x07u))) {
+		/* all three from ONE read where the frame qualifies (scope_dock_kernel: one round of 16-column strips) */
+		const uint32_t cw = channel_mask(p->cfg.wvs_components), ch = p->his_bytes ? channel_mask(p->cfg.his_components) : 0u;
+		st = run_dock(ctx, plane, 1, pitch, w, h, cw, ch, p->cfg.colorspace, dev_flags, s->dev_vss, s->dev_wvs,
+			      p->his_bytes ? (uint32_t *)s->dev_his : NULL);
+		if (st < 0)
+			return st;
+		all_done = his_done = st == 1;
+		st = SCOPE_OK;
+	}
+	if (p->vss_bytes && !all_done) {
 		st = run_vectorscope(ctx, plane, 1, pitch, w, h, 1, p->cfg.colorspace, dev_flags, s->dev_vss);
 		if (st)
 			return st;
 	}
-	bool his_done = false;
-	if (p->wvs_bytes) {
+	if (p->wvs_bytes && !all_done) {
 		const uint32_t c = p->cfg.wvs_components, hc = p->cfg.his_components;
 		/* the histogram rides on the waveform's pass when it counts the same kind of plane and no other channels */
 		his_done = p->his_bytes && ((c & 0x07u) != 0) == ((hc & 0x07u) != 0) && (channel_mask(hc) & ~channel_mask(c)) == 0;
