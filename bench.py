@@ -59,7 +59,8 @@ WORKLOAD_TEXT = {
                    "passes with the histogram riding on the waveform's; one-frame launches read the plane once",
 }
 KERNEL = {"vectorscope": "scope_vss_kernel", "vectorscope_rgb": "scope_vss_kernel", "waveform": "scope_wvs_kernel",
-          "histogram": "scope_his_kernel", "three_scope": "scope_vss_kernel + scope_wvs_kernel"}
+          "histogram": "scope_his_kernel",
+          "three_scope": "scope_vss_kernel + scope_wvs_kernel (batches) / scope_dock_kernel (one-frame launches: one read)"}
 
 
 def log(*a):
