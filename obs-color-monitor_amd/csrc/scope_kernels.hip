@@ -17,6 +17,9 @@
  *     tables, by the last workgroup of the frame.
  *   * K0 inside the scopes runs in 24-bit fixed point with an exhaustively derived guard band and an fp32 redo
  *     near a step: bit-exact with the fp32 definition, a third of its instructions.
+ *   * One-frame launches have shapes of their own: the waveform in 16-column strips (240 units per 4K frame, no row
+ *     bands, no partial tables), and scope_dock_kernel, which keeps a strip's texels in REGISTERS and walks them for
+ *     waveform + histogram and again for the vectorscope: the dock's three tables from one read of the frame.
  *
  * Reference semantics (relative to /root/reference): data/common.effect:23-43,
  * src/vectorscope.c:217-238, src/waveform.c:220-257, src/histogram.c:357-395.
