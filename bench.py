@@ -235,12 +235,21 @@ def roofline(wl, algo_bytes, launches, kernel_ms, ms_per_step, traffic):
     }
 
 
+def code_only(src):
+    """The source text without comments and without white space: an edit of a comment is not another kernel."""
+    import re
+
+    src = re.sub(rb"/\*.*?\*/", b"", src, flags=re.S)
+    src = re.sub(rb"//[^\n]*", b"", src)
+    return re.sub(rb"\s+", b"", src)
+
+
 def kernel_fingerprint():
     """sha256 of the kernel sources the library was built from: PMC traffic files are only believed for this build."""
     hsh = hashlib.sha256()
     for f in ("scope_kernels.hip", "scope_kernels.h", "scope_vec.h", "scope_api.hip"):
         with open(os.path.join(ROOT, "obs-color-monitor_amd", "csrc", f), "rb") as fh:
-            hsh.update(fh.read())
+            hsh.update(code_only(fh.read()))
     return hsh.hexdigest()[:16]
 
 

@@ -25,11 +25,18 @@ LEAD = {"vectorscope": "scope_vss_kernel", "vectorscope_rgb": "scope_vss_kernel"
 W, H = 3840, 2160
 
 
+def code_only(src):
+    """As bench.py: the source text without comments and white space."""
+    src = re.sub(rb"/\*.*?\*/", b"", src, flags=re.S)
+    src = re.sub(rb"//[^\n]*", b"", src)
+    return re.sub(rb"\s+", b"", src)
+
+
 def fingerprint():
     hsh = hashlib.sha256()
     for f in ("scope_kernels.hip", "scope_kernels.h", "scope_vec.h", "scope_api.hip"):
         with open(os.path.join(ROOT, "obs-color-monitor_amd", "csrc", f), "rb") as fh:
-            hsh.update(fh.read())
+            hsh.update(code_only(fh.read()))
     return hsh.hexdigest()[:16]
 
 
