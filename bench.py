@@ -216,6 +216,34 @@ def place_pool(torch, ctx, frames, probe, candidates):
     return keep, us, best
 
 
+class Overlap:
+    """The table sum of step i under the accumulation of step i + 1: a second scope context on a second hipStream carries
+    ncclAllReduce + unpack/clamp, events order it behind the accumulation that filled the buffer and hold the accumulation
+    that will overwrite the buffer (two steps later) until the sum has left it.  Nothing is skipped, bucketed or deferred
+    beyond the timed region: the closing synchronize waits for both streams."""
+
+    def __init__(self, torch, ocm, device, compute_stream):
+        self.torch, self.compute = torch, compute_stream
+        self.stream = torch.cuda.Stream()
+        self.ctx = ocm.ScopeContext(device)
+        self.ctx.set_stream(self.stream.cuda_stream)
+        self.filled = [torch.cuda.Event() for _ in range(2)]
+        self.summed = [torch.cuda.Event() for _ in range(2)]
+        self.used = [False, False]
+
+    def before_compute(self, buf):
+        if self.used[buf]:
+            self.compute.wait_event(self.summed[buf])
+
+    def after_compute(self, buf):
+        self.filled[buf].record(self.compute)
+        self.stream.wait_event(self.filled[buf])
+
+    def after_reduce(self, buf):
+        self.summed[buf].record(self.stream)
+        self.used[buf] = True
+
+
 def roofline(wl, algo_bytes, launches, kernel_ms, ms_per_step, traffic):
     kern_avg_ms = kernel_ms / launches if launches else float("nan")
     achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches else float("nan")
@@ -299,6 +327,9 @@ def main():
                     help="N > 1: make BASELINE config 4 (one 7680x4320 batch, row tiles, strong scaling) the headline")
     ap.add_argument("--force-reduce", action="store_true",
                     help="run the RCCL table reduction even with one rank (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--serial-reduce", action="store_true",
+                    help="N > 1: enqueue the RCCL table sum on the accumulation's own stream (round 2's first form) instead of "
+                         "overlapping step i's sum with step i+1's accumulation on a second stream")
     ap.add_argument("--torch-reduce", action="store_true", help="N > 1: sum the tables with torch.distributed (TableAllReduce) "
                     "instead of the C-ABI's scope_table_allreduce")
     ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
@@ -396,7 +427,7 @@ def main():
     table_bytes = work.tbytes
 
     # ---- N > 1: the table sum over RCCL -----------------------------------------------------------------------------
-    reducer, comm, reduce_path = None, None, None
+    reducer, comm, reduce_path, overlap = None, None, None, None
     wire = None
     if use_dist and wl in ("vectorscope", "vectorscope_rgb", "histogram"):
         if not args.torch_reduce:
@@ -415,8 +446,14 @@ def main():
                     ctx.rccl_comm_destroy(comm)
                 comm = None
         if comm:
-            reduce_path = "C-ABI: scope_table_allreduce (ncclAllReduce uint32 sum) every step, unpack/clamp on the same stream"
             wire = [torch.empty((n, 32768 if wl != "histogram" else 1024), dtype=torch.int32, device="cuda") for _ in range(2)]
+            if args.serial_reduce:
+                reduce_path = "C-ABI: scope_table_allreduce (ncclAllReduce uint32 sum) every step, unpack/clamp on the same stream"
+                overlap = None
+            else:
+                reduce_path = ("C-ABI: scope_table_allreduce (ncclAllReduce uint32 sum) + unpack/clamp of EVERY step on a second "
+                               "hipStream: step i's table sum runs under step i+1's accumulation (two table buffers)")
+                overlap = Overlap(torch, ocm, local_rank, stream)
         else:
             from obs_color_monitor_amd.row_tiles import TableAllReduce
 
@@ -428,15 +465,25 @@ def main():
     def step(i):
         if comm:
             b, buf = work.batches[i % work.groups], i & 1
+            rctx = ctx
+            if overlap:
+                overlap.before_compute(buf)  # this buffer's previous sum must be through before it is overwritten
+                rctx = overlap.ctx
             if wl == "histogram":
                 ctx.histogram_counts_batch_dev(b, args.components, wire[buf], sync=False)
-                ctx.table_allreduce(comm, wire[buf], n * 1024)
+                if overlap:
+                    overlap.after_compute(buf)
+                rctx.table_allreduce(comm, wire[buf], n * 1024)
                 result_tables[0] = wire[buf].view(torch.uint8).view(n, 4096)
             else:
                 ctx.vectorscope_batch_dev(b, wire[buf], sync=False, packed16=True)
-                ctx.table_allreduce(comm, wire[buf], n * 32768)
-                ctx.unpack16_clamp_dev(wire[buf], work.tables[buf], n * 32768)
+                if overlap:
+                    overlap.after_compute(buf)
+                rctx.table_allreduce(comm, wire[buf], n * 32768)
+                rctx.unpack16_clamp_dev(wire[buf], work.tables[buf], n * 32768)
                 result_tables[0] = work.tables[buf]
+            if overlap:
+                overlap.after_reduce(buf)
             work.last = (i % work.groups, buf)
             return
         if reducer is not None:
@@ -593,7 +640,7 @@ def main():
     # ---- BASELINE config 4 as written: one 7680x4320 batch in N row tiles, strong scaling ---------------------------
     if (extras or args.strong) and use_dist and comm and wl in ("vectorscope", "vectorscope_rgb"):
         try:
-            result["config4"] = config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream)
+            result["config4"] = config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream, overlap=overlap)
         except Exception as e:  # noqa: BLE001
             result["config4"] = {"error": repr(e)}
         if args.strong and "error" not in result["config4"]:
@@ -609,7 +656,10 @@ def main():
     if rank == 0:
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if comm:
+        torch.cuda.synchronize()
         ctx.rccl_comm_destroy(comm)
+    if overlap:
+        overlap.ctx.close()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
@@ -617,7 +667,7 @@ def main():
         sys.exit(3)
 
 
-def config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream, frames=16, seconds=0.6):
+def config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream, frames=16, seconds=0.6, overlap=None):
     """ONE batch of 7680x4320 frames; rank r owns rows [4320 r/N, 4320 (r+1)/N) of every frame; per step every rank
     reduces its tiles, the packed tables are summed over RCCL and clamped.  Two figures: throughput with the steps
     enqueued back to back, and the latency of one step with its reduce waited for (nothing bucketed or deferred)."""
@@ -631,10 +681,29 @@ def config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream, frames=16, s
     # (cheaper than generating whole 8K frames on every GPU: a tile is all a rank ever reads)
     rgb, yuv = make_frames(torch, ctx, frames, w, th, "uniform", 0xC0FFEE + rank)
     batch = ctx.make_device_batch(yuv, 4 * w, w, th, planes_are_rgb=False)
-    wire = torch.empty((frames, 32768), dtype=torch.int32, device="cuda")
-    out = torch.empty((frames, 65536), dtype=torch.uint8, device="cuda")
+    wires = [torch.empty((frames, 32768), dtype=torch.int32, device="cuda") for _ in range(2)]
+    outs = [torch.empty((frames, 65536), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    wire, out = wires[0], outs[0]
+    count = [0]
 
     def step():
+        """steps enqueued back to back: step i's table sum overlaps step i + 1's accumulation (`overlap`), or follows it on
+        the same stream"""
+        buf = count[0] & 1
+        count[0] += 1
+        rctx = ctx
+        if overlap:
+            overlap.before_compute(buf)
+            rctx = overlap.ctx
+        ctx.vectorscope_batch_dev(batch, wires[buf], sync=False, packed16=True)
+        if overlap:
+            overlap.after_compute(buf)
+        rctx.table_allreduce(comm, wires[buf], frames * 32768)
+        rctx.unpack16_clamp_dev(wires[buf], outs[buf], frames * 32768)
+        if overlap:
+            overlap.after_reduce(buf)
+
+    def step_waited():
         ctx.vectorscope_batch_dev(batch, wire, sync=False, packed16=True)
         ctx.table_allreduce(comm, wire, frames * 32768)
         ctx.unpack16_clamp_dev(wire, out, frames * 32768)
@@ -663,7 +732,7 @@ def config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream, frames=16, s
         dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        step()
+        step_waited()
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
     lat_t = torch.tensor([sorted(lat)[len(lat) // 2]], dtype=torch.float64, device="cuda")
