@@ -132,6 +132,9 @@ def agree(torch, dist, keep_going):
     while ANY rank wants to (one tiny all-reduce per chunk of steps, which also drains the stream)."""
     if dist is None:
         return keep_going
+    # nothing of the data path -- which has a communicator of its own, on a stream of its own -- is in flight while
+    # torch.distributed's communicator runs: two communicators never have collectives queued at the same time
+    torch.cuda.synchronize()
     t = torch.tensor([1 if keep_going else 0], dtype=torch.int32, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return bool(t.item())
@@ -151,6 +154,7 @@ def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=Non
         torch.cuda.synchronize()
     for j in range(warmup):
         step(j)
+    torch.cuda.synchronize()  # the data path's own communicator is idle before torch.distributed's barrier runs
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
