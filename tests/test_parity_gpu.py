@@ -167,6 +167,18 @@ def test_one_and_three_frame_launches_4k(hip_ctx, oracle):
             pc.assert_same(wvs[f].cpu().numpy().reshape(256, w, 4), oracle.waveform(rgbs[f], None, w, 0x07), f"wvs n{n} f{f}")
 
 
+def test_randomised_geometries(hip_ctx, oracle):
+    """tools/fuzz_parity.py: random geometries (vector and scalar shapes, heights around the limits of the one-frame
+    kernels), pitches, masks, matrices and launch sizes through every accumulation entry point."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.run(hip_ctx, oracle, 60, 5, lambda m: None) == 60
+
+
 @pytest.mark.parametrize("dock", [1, 0])
 def test_three_scopes_one_read(hip_ctx, oracle, dock):
     """scope_three_scopes_batch: the dock's three scopes of a frame.  Small device-resident launches read the plane ONCE

@@ -21,14 +21,8 @@ import parity_cases as pc  # noqa: E402
 import scope_oracle  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=200)
-    ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
-    rnd = random.Random(args.seed)
-    o = scope_oracle.COracle()
-    ctx = ocm.ScopeContext(0)
+def run(ctx, o, cases, seed, log=print):
+    rnd = random.Random(seed)
 
     def to_dev(a):
         t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -37,7 +31,7 @@ def main():
     to_host = lambda t: t.cpu().numpy()  # noqa: E731
     masks = [0x07, 0x01, 0x02, 0x04, 0x03, 0x05, 0x06]
     done = 0
-    for case in range(args.cases):
+    for case in range(cases):
         shape = rnd.choice(["tiny", "wide", "tall", "mid", "odd"])
         if shape == "tiny":
             w, h = rnd.choice([4, 8, 12, 16, 20, 36, 60, 64, 68]), rnd.randint(1, 40)
@@ -67,11 +61,21 @@ def main():
             pc.check_histogram_counts(ctx, o, w, h, dist, comp, ls, colorspace=cs)
             pc.check_vectorscope(ctx, o, w, h, dist, ls, fuse=rnd.random() < 0.5, colorspace=cs)
         except Exception as e:  # noqa: BLE001
-            print("FAIL", tag, "--", repr(e)[:300], flush=True)
+            log("FAIL " + tag + " -- " + repr(e)[:300])
             raise
         done += 1
         if done % 20 == 0:
-            print(f"{done} cases ok (last: {tag})", flush=True)
+            log(f"{done} cases ok (last: {tag})")
+    return done
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    ctx = ocm.ScopeContext(0)
+    done = run(ctx, scope_oracle.COracle(), args.cases, args.seed, lambda m: print(m, flush=True))
     print(f"all {done} cases bit-exact vs the oracle")
 
 
