@@ -2,7 +2,7 @@
 
 Backends:
   * ``emul``  -- tests/emul/libscope_emul.so: the UNMODIFIED csrc/*.hip sources compiled for the
-    CPU against a thread-per-GPU-thread stand-in of the HIP runtime (tests/emul/).  Test
+    CPU against a fiber-per-GPU-thread stand-in of the HIP runtime (tests/emul/).  Test
     infrastructure only; lets kernel index arithmetic and the host glue be checked without a GPU.
   * ``hip``   -- obs-color-monitor_amd/libscope_hip.so on a real MI355X (``-m gpu``).
 

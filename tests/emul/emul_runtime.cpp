@@ -1,10 +1,13 @@
 /*
  * tests/emul/emul_runtime.cpp -- the other half of tests/emul/hip/hip_runtime.h.
- * TEST INFRASTRUCTURE ONLY: a thread-per-GPU-thread executor and malloc-backed "device" memory.
+ * TEST INFRASTRUCTURE ONLY: a fiber-per-GPU-thread executor and malloc-backed "device" memory.
  */
 #include <hip/hip_runtime.h>
 
-#include <barrier>
+#include <mutex>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <ucontext.h>
 #include <memory>
 #include <stdio.h>
 #include <thread>
@@ -17,36 +20,82 @@ alignas(16) uint32_t scope_lds[160 * 1024 / 4];
 
 namespace emul {
 
-static thread_local std::barrier<> *tls_barrier = nullptr;
+/* The GPU threads of a workgroup are FIBERS (ucontext) of the launching OS thread: thread t runs until its next
+ * __syncthreads() -- or to its end -- then thread t + 1, and when every thread of the workgroup stands at the barrier the
+ * sweep starts over.  (One OS thread per GPU thread, with a std::barrier, spent most of the test suite's time in futex
+ * calls.)  Legal for kernels in which every thread of a workgroup reaches the same barriers, which HIP demands anyway;
+ * nothing in the product's kernels spins on another thread.  Workgroups run one after the other (one LDS window), launches
+ * from several host threads are serialised. */
+struct Fiber {
+	ucontext_t uc;
+	bool done;
+};
+
+static std::mutex launch_mu;
+static thread_local ucontext_t main_uc;
+static thread_local Fiber *cur_fiber = nullptr;
+static void (*g_fn)(void *) = nullptr;
+static void *g_ctx = nullptr;
+
+static void fiber_entry()
+{
+	g_fn(g_ctx);
+	cur_fiber->done = true;
+	swapcontext(&cur_fiber->uc, &main_uc);
+}
 
 void block_barrier()
 {
-	tls_barrier->arrive_and_wait();
+	swapcontext(&cur_fiber->uc, &main_uc);
 }
 
 void run_grid(dim3 grid, dim3 block, void (*thread_fn)(void *), void *ctx)
 {
-	const unsigned nthreads = block.x * block.y * block.z;
-	std::barrier<> bar(nthreads);
-	std::vector<std::thread> pool;
-	pool.reserve(nthreads);
-	for (unsigned t = 0; t < nthreads; t++) {
-		pool.emplace_back([=, &bar]() {
-			tls_barrier = &bar;
-			blockDim = block;
-			gridDim = grid;
-			threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-			for (unsigned by = 0; by < grid.y; by++)
-				for (unsigned bx = 0; bx < grid.x; bx++) {
-					blockIdx = dim3(bx, by, 0);
-					thread_fn(ctx);
-					/* workgroups share the one LDS window: finish this one first */
-					bar.arrive_and_wait();
-				}
-		});
+	std::lock_guard<std::mutex> one(launch_mu);
+	const unsigned n = block.x * block.y * block.z;
+	constexpr size_t STACK = 256 * 1024;
+	static std::vector<Fiber> fibers;
+	static std::vector<char *> stacks;
+	while (stacks.size() < n) {
+		void *m = mmap(nullptr, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (m == MAP_FAILED) {
+			fprintf(stderr, "emul: cannot map a fiber stack\n");
+			abort();
+		}
+		stacks.push_back((char *)m);
 	}
-	for (auto &th : pool)
-		th.join();
+	if (fibers.size() < n)
+		fibers.resize(n);
+	g_fn = thread_fn;
+	g_ctx = ctx;
+	blockDim = block;
+	gridDim = grid;
+	for (unsigned by = 0; by < grid.y; by++)
+		for (unsigned bx = 0; bx < grid.x; bx++) {
+			blockIdx = dim3(bx, by, 0);
+			for (unsigned t = 0; t < n; t++) {
+				Fiber &f = fibers[t];
+				getcontext(&f.uc);
+				f.uc.uc_stack.ss_sp = stacks[t];
+				f.uc.uc_stack.ss_size = STACK;
+				f.uc.uc_link = nullptr;
+				f.done = false;
+				makecontext(&f.uc, fiber_entry, 0);
+			}
+			for (unsigned live = n; live;) {
+				live = 0;
+				for (unsigned t = 0; t < n; t++) {
+					Fiber &f = fibers[t];
+					if (f.done)
+						continue;
+					threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+					cur_fiber = &f;
+					swapcontext(&main_uc, &f.uc);
+					live += f.done ? 0u : 1u;
+				}
+			}
+		}
+	cur_fiber = nullptr;
 }
 
 } // namespace emul

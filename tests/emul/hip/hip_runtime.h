@@ -8,8 +8,8 @@
  * against the oracle on machines without a GPU.  It is never built into, linked with or loaded
  * by the product library (libscope_hip.so), which has no CPU path at all.
  *
- * Model: one OS thread per GPU thread of a workgroup, workgroups run one after another,
- * __syncthreads() is a std::barrier, LDS is one static buffer.  Wave-level operations see a
+ * Model: one fiber (ucontext) per GPU thread of a workgroup, run in turn up to their next __syncthreads() by the
+ * launching OS thread; workgroups run one after another, LDS is one static buffer.  Wave-level operations see a
  * wave of ONE active lane (a legal execution mask on the hardware), so code must already be
  * correct for arbitrary masks; the full-wave behaviour is covered by the -m gpu tests.
  */

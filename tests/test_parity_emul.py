@@ -1,5 +1,5 @@
 """Parity of the product sources against the oracle WITHOUT a GPU: csrc/*.hip compiled for the CPU
-by tests/emul (thread-per-GPU-thread executor).  Small frames only; the -m gpu tests repeat these
+by tests/emul (fiber-per-GPU-thread executor).  Small frames only; the -m gpu tests repeat these
 on the real kernels and add the full BASELINE sizes."""
 import numpy as np
 import pytest
@@ -96,7 +96,7 @@ def test_waveform_unit_walk(emul_ctx, oracle, persist):
             pc.check_waveform(emul_ctx, oracle, 66, 50, 7, 0x05)  # bands of different heights
 
 
-@pytest.mark.parametrize("w,h,ls", [(72, 9, None), (20, 7, 96), (4, 1, None), (320, 17, 1296)])
+@pytest.mark.parametrize("w,h,ls", [(64, 36, None), (72, 9, None), (20, 7, 96), (4, 1, None), (132, 8, None), (320, 17, 1296), (1284, 19, None)])
 def test_waveform_narrow_strips_geometry(emul_ctx, oracle, w, h, ls):
     """16-column strips (the shape of one- and two-frame launches): eight rows per wave instruction into four table
     replicas, ragged last strips, 1..7 rows left over, more than 16 units (the XCD pairing of neighbouring strips)."""
@@ -104,7 +104,7 @@ def test_waveform_narrow_strips_geometry(emul_ctx, oracle, w, h, ls):
         pc.check_waveform(emul_ctx, oracle, w, h, 1, 0x07, ls)
 
 
-@pytest.mark.parametrize("comp", [0x07, 0x20, 0x50, 0x13])  # every mask runs on the GPU (test_waveform_strip_widths)
+@pytest.mark.parametrize("comp", pc.COMPONENTS)
 def test_waveform_narrow_strips_components(emul_ctx, oracle, comp):
     with pc.options(emul_ctx, **{"wvs.strip": 16}):
         pc.check_waveform(emul_ctx, oracle, 72, 19, 5, comp)
@@ -146,11 +146,12 @@ def test_three_scopes_one_read(emul_ctx, oracle, dock):
     with pc.options(emul_ctx, dock=dock):
         dev = lambda *a, **k: pc.check_three_scopes_dev(emul_ctx, oracle, _np_dev, lambda hnd: hnd, *a, **k)  # noqa: E731
         dev(72, 19, [5])                                  # 5 strips, the last one 8 columns wide, row ranges of 3 rows
-        if dock:
-            dev(64, 150, [3], reps=1)                     # flat: waveform columns saturate, absorb mode in the vectorscope
-            dev(36, 7, [1], 0x05, 0x04, 36 * 4 + 8, 1)    # fewer rows than row ranges, padded pitch, BT.601
-            dev(16, 9, [1, 2], 0x02, 0x02, reps=1)        # two frames in one launch
-            dev(100, 5, [1], reps=1)                      # 7 strips on 6 CUs: two passes
+        dev(64, 150, [3], reps=1)                         # flat: waveform columns saturate, absorb mode in the vectorscope
+        dev(36, 7, [1], 0x05, 0x04, 36 * 4 + 8, 1)        # fewer rows than row ranges, padded pitch, BT.601
+        dev(16, 9, [1, 2], 0x02, 0x02, reps=1)            # two frames in one launch
+        dev(100, 5, [1], reps=1)                          # 7 strips on 6 CUs: two passes
+        dev(80, 2170, [2], reps=1)                        # 17 loads per lane, the last ones partly past the end
+        dev(16, 2300, [1], reps=1)                        # more rows than the registers hold: two passes
 
 
 def test_three_scopes_host_planes(emul_ctx, oracle):

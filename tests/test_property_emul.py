@@ -11,7 +11,7 @@ GEOM = st.tuples(st.integers(1, 97), st.integers(1, 33), st.integers(0, 9), st.s
 OPTS = st.fixed_dictionaries({"vss.merge": st.sampled_from([0, 2, 3]), "vss.hash": st.sampled_from([0, 1]),
                               "vss.groups": st.integers(0, 3), "vss.unroll": st.sampled_from([1, 2, 4]),
                               "slices": st.sampled_from([0, 1, 2, 5]), "nt": st.sampled_from([0, 1])})
-SETTINGS = dict(max_examples=12, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+SETTINGS = dict(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 
 
 def _dev(a):
