@@ -14,21 +14,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 import obs_color_monitor_amd as ocm  # noqa: E402
 import parity_cases as pc  # noqa: E402
 import scope_oracle  # noqa: E402
 
 
-def run(ctx, o, cases, seed, log=print):
+def run(ctx, o, cases, seed, log=print, to_dev=None, to_host=None):
+    """to_dev / to_host: how "device" buffers are made and read back (default: torch on the GPU; the CPU emulation passes
+    numpy buffers, which are their own device memory there)."""
     rnd = random.Random(seed)
+    if to_dev is None:
+        import torch
 
-    def to_dev(a):
-        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
-        return t, int(t.data_ptr())
+        def to_dev(a):
+            t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            return t, int(t.data_ptr())
 
-    to_host = lambda t: t.cpu().numpy()  # noqa: E731
+        to_host = lambda t: t.cpu().numpy()  # noqa: E731
     masks = [0x07, 0x01, 0x02, 0x04, 0x03, 0x05, 0x06]
     done = 0
     for case in range(cases):
