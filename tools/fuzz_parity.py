@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
+    import torch  # noqa: F401  (first, so that the library shares torch's HIP runtime)
+
     ctx = ocm.ScopeContext(0)
     done = run(ctx, scope_oracle.COracle(), args.cases, args.seed, lambda m: print(m, flush=True))
     print(f"all {done} cases bit-exact vs the oracle")
