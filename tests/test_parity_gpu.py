@@ -406,6 +406,28 @@ def test_fused_k0_all_colours(hip_ctx, oracle, cs):
     pc.assert_same(got, oracle.waveform(None, yuv2, 4096, 0x20), f"fused luma waveform, all colours, cs{cs}")
 
 
+@pytest.mark.parametrize("cs", [1, 2])
+def test_dock_kernel_all_colours(hip_ctx, oracle, cs):
+    """All 2^24 colours through the one-read kernel (K0 on texel pairs out of registers): two device-resident frames of
+    4096 x 2048 (256 strips each: exactly one round), a shuffled order so that every row range and replica sees all kinds;
+    the vectorscope, the RGB waveform and the RGB histogram of each against the oracle."""
+    to_dev, to_host = _torch_dev()
+    perm = np.random.default_rng(11 + cs).permutation(1 << 24).astype(np.uint32)
+    v = perm | np.uint32(0xFF000000)
+    for half in range(2):
+        rgb = np.ascontiguousarray(v[half << 23:(half + 1) << 23]).view(np.uint8).reshape(2048, 4096 * 4)
+        yuv = oracle.rgb_to_yuv(rgb, 4096, cs)
+        hr, ar = to_dev(rgb.reshape(-1))
+        b = hip_ctx._batch([ar], 4096 * 4, 4096, 2048, True, cs)
+        hv, av = to_dev(np.full(65536, 0xEE, np.uint8))
+        hw, aw = to_dev(np.full(256 * 4096 * 4, 0xEE, np.uint8))
+        hh, ah = to_dev(np.full(4096, 0xEE, np.uint8))
+        hip_ctx.three_scopes_batch_dev(b, 0x07, 0x07, av, aw, ah)
+        pc.assert_same(to_host(hv).reshape(256, 256), oracle.vectorscope(yuv, 4096), f"dock vectorscope, all colours, cs{cs} half {half}")
+        pc.assert_same(to_host(hw).reshape(256, 4096, 4), oracle.waveform(rgb, yuv, 4096, 0x07), f"dock waveform, all colours, half {half}")
+        pc.assert_same(to_host(hh).view(np.uint32).reshape(256, 4), oracle.histogram_counts(rgb, yuv, 4096, 0x07), f"dock histogram, half {half}")
+
+
 # ---------------------------------------------------------------------------------- full sizes ---
 
 
