@@ -406,6 +406,41 @@ def test_fused_k0_all_colours(hip_ctx, oracle, cs):
     pc.assert_same(got, oracle.waveform(None, yuv2, 4096, 0x20), f"fused luma waveform, all colours, cs{cs}")
 
 
+def test_dock_kernel_back_to_back_stress(hip_ctx, oracle):
+    """2000 one-read launches back to back on one stream, two alternating 1080p frames (120 strips each), no host
+    synchronisation in between: the histogram's accumulator and arrival tickets -- fired after the waveform's flush, waited
+    for at the end of the kernel -- must be back at zero for every launch, and partial tables must not be overwritten
+    before the reduce kernel has read them.  Every 100th pair of results is compared on the device with tables checked
+    against the oracle."""
+    import torch
+
+    w, h = 1920, 1080
+    frames_ = [pc.frames(oracle, w, h, d, seed=700 + d) for d in (1, 5)]
+    tr = [torch.from_numpy(f[0]).cuda() for f in frames_]
+    batches = [hip_ctx.make_device_batch(t.unsqueeze(0), 4 * w, w, h, planes_are_rgb=True, colorspace=2) for t in tr]
+    ref = []
+    for i, (rgb, yuv) in enumerate(frames_):
+        v = torch.empty(65536, dtype=torch.uint8, device="cuda")
+        wv = torch.empty(256 * w * 4, dtype=torch.uint8, device="cuda")
+        hs = torch.empty(1024, dtype=torch.int32, device="cuda")
+        hip_ctx.three_scopes_batch_dev(batches[i], 0x07, 0x07, v, wv, hs)
+        pc.assert_same(v.cpu().numpy().reshape(256, 256), oracle.vectorscope(yuv, w), "stress reference vectorscope")
+        pc.assert_same(wv.cpu().numpy().reshape(256, w, 4), oracle.waveform(rgb, yuv, w, 0x07), "stress reference waveform")
+        pc.assert_same(hs.cpu().numpy().view(np.uint32).reshape(256, 4), oracle.histogram_counts(rgb, yuv, w, 0x07), "stress reference histogram")
+        ref.append((v, wv, hs))
+    outs = [[(torch.empty(65536, dtype=torch.uint8, device="cuda"), torch.empty(256 * w * 4, dtype=torch.uint8, device="cuda"),
+              torch.empty(1024, dtype=torch.int32, device="cuda")) for _ in range(2)] for _ in range(2)]
+    for it in range(1000):
+        for i in range(2):
+            v, wv, hs = outs[i][it & 1]
+            hip_ctx.three_scopes_batch_dev(batches[i], 0x07, 0x07, v, wv, hs, sync=False)
+        if it % 100 == 99:
+            hip_ctx.sync()
+            for i in range(2):
+                for got, want, what in zip(outs[i][it & 1], ref[i], ("vectorscope", "waveform", "histogram")):
+                    assert torch.equal(got, want), f"dock stress: {what} of frame {i} differs after {2 * (it + 1)} launches"
+
+
 @pytest.mark.parametrize("cs", [1, 2])
 def test_dock_kernel_all_colours(hip_ctx, oracle, cs):
     """All 2^24 colours through the one-read kernel (K0 on texel pairs out of registers): two device-resident frames of
