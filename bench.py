@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on its config: Gpix/s of scope accumulation @3840x2160.
 
-  python bench.py --gpus N --steps K --warmup W         (N > 1: launched under torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: bench.py STARTS ITS OWN RANKS (one process per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set for each, rendezvous on 127.0.0.1), watches them against a hard deadline, and prints rank 0's
+line with a `launcher` object added.  A collective that hangs or fails does not take the line with it: the launcher
+kills the ranks it started and tries the next reduce path (C-ABI RCCL -> torch.distributed -> replicas without a table
+sum, which says so in every field that matters).  Under `python -m torch.distributed.run ... bench.py --gpus N` (the
+environment has WORLD_SIZE) the process is one rank, as before.
 
 A *step* is one pass of the hot path over one batch of synthetic input: by default the 256x256 CbCr vectorscope
 scatter (BASELINE configs[1]) over `--frames` (64, the most one launch takes) distinct 3840x2160 BGRA8 frames that are
@@ -13,31 +20,40 @@ The timed region is EXACTLY K steps between barrier + synchronize (-> `value`). 
 before a clock or a utilisation sampler notices, the same steps then run on for at least `--min-seconds` (1 s) more
 (-> `sustained`).  The accumulation kernel's average duration (-> `roofline`) comes from a third leg of the same steps
 in which every launch carries its own begin/end HIP events on its stream (hipExtLaunchKernelGGL: the figure rocprofv3
---kernel-trace --stats reports for the same command); it is a separate leg because reading events costs the host a
-few microseconds per launch, which a one-frame step would feel.
+--kernel-trace --stats reports for the same command).
 
 Besides the headline the default one-GPU run measures, briefly and in the same process (`--no-extras` skips them):
-  variants   the other workloads of BASELINE.json at the same batch: vectorscope with K0 fused (config 2, variant ii),
-             waveform (config 3), histogram, and the dock's three scopes on one frame set (config 5's kernels; its
-             algorithmic bytes are ONE read of the frames)
-  latency    the reference's real call shape: ONE frame per call and the 3-slot ring (src/common.c:366-368,
-             src/common.h:46) -- microseconds of stream work per call, all kernels of the call included
-  stream     BASELINE config 5 under this clock: pinned host frames -> scope_pipe_* (upload / compute / download
-             streams, depth 3), flat out and paced at 240 fps (PCIe-inclusive; never `value`)
+  variants       the other workloads of BASELINE.json at the same batch: vectorscope with K0 fused (config 2, variant ii),
+                 waveform for every mode config 3 names (RGB, Y, R, G, B), histogram, the dock's three scopes (config 5's
+                 kernels; algorithmic bytes = ONE read of the frames)
+  distributions  SURVEY.md 8(d)'s inputs other than uniform noise -- natural, concentrated, flat, screen, ramp, padded
+                 pitch -- through the headline kernel and the fused-K0 one; alpha holes through histogram and waveform
+  latency        the reference's real call shape: ONE frame per call and the 3-slot ring (src/common.c:366-368,
+                 src/common.h:46) -- microseconds of stream work per call, all kernels of the call included
+  config1        BASELINE configs[0]: histogram over one 1280x720 frame on the CPU path (the oracle, one thread), ms per
+                 frame, and whether the GPU's tables of the same frame are bit-identical
+  stream         BASELINE config 5 under this clock: pinned host frames -> scope_pipe_* (upload / compute / download
+                 streams, depth 3), flat out and paced at 240 fps (PCIe-inclusive; never `value`)
+  config4        BASELINE configs[3] as written, at EVERY N including 1: ONE batch of 7680x4320 frames (the same frames on
+                 every rank count: shared seed), rank r owns rows [4320 r/N, 4320 (r+1)/N), tables summed over RCCL
+                 through the C-ABI ("strong"), with the reduce of a step overlapped and waited for
 `--workload` makes any of them the headline instead (e.g. `--workload vectorscope --frames 1`).
 
-N > 1: every rank owns one 3840x2160 row tile of a frame N times as tall ("weak"); the ranks' clamped 256x256 tables
-are summed over RCCL through the C-ABI (scope_table_allreduce: two bins per uint32 word, no torch.distributed in the
-data path; torch.distributed only carries the communicator id, the barriers and the max-over-ranks time) and clamped
-once.  The same run then measures BASELINE config 4 as written (`config4`): ONE batch of 7680x4320 frames, rank r
-owns rows [4320 r/N, 4320 (r+1)/N) of every frame ("strong"), with the reduce of every step waited for.
+N > 1 headline: every rank owns one 3840x2160 row tile of a frame N times as tall ("weak"); the ranks' clamped 256x256
+tables are summed over RCCL through the C-ABI (scope_table_allreduce: two bins per uint32 word) and clamped once.
+torch.distributed (gloo, CPU tensors) only carries the communicator id, the barriers and the max-over-ranks time: no
+control-plane collective ever shares a GPU queue with the data path's.
 
 Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).
 """
 import argparse
+import faulthandler
 import hashlib
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,19 +64,19 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 W4K, H4K = 3840, 2160
-PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
+METRIC = "Gpix/s scope accumulation @3840×2160; achieved HBM GB/s vs peak"
+UNPINNED = " (parity unpinned: the oracle is this build's restatement of the reference loops, DESIGN.md section 4)"
 
 WORKLOAD_TEXT = {
     "vectorscope": "vectorscope 256x256 CbCr scatter (K1) over staged Y'CbCr planes",
     "vectorscope_rgb": "vectorscope with fused K0 over RGB planes",
     "waveform": "waveform per-column 256-bin (K2)",
     "histogram": "histogram 3x256 u32 (K3)",
-    "three_scope": "vectorscope (fused K0) + waveform + histogram of every frame (scope_three_scopes_batch): batches in two "
-                   "passes with the histogram riding on the waveform's; one-frame launches read the plane once",
+    "three_scope": "vectorscope (fused K0) + waveform + histogram of every frame (scope_three_scopes_batch)",
 }
 KERNEL = {"vectorscope": "scope_vss_kernel", "vectorscope_rgb": "scope_vss_kernel", "waveform": "scope_wvs_kernel",
-          "histogram": "scope_his_kernel",
-          "three_scope": "scope_vss_kernel + scope_wvs_kernel (batches) / scope_dock_kernel (one-frame launches: one read)"}
+          "histogram": "scope_his_kernel", "three_scope": "scope_dock_kernel / scope_vss_kernel + scope_wvs_kernel"}
 
 
 def log(*a):
@@ -72,23 +88,234 @@ def table_bytes_of(wl, w):
             "three_scope": 65536 + 256 * w * 4 + 4096}[wl]
 
 
+# =====================================================================================================================
+#  the launcher: `python bench.py --gpus N` with no WORLD_SIZE around starts N ranks itself
+# =====================================================================================================================
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def kill_ranks(procs):
+    """Ends exactly the processes this launcher started (each is the leader of its own process group)."""
+    for p in procs:
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+    t_end = time.time() + 5
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            p.wait()
+
+
+def launch_once(argv, n, timeout_s):
+    """N ranks of this script, one per GPU.  Returns (rank 0's last stdout line or None, outcome dict)."""
+    import tempfile
+
+    port = free_port()
+    procs, t0 = [], time.time()
+    out_file = tempfile.TemporaryFile()  # not a pipe: nobody has to drain it while the ranks run
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        env.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the control plane needs no resolvable hostname
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True,
+                                      stdout=out_file if r == 0 else subprocess.DEVNULL))
+    outcome = {"ranks_started": n, "rendezvous": f"127.0.0.1:{port}"}
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0, 3)]  # 3 = "ran, parity mismatch": every rank leaves with it
+        if bad:
+            why = f"rank {bad[0][0]} exited with code {bad[0][1]} while others were still running"
+            break
+        if time.time() - t0 > timeout_s:
+            why = f"deadline of {timeout_s:.0f} s passed (a hung collective or rendezvous)"
+            break
+        time.sleep(0.05)
+    if why:
+        log(f"bench.py launcher: {why}; ending the ranks of this attempt")
+        kill_ranks(procs)
+    out_file.seek(0)
+    out = out_file.read().decode(errors="replace")
+    out_file.close()
+    codes = [p.returncode for p in procs]
+    outcome.update({"exit_codes": codes, "seconds": round(time.time() - t0, 1), "failure": why})
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if not why and any(c not in (0, 3) for c in codes):
+        outcome["failure"] = f"exit codes {codes}"
+    return line, outcome
+
+
+def launcher(args, argv):
+    """Attempts in order: what was asked for; the torch.distributed table sum; replicas with no table sum at all.  The
+    first attempt whose ranks all exit 0 and whose rank 0 printed a line wins; its line goes out with `launcher` added.
+    If nothing works a line still goes out (value 0, the attempts' failures inside) and the exit code is 5."""
+    ladder = [[]]
+    if not args.torch_reduce and not args.no_collective:
+        ladder.append(["--torch-reduce"])
+    if not args.no_collective:
+        ladder.append(["--no-collective"])
+    attempts, deadline = [], args.launch_timeout
+    for extra in ladder:
+        line, outcome = launch_once(argv + extra, args.gpus, deadline)
+        outcome["extra_args"] = extra
+        attempts.append(outcome)
+        ok = line is not None and not outcome["failure"]
+        parity_exit = ok and 3 in outcome["exit_codes"]
+        if ok:
+            try:
+                res = json.loads(line)
+            except ValueError:
+                outcome["failure"] = "rank 0's line is not JSON"
+                continue
+            res["launcher"] = {"mode": "bench.py started its own ranks (subprocess per GPU, rendezvous on 127.0.0.1)",
+                               "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout}
+            print(json.dumps(res), flush=True)
+            return 3 if parity_exit else 0
+        deadline = max(120.0, args.launch_timeout / 2)  # the later rungs get less: the whole ladder stays bounded
+    print(json.dumps({
+        "metric": METRIC, "value": 0.0, "unit": "Gpix/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "error": "no attempt of the N-rank run completed; see launcher.attempts (rank logs are on stderr)",
+        "config": {"workload": "none completed"},
+        "launcher": {"mode": "bench.py started its own ranks", "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout},
+    }), flush=True)
+    return 5
+
+
+# =====================================================================================================================
+#  device plumbing: the real thing is torch.cuda + libscope_hip.so; `--backend emul` is the CPU emulation build of the
+#  same sources (tests/emul) so that the N-rank logic of this file can run without a GPU (tests/test_bench_launcher.py)
+# =====================================================================================================================
+class HostEvent:
+    def __init__(self):
+        self.t = 0.0
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class HostStream:
+    cuda_stream = None
+
+    def wait_event(self, ev):
+        pass
+
+
+class Dev:
+    def __init__(self, torch, args, local_rank):
+        self.torch, self.emul = torch, args.backend == "emul"
+        if self.emul:
+            self.device, self.index, self.shared = "cpu", 0, False
+            return
+        have = torch.cuda.device_count()
+        if have < 1:
+            raise RuntimeError("no HIP device is visible: the scope path has no CPU implementation (--backend emul is the "
+                               "test-only emulation build)")
+        if local_rank >= have and not args.oversubscribe:
+            raise RuntimeError(f"rank {local_rank} has no GPU of its own ({have} visible); --oversubscribe lets ranks share one")
+        self.index = local_rank % have
+        self.shared = int(os.environ.get("WORLD_SIZE", "1")) > have
+        self.device = "cuda"
+        torch.cuda.set_device(self.index)
+
+    def sync(self):
+        if not self.emul:
+            self.torch.cuda.synchronize()
+
+    def stream(self):
+        return HostStream() if self.emul else self.torch.cuda.Stream()
+
+    def event(self, timing=False):
+        return HostEvent() if self.emul else self.torch.cuda.Event(enable_timing=timing)
+
+    def empty_cache(self):
+        if not self.emul:
+            self.torch.cuda.empty_cache()
+
+
+class Ctl:
+    """Control plane of an N-rank run: barriers, agreement flags, max / sum over ranks -- gloo on CPU tensors, so that
+    nothing of it is ever queued on a GPU beside the data path's collectives."""
+
+    def __init__(self, torch, dist, world):
+        self.torch, self.dist, self.world = torch, dist, world
+
+    def _reduce(self, values, op, dtype):
+        if self.dist is None:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=dtype)
+        self.dist.all_reduce(t, op=op)
+        return t.tolist()
+
+    def barrier(self):
+        if self.dist is not None:
+            self._reduce([1], self.dist.ReduceOp.SUM, self.torch.int32)
+
+    def max(self, x):
+        return self._reduce([x], self.dist.ReduceOp.MAX if self.dist else None, self.torch.float64)[0]
+
+    def all_true(self, flag):
+        return bool(self._reduce([1 if flag else 0], self.dist.ReduceOp.MIN if self.dist else None, self.torch.int32)[0])
+
+    def any_true(self, flag):
+        return bool(self._reduce([1 if flag else 0], self.dist.ReduceOp.MAX if self.dist else None, self.torch.int32)[0])
+
+    def sum_array(self, arr):
+        """int64 numpy array summed over ranks (oracle tables of the ranks' tiles)."""
+        if self.dist is None:
+            return arr
+        t = self.torch.from_numpy(arr.copy())
+        self.dist.all_reduce(t)
+        return t.numpy()
+
+    def bcast(self, obj):
+        if self.dist is None:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+
 class Workload:
     """One scope workload over a pool of HBM-resident frames, `n` frames per step, rotating through the pool."""
 
     def __init__(self, torch, ctx, wl, rgb, yuv, w, h, n, components=0x07):
         self.torch, self.ctx, self.wl, self.w, self.h, self.n, self.comp = torch, ctx, wl, w, h, n, components
         pool = rgb.shape[0]
+        dev = rgb.device
         self.groups = pool // n
         src = yuv if wl == "vectorscope" else rgb
-        self.batches = [ctx.make_device_batch(src[g * n:(g + 1) * n], 4 * w, w, h, planes_are_rgb=(wl != "vectorscope"), colorspace=2)
+        self.linesize = int(src.shape[2])
+        self.batches = [ctx.make_device_batch(src[g * n:(g + 1) * n], self.linesize, w, h, planes_are_rgb=(wl != "vectorscope"), colorspace=2)
                         for g in range(self.groups)]
         self.tbytes = table_bytes_of(wl, w)
         if wl == "three_scope":
-            self.vss = [torch.empty((n, 65536), dtype=torch.uint8, device="cuda") for _ in range(2)]
-            self.wvs = [torch.empty((n, 256 * w * 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
-            self.his = [torch.empty((n, 1024), dtype=torch.int32, device="cuda") for _ in range(2)]
+            self.vss = [torch.empty((n, 65536), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.wvs = [torch.empty((n, 256 * w * 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.his = [torch.empty((n, 1024), dtype=torch.int32, device=dev) for _ in range(2)]
         else:
-            self.tables = [torch.empty((n, self.tbytes), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            self.tables = [torch.empty((n, self.tbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.last = (0, 0)
         # SURVEY.md 8(d): 4 B per pixel read once + the tables once per frame
         self.algo_bytes = n * (4 * w * h + self.tbytes)
@@ -103,7 +330,6 @@ class Workload:
         elif wl == "histogram":
             ctx.histogram_counts_batch_dev(b, self.comp, self.tables[buf], sync=False)
         else:
-            # one C-ABI call: small launches read the planes once (scope_dock_kernel), batches take two passes
             ctx.three_scopes_batch_dev(b, self.comp, self.comp, self.vss[buf], self.wvs[buf], self.his[buf], sync=False)
         self.last = (i % self.groups, buf)
 
@@ -126,47 +352,38 @@ class Workload:
         return ok
 
 
-def agree(torch, dist, keep_going):
-    """Loops that run 'for so many seconds' must run the SAME number of steps on every rank -- a step holds a collective, and
-    a rank that enqueues one more than its peers waits for ever.  So the clock of no single rank decides: the loop goes on
-    while ANY rank wants to (one tiny all-reduce per chunk of steps, which also drains the stream)."""
-    if dist is None:
-        return keep_going
-    # nothing of the data path -- which has a communicator of its own, on a stream of its own -- is in flight while
-    # torch.distributed's communicator runs: two communicators never have collectives queued at the same time
-    torch.cuda.synchronize()
-    t = torch.tensor([1 if keep_going else 0], dtype=torch.int32, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return bool(t.item())
+def timed_run(dev, ctl, ctx, stream, step, steps, warmup, settle_s, min_s, multi=False):
+    """settle -> warm-up -> EXACTLY `steps` steps between barrier + synchronize -> at least min_s more of the same ->
+    a short leg with the accumulation kernel bracketed by its own begin/end stamps.
+    Loops that run 'for so many seconds' run the SAME number of steps on every rank (a step may hold a collective, and a
+    rank that enqueues one more than its peers waits for ever): no single rank's clock decides, the loop goes on while
+    ANY rank wants to.  Returns (elapsed of the K steps, sustained dict, bracketed launches, their summed ms)."""
+    def go_on(flag):
+        if not multi:
+            return flag
+        dev.sync()
+        return ctl.any_true(flag)
 
-
-def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=None):
-    """settle -> warm-up -> EXACTLY `steps` steps between (barrier +) synchronize -> at least min_s more of the same ->
-    a short leg with the accumulation kernel bracketed by HIP events (the bracket costs a few microseconds of stream time
-    per launch -- a quarter of a one-frame step -- so it stays out of the two timed legs).
-    Returns (elapsed of the K steps, sustained dict, bracketed kernel launches, their summed ms)."""
     t_end = time.perf_counter() + settle_s
     i = 0
-    while agree(torch, dist, time.perf_counter() < t_end):
+    while go_on(time.perf_counter() < t_end):
         for _ in range(8):
             step(i)
             i += 1
-        torch.cuda.synchronize()
+        dev.sync()
     for j in range(warmup):
         step(j)
-    torch.cuda.synchronize()  # the data path's own communicator is idle before torch.distributed's barrier runs
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    dev.sync()
+    ctl.barrier()
+    dev.sync()
     t0 = time.perf_counter()
     for j in range(steps):
         step(j)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    dev.sync()
+    ctl.barrier()
     elapsed = time.perf_counter() - t0
     # the sustained leg: the same step for >= min_s; the host only enqueues (its own pace is reported beside the GPU's)
-    s_steps, e0, e1 = 0, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s_steps, e0, e1 = 0, dev.event(True), dev.event(True)
     chunk = max(8, steps)
     t1 = time.perf_counter()
     e0.record(stream)
@@ -174,31 +391,30 @@ def timed_run(torch, ctx, stream, step, steps, warmup, settle_s, min_s, dist=Non
         for j in range(chunk):
             step(s_steps + j)
         s_steps += chunk
-        if not agree(torch, dist, time.perf_counter() - t1 < min_s):
+        if not go_on(time.perf_counter() - t1 < min_s):
             break
     host_s = time.perf_counter() - t1
     e1.record(stream)
-    torch.cuda.synchronize()
+    dev.sync()
     sustained = {"seconds": round(time.perf_counter() - t1, 3), "steps": s_steps,
                  "ms_per_step": round(e0.elapsed_time(e1) / s_steps, 5),
                  "host_enqueue_ms_per_step": round(host_s / s_steps * 1e3, 5)}
     ctx.profile(True)
-    for j in range(min(400, max(60, steps))):
+    for j in range(min(400, max(60, steps)) if not dev.emul else 2):
         step(j)
-    torch.cuda.synchronize()
+    dev.sync()
     launches, kernel_ms = ctx.kernel_ms()
     ctx.profile(False)
     return elapsed, sustained, launches, kernel_ms
 
 
-def place_pool(torch, ctx, frames, probe, candidates, good_us=0.0):
+def place_pool(dev, ctx, frames, probe, candidates, good_us=0.0):
     """WHERE a frame pool lies in HBM decides a few per cent of every streaming kernel's rate, and the first pools a
-    process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt: 6300-6490 GB/s for the first
-    against 6800-6860 for the ten that follow, same frames, same kernel, same process).  A host that
-    keeps a long-lived pool can afford to look: allocate `candidates` copies, time the accumulation kernel on each
-    (its own begin/end stamps), keep the fastest and give the rest back; when none of them is as fast as `good_us` (what a
-    well-placed pool reads in), up to as many again are tried.  Untimed set-up, rank-local, no collective.
-    Returns (the pool to use, kernel microseconds per candidate, index kept)."""
+    process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt).  A host
+    that keeps a long-lived pool can afford to look: allocate `candidates` copies, time the accumulation kernel on each
+    (its own begin/end stamps), keep the fastest and give the rest back; when none of them is as fast as `good_us`, up
+    to as many again are tried.  Untimed set-up, rank-local, no collective.  (The C-ABI offers the same to any host:
+    scope_frame_pool_alloc.)  Returns (the pool to use, kernel microseconds per candidate, index kept)."""
     pools, us = [frames], []
     k = 0
     while k < candidates or (good_us and k < 2 * candidates and min(us) > good_us):
@@ -219,7 +435,7 @@ def place_pool(torch, ctx, frames, probe, candidates, good_us=0.0):
     best = min(range(len(us)), key=lambda i: us[i])
     keep = pools[best]
     del pools
-    torch.cuda.empty_cache()
+    dev.empty_cache()
     return keep, us, best
 
 
@@ -229,13 +445,14 @@ class Overlap:
     that will overwrite the buffer (two steps later) until the sum has left it.  Nothing is skipped, bucketed or deferred
     beyond the timed region: the closing synchronize waits for both streams."""
 
-    def __init__(self, torch, ocm, device, compute_stream):
-        self.torch, self.compute = torch, compute_stream
-        self.stream = torch.cuda.Stream()
-        self.ctx = ocm.ScopeContext(device)
-        self.ctx.set_stream(self.stream.cuda_stream)
-        self.filled = [torch.cuda.Event() for _ in range(2)]
-        self.summed = [torch.cuda.Event() for _ in range(2)]
+    def __init__(self, dev, ocm, lib_path, compute_stream):
+        self.compute = compute_stream
+        self.stream = dev.stream()
+        self.ctx = ocm.ScopeContext(dev.index, lib_path)
+        if not dev.emul:
+            self.ctx.set_stream(self.stream.cuda_stream)
+        self.filled = [dev.event() for _ in range(2)]
+        self.summed = [dev.event() for _ in range(2)]
         self.used = [False, False]
 
     def before_compute(self, buf):
@@ -253,7 +470,7 @@ class Overlap:
 
 def roofline(wl, algo_bytes, launches, kernel_ms, ms_per_step, traffic):
     kern_avg_ms = kernel_ms / launches if launches else float("nan")
-    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches else float("nan")
+    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches and kern_avg_ms > 0 else float("nan")
     return {
         "bound": "hbm",
         "kernel": KERNEL[wl],
@@ -262,7 +479,7 @@ def roofline(wl, algo_bytes, launches, kernel_ms, ms_per_step, traffic):
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4),
         # the whole step (every kernel of the call + launch gaps) on the same scale: what the host sees
-        "frac_whole_step": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "frac_whole_step": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_per_step > 0 else None,
         "traffic": traffic,
         "algorithmic_bytes_per_launch": algo_bytes,
         "avg_launch_ms": round(kern_avg_ms, 5),
@@ -292,11 +509,16 @@ def pmc_traffic(wl, n, w, h, plain):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), measured with
     rocprofv3 on this exact workload by tools/gpu_job.sh and committed with the fingerprint of the kernel sources.
     bench.py cannot run under a counter pass itself; a file measured on OTHER kernel sources is refused, loudly."""
-    path = os.path.join(PROFILE_DIR, "pmc_traffic.json")
-    try:
-        pmc = json.load(open(path))
-    except (OSError, ValueError):
-        return None, "no profiles/round2/pmc_traffic.json"
+    pmc, path = None, None
+    for d in PROFILE_DIRS:
+        path = os.path.join(d, "pmc_traffic.json")
+        try:
+            pmc = json.load(open(path))
+            break
+        except (OSError, ValueError):
+            continue
+    if pmc is None:
+        return None, "no profiles/round*/pmc_traffic.json"
     if pmc.get("kernel_sources_sha256_16") != kernel_fingerprint():
         log(f"bench.py: {path} was measured on other kernel sources ({pmc.get('kernel_sources_sha256_16')} != "
             f"{kernel_fingerprint()}): roofline.traffic is null until tools/gpu_job.sh traffic is re-run")
@@ -309,7 +531,7 @@ def pmc_traffic(wl, n, w, h, plain):
     return None, "not measured for this workload"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -321,6 +543,7 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="distinct HBM-resident frames rotated through (default: max(frames, 24) for small launches)")
     ap.add_argument("--size", default="4k", choices=["4k", "8k"],
                     help="frame size: 3840x2160 (the metric's configuration) or 7680x4320 (BASELINE config 4's frame)")
+    ap.add_argument("--geometry", default="", help="WxH instead of --size (emulation runs and experiments; not the metric's configuration)")
     ap.add_argument("--workload", default="vectorscope",
                     choices=["vectorscope", "vectorscope_rgb", "waveform", "histogram", "three_scope", "stream"])
     ap.add_argument("--components", type=lambda s: int(s, 0), default=0x07)
@@ -329,25 +552,58 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "concentrated", "flat", "ramp", "natural", "screen"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="headline only: no variants / latency / stream / config4 legs")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no variants / distributions / latency / stream / config1 / config4 legs")
+    ap.add_argument("--config4-frames", type=int, default=16, help="7680x4320 frames in BASELINE config 4's one batch")
+    ap.add_argument("--config4-geometry", default="7680x4320")
     ap.add_argument("--strong", action="store_true",
-                    help="N > 1: make BASELINE config 4 (one 7680x4320 batch, row tiles, strong scaling) the headline")
+                    help="make BASELINE config 4 (one 7680x4320 batch, row tiles, strong scaling) the headline")
     ap.add_argument("--force-reduce", action="store_true",
                     help="run the RCCL table reduction even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--serial-reduce", action="store_true",
-                    help="N > 1: enqueue the RCCL table sum on the accumulation's own stream (round 2's first form) instead of "
-                         "overlapping step i's sum with step i+1's accumulation on a second stream")
+                    help="enqueue the RCCL table sum on the accumulation's own stream instead of overlapping step i's sum with "
+                         "step i+1's accumulation on a second stream")
     ap.add_argument("--torch-reduce", action="store_true", help="N > 1: sum the tables with torch.distributed (TableAllReduce) "
                     "instead of the C-ABI's scope_table_allreduce")
+    ap.add_argument("--no-collective", action="store_true",
+                    help="N > 1: independent replicas, NO table sum (the launcher's last resort; every field says so)")
+    ap.add_argument("--launch-timeout", type=float, default=480.0, help="self-launched ranks: seconds before an attempt is given up")
+    ap.add_argument("--rank-timeout", type=float, default=0.0,
+                    help="seconds after which a rank dumps its stacks and exits (default: the launcher's deadline minus 15 s, or none)")
+    ap.add_argument("--backend", default="hip", choices=["hip", "emul"],
+                    help="emul = tests/emul/libscope_emul.so on CPU tensors with gloo: exercises this file's N-rank logic without a GPU "
+                         "(tests only; its numbers mean nothing)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="let ranks share a GPU when there are fewer GPUs than ranks (the table sum then needs SCOPE_RCCL_LIBRARY "
+                         "= tools/libshm_rccl_hip.so or --torch-reduce over gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launcher(args, sys.argv[1:]))
+    run_rank(args)
+
+
+def run_rank(args):
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C
-    # stdio when a process group exists), so everything else in this process goes to stderr: file descriptor 1 is
+    # stdio when a communicator exists), so everything else in this process goes to stderr: file descriptor 1 is
     # pointed at stderr for the run and the JSON line is written to the saved, real stdout at the end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the environment decides, this process is rank {rank} of {world}")
+    rank_timeout = args.rank_timeout or (args.launch_timeout - 15 if os.environ.get("BENCH_SELF_LAUNCHED") else 0)
+    if rank_timeout > 0:
+        # a rank that is stuck (a collective its peers never entered) says where and leaves: the launcher, or
+        # torch.distributed.run, then ends the others instead of the whole job hanging silently
+        faulthandler.dump_traceback_later(rank_timeout, exit=True)
 
     import numpy as np
     import torch
@@ -355,36 +611,40 @@ def main():
 
     import obs_color_monitor_amd as ocm
     import scope_oracle
-    from obs_color_monitor_amd.synth import make_frames
+    from obs_color_monitor_amd.synth import make_frames, pad_pitch, punch_alpha_holes
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or args.force_reduce
-    if use_dist:
+    dev = Dev(torch, args, local_rank)
+    lib_path = os.path.join(ROOT, "tests", "emul", "libscope_emul.so") if dev.emul else None
+    if dev.emul:
+        os.environ.setdefault("SCOPE_RCCL_LIBRARY", os.path.join(ROOT, "tests", "emul", "libshm_rccl_emul.so"))
+    multi = world > 1
+    use_dist = multi or args.force_reduce
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo")  # control plane only (class Ctl)
+    ctl = Ctl(torch, dist if multi else None, world)
+    data_group = None
+    if multi and args.torch_reduce and not dev.emul and not dev.shared:
+        data_group = dist.new_group(backend="nccl")  # RCCL through c10d, for TableAllReduce
 
-    ctx = ocm.ScopeContext(local_rank)  # raises without libscope_hip.so / a GPU: no fallback
+    ctx = ocm.ScopeContext(dev.index, lib_path)  # raises without the library / a GPU: no fallback
     # one explicit (non-default) stream for torch AND the C-ABI: generation, kernels, RCCL and the HIP
     # events that time the kernels are all ordered on it (a NULL handle would mean "ctx's own stream")
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
+    stream = dev.stream()
+    if not dev.emul:
+        torch.cuda.set_stream(stream)
+        ctx.set_stream(stream.cuda_stream)
     for kv in args.option:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
     info = ctx.device_info()
     o = scope_oracle.COracle()
-    plain = not args.option and args.dist == "uniform" and args.components == 0x07
+    plain = not args.option and args.dist == "uniform" and args.components == 0x07 and not args.geometry
 
     if args.workload == "stream":
-        from obs_color_monitor_amd.stream import stream_leg
+        from bench_stream import stream_leg
 
         res = stream_leg(torch, np, ctx, o, seconds=max(2.0, args.min_seconds), dist_kind="natural" if args.dist == "uniform" else args.dist)
         flat = res["flat_out"]
@@ -403,16 +663,19 @@ def main():
         sys.exit(0 if res["parity"].startswith("bit-exact") else 3)
 
     # ---- synthetic input, resident in HBM ------------------------------------------------------
-    w, h = (W4K, H4K) if args.size == "4k" else (2 * W4K, 2 * H4K)
-    n = args.frames or (64 if args.size == "4k" else 16)
+    if args.geometry:
+        w, h = (int(v) for v in args.geometry.lower().split("x"))
+    else:
+        w, h = (W4K, H4K) if args.size == "4k" else (2 * W4K, 2 * H4K)
+    n = args.frames or (64 if w * h <= W4K * H4K else 16)
     pool = args.pool or (n if n >= 24 else (24 // n) * n)  # small launches rotate over >= 24 frames (0.8 GB > the Infinity Cache)
     wl = args.workload
-    rgb, yuv = make_frames(torch, ctx, pool, w, h, args.dist, 0x9E3779B9 + rank)
-    torch.cuda.synchronize()
+    rgb, yuv = make_frames(torch, ctx, pool, w, h, args.dist, 0x9E3779B9 + rank, device=dev.device)
+    dev.sync()
     placement = None
-    if args.placement_candidates > 1:
+    if args.placement_candidates > 1 and not dev.emul:
         pn = min(pool, 64)  # the probe reads the whole pool (one launch takes at most 64 frames)
-        ptab = torch.empty((pn, 65536), dtype=torch.uint8, device="cuda")
+        ptab = torch.empty((pn, 65536), dtype=torch.uint8, device=dev.device)
 
         def probe_yuv(t):
             b = ctx.make_device_batch(t[:pn], 4 * w, w, h, planes_are_rgb=False)
@@ -425,52 +688,50 @@ def main():
         # "as fast as a well-placed pool": 0.84 of the HBM peak for the probe's bytes (the kernels reach 0.85 there)
         # (full-size launches of the headline's kernel only: a probe of fewer than 64 frames does not reach that rate anywhere)
         good = (pn * (4 * w * h + 65536) / (0.84 * HBM_PEAK_GBPS * 1e9) * 1e6) if pn == 64 else 0.0
-        yuv, us_y, ky = place_pool(torch, ctx, yuv, probe_yuv, args.placement_candidates, good)
-        rgb, us_r, kr = place_pool(torch, ctx, rgb, probe_rgb, args.placement_candidates)
+        yuv, us_y, ky = place_pool(dev, ctx, yuv, probe_yuv, args.placement_candidates, good)
+        rgb, us_r, kr = place_pool(dev, ctx, rgb, probe_rgb, args.placement_candidates)
         placement = {"candidates": args.placement_candidates,
                      "yuv_pool_vectorscope_kernel_us": us_y, "yuv_pool_kept": ky,
                      "rgb_pool_histogram_kernel_us": us_r, "rgb_pool_kept": kr,
+                     "first_allocation_frac": round(pn * (4 * w * h + 65536) / (us_y[0] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                      "what": "copies of the frame pool allocated one after the other, the accumulation kernel timed on each "
                              "(own begin/end stamps), the fastest kept, the others freed; as many again when none reads at 0.84 of "
                              "peak: untimed set-up (DESIGN.md section 5)"}
         del ptab
     work = Workload(torch, ctx, wl, rgb, yuv, w, h, n, args.components)
     table_bytes = work.tbytes
+    frame0 = (rgb[0].cpu().numpy(), yuv[0].cpu().numpy())  # the CPU baseline's sample
 
     # ---- N > 1: the table sum over RCCL -----------------------------------------------------------------------------
-    reducer, comm, reduce_path, overlap = None, None, None, None
+    reducer, comm, reduce_path, overlap, rccl_info = None, None, None, None, None
     wire = None
-    if use_dist and wl in ("vectorscope", "vectorscope_rgb", "histogram"):
+    sums_tables = wl in ("vectorscope", "vectorscope_rgb", "histogram")
+    if use_dist and args.no_collective:
+        reduce_path = ("NONE: independent replicas, no table sum (--no-collective; as the launcher's last resort this means the "
+                       "collective paths failed or hung: see launcher.attempts)")
+    elif use_dist and sums_tables:
         if not args.torch_reduce:
-            try:  # every rank must agree on the path: the verdict is all-reduced before anybody uses it
-                uid = [ctx.rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                comm = ctx.rccl_comm_create(uid[0], world, rank)
-                ok = 1
-            except Exception as e:  # noqa: BLE001
-                log(f"rank {rank}: scope_rccl_comm_create failed ({e}); falling back to torch.distributed")
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if not int(flag.item()):
-                if comm:
-                    ctx.rccl_comm_destroy(comm)
-                comm = None
+            comm, why = make_comm(ctx, ctl, world, rank)
+            if comm is None:
+                log(f"rank {rank}: no C-ABI communicator ({why}); every rank falls back to torch.distributed together")
         if comm:
-            wire = [torch.empty((n, 32768 if wl != "histogram" else 1024), dtype=torch.int32, device="cuda") for _ in range(2)]
+            rccl_info = ctx.rccl_comm_info(comm)
+            wire = [torch.empty((n, 32768 if wl != "histogram" else 1024), dtype=torch.int32, device=dev.device) for _ in range(2)]
             if args.serial_reduce:
                 reduce_path = "C-ABI: scope_table_allreduce (ncclAllReduce uint32 sum) every step, unpack/clamp on the same stream"
-                overlap = None
             else:
                 reduce_path = ("C-ABI: scope_table_allreduce (ncclAllReduce uint32 sum) + unpack/clamp of EVERY step on a second "
                                "hipStream: step i's table sum runs under step i+1's accumulation (two table buffers)")
-                overlap = Overlap(torch, ocm, local_rank, stream)
-        else:
+                overlap = Overlap(dev, ocm, lib_path, stream)
+        elif multi:
             from obs_color_monitor_amd.row_tiles import TableAllReduce
 
             # one collective per 8 steps: c10d's per-collective host cost is about a step's GPU time
-            reducer = TableAllReduce(ctx, n * table_bytes, "cuda", "sum_u32" if wl == "histogram" else "sat_u8", bucket=8)
-            reduce_path = "torch.distributed: TableAllReduce, 8 steps per collective, side stream"
+            reducer = TableAllReduce(ctx, n * table_bytes, dev.device, "sum_u32" if wl == "histogram" else "sat_u8", bucket=8, group=data_group)
+            reduce_path = ("torch.distributed (" + ("nccl = RCCL" if data_group is not None else "gloo") +
+                           "): TableAllReduce, 8 steps per collective, side stream")
+        else:
+            reduce_path = "NONE: --force-reduce with one rank needs the C-ABI communicator, which could not be made"
     result_tables = [None]
 
     def step(i):
@@ -510,21 +771,12 @@ def main():
             return
         work.step(i)
 
-    def drain():
-        if reducer is not None:
-            result_tables[0] = reducer.drain()
-
-    def step_and_drain(i):
-        step(i)
-
-    elapsed, sustained, launches, kernel_ms = timed_run(torch, ctx, stream, step_and_drain, args.steps, args.warmup,
-                                                        args.settle_seconds, args.min_seconds, dist if use_dist else None)
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, sustained, launches, kernel_ms = timed_run(dev, ctl, ctx, stream, step, args.steps, args.warmup,
+                                                        args.settle_seconds, args.min_seconds, multi)
+    if reducer is not None:
+        result_tables[0] = reducer.drain()
+    dev.sync()
+    elapsed = ctl.max(elapsed)
 
     # ---- parity of what was just computed (untimed) ---------------------------------------------
     if comm or reducer is not None:
@@ -535,25 +787,17 @@ def main():
         for f in sorted({0, n - 1}):
             pr, py = rgb[g * n + f].cpu().numpy(), yuv[g * n + f].cpu().numpy()
             if wl == "histogram":
-                mine = o.histogram_counts(pr, py, w, args.components).astype(np.int64)
+                want = ctl.sum_array(o.histogram_counts(pr, py, w, args.components).astype(np.int64).reshape(-1))
+                got = final[f].cpu().numpy().view(np.uint32).astype(np.int64)
             else:
-                mine = o.vectorscope(py, w).astype(np.int64)
-            want = torch.from_numpy(mine.reshape(-1)).cuda()
-            dist.all_reduce(want)
-            if wl == "histogram":
-                got = final[f].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-            else:
-                want = want.clamp(max=255)
-                got = final[f].to(torch.int64)
-            parity = parity and bool(torch.equal(got, want))
+                want = np.minimum(ctl.sum_array(o.vectorscope(py, w).astype(np.int64).reshape(-1)), 255)
+                got = final[f].cpu().numpy().astype(np.int64)
+            parity = parity and bool(np.array_equal(got, want))
     else:
         work.step(args.steps - 1)
-        torch.cuda.synchronize()
+        dev.sync()
         parity = work.check(o, rgb, yuv, np)
-    if use_dist:  # the line rank 0 prints speaks for every rank
-        okf = torch.tensor([1 if parity else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-        parity = bool(okf.item())
+    parity = ctl.all_true(parity)  # the line rank 0 prints speaks for every rank
 
     # ---- the numbers ------------------------------------------------------------------------------
     pix_per_step = world * n * w * h
@@ -562,9 +806,18 @@ def main():
     traffic, traffic_src = pmc_traffic(wl, n, w, h, plain and world == 1)
     rf = roofline(wl, work.algo_bytes, launches, kernel_ms, ms_per_step, traffic)
     rf["traffic_source"] = traffic_src
-    sustained["value"] = round(pix_per_step / (sustained["ms_per_step"] * 1e-3) / 1e9, 3)
+    if placement:
+        # beside the placed pool's figure: the same kernel on the pool as the process first allocated it
+        rf["frac_first_allocation"] = placement["first_allocation_frac"]
+    sustained["value"] = round(pix_per_step / (sustained["ms_per_step"] * 1e-3) / 1e9, 3) if sustained["ms_per_step"] > 0 else None
+    if world == 1:
+        partition = "one frame batch per GPU"
+    elif args.no_collective:
+        partition = f"{world} independent replicas of one {w}x{h} batch each: NO table sum"
+    else:
+        partition = f"{world} row tiles of {w}x{h} + sum of the ranks' tables"
     result = {
-        "metric": "Gpix/s scope accumulation @3840×2160; achieved HBM GB/s vs peak",
+        "metric": METRIC,
         "value": round(value, 3),
         "unit": "Gpix/s",
         "n_gpus": world,
@@ -576,8 +829,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u8" if wl != "histogram" else "u32",
         "data": "synthetic",
-        "parity": ("bit-exact vs oracle" if parity else "MISMATCH vs oracle") + " (parity unpinned: the oracle is this build's "
-                  "restatement of the reference loops, DESIGN.md section 4)",
+        "parity": ("bit-exact vs oracle" if parity else "MISMATCH vs oracle") + UNPINNED,
         "config": {
             "workload": WORKLOAD_TEXT[wl] + (f", components {args.components:#04x}" if wl in ("waveform", "histogram", "three_scope") else "")
                         + f", {w}x{h} BGRA8, {n} frame(s) per launch from {pool} distinct HBM-resident frames, {args.dist} RGB through K0",
@@ -586,9 +838,16 @@ def main():
             "width": w,
             "height": h,
             "input_distribution": args.dist,
-            "partition": "one frame batch per GPU" if world == 1 else f"{world} row tiles of {w}x{h} + RCCL sum of tables",
+            "partition": partition,
             "frame_pool_placement": placement,
             "reduce": reduce_path,
+            "rccl": None if rccl_info is None else {
+                "ranks_in_communicator": rccl_info["ranks"], "rank": rccl_info["rank"], "version": rccl_info["version"],
+                "library": os.environ.get("SCOPE_RCCL_LIBRARY") or "librccl (dlopen by libscope_hip.so)",
+                "what": "ncclCommCount / ncclCommUserRank / ncclGetVersion of the data path's communicator (scope_rccl_comm_info)"},
+            "launch": "self-launched rank" if os.environ.get("BENCH_SELF_LAUNCHED") else ("torch.distributed.run rank" if multi else "single process"),
+            "backend": "libscope_hip.so on " + info["name"] if not dev.emul else "EMULATION (tests/emul, CPU): numbers are meaningless",
+            "gpu_shared_by_ranks": bool(dev.shared),
             "device": info["name"],
             "compute_units": info["compute_units"],
             "options": args.option,
@@ -598,36 +857,28 @@ def main():
         "sustained": sustained,
     }
 
-    # ---- the other legs (rank 0 of a one-GPU run; short, >= 0.5 s each) ---------------------------------------------
-    extras = not args.no_extras and w == W4K
+    # ---- the other legs (one-GPU run; short, >= 0.5 s each) ---------------------------------------------------------
+    extras = not args.no_extras and (w, h) == (W4K, H4K) and not dev.emul
     if extras and world == 1 and not use_dist:
         del work
+        legs = Legs(dev, ctl, ctx, stream, o, np, torch, w, h, n)
         variants = {}
-        for v in ("vectorscope_rgb", "waveform", "histogram", "three_scope"):
+        for v, comp in (("vectorscope_rgb", 0x07), ("waveform", 0x07), ("waveform_y", 0x20), ("waveform_r", 0x04),
+                        ("waveform_g", 0x02), ("waveform_b", 0x01), ("histogram", 0x07), ("three_scope", 0x07)):
+            base = v.split("_")[0] if v.startswith("waveform") else v
             if v == wl:
                 continue
-            vw = Workload(torch, ctx, v, rgb, yuv, w, h, n, 0x07)
-            steps_v = max(4, min(args.steps, 40))
-            el, sus, ln, kms = timed_run(torch, ctx, stream, vw.step, steps_v, 3, 0.2, 0.5)
-            ok = vw.check(o, rgb, yuv, np, frames=[0])
-            tr, _ = pmc_traffic(v, n, w, h, True)
-            vr = roofline(v, vw.algo_bytes, ln, kms, sus["ms_per_step"], tr)
-            if v == "three_scope":  # two accumulation kernels per step: the event average is per kernel, the step has both
-                vr["achieved"] = round(vw.algo_bytes / (sus["ms_per_step"] * 1e-3) / 1e9, 1)
-                vr["frac"] = vr["frac_whole_step"]
-                vr["note"] = "achieved = SURVEY 8(d) config-5 bytes (one read of the frames + the three tables) / whole step"
-            variants[v] = {"value": round(n * w * h / (sus["ms_per_step"] * 1e-3) / 1e9, 3), "unit": "Gpix/s",
-                           "ms_per_step": sus["ms_per_step"], "steps": sus["steps"], "parity": bool(ok), "roofline": vr}
-            del vw
+            variants[v] = legs.variant(base, rgb, yuv, comp, steps=max(4, min(args.steps, 40)),
+                                       seconds=0.5 if v in ("vectorscope_rgb", "waveform", "histogram", "three_scope") else 0.3)
         result["variants"] = variants
         # the reference's call shape: one surface per callback, ring of three
         latency = {}
         for nf in (1, 3):
             for v in ("vectorscope", "vectorscope_rgb", "histogram", "waveform", "three_scope"):
                 lw = Workload(torch, ctx, v, rgb[:24], yuv[:24], w, h, nf, 0x07)
-                el, sus, ln, kms = timed_run(torch, ctx, stream, lw.step, 200, 50, 0.15, 0.3)
+                el, sus, ln, kms = timed_run(dev, ctl, ctx, stream, lw.step, 200, 50, 0.15, 0.3)
                 lw.step(0)
-                torch.cuda.synchronize()
+                dev.sync()
                 ok = lw.check(o, rgb, yuv, np, frames=[nf - 1])
                 us = sus["ms_per_step"] * 1e3
                 latency[f"{v}_x{nf}"] = {
@@ -639,19 +890,48 @@ def main():
         latency["note"] = ("us_per_call = stream time per call in steady state, calls back to back on one stream over 24 rotating "
                            "frames: every kernel of the call (accumulation + partial-table reduction) and the gaps between them, no "
                            "event brackets in between; us_accumulation_kernel comes from a separate bracketed leg and carries "
-                           "~2-3 us of event overhead at this scale (rocprofv3 --stats of the same launches: profiles/round2/)")
+                           "~2-3 us of event overhead at this scale (rocprofv3 --stats of the same launches: profiles/)")
         result["latency"] = latency
         try:
-            from obs_color_monitor_amd.stream import stream_leg
+            result["distributions"] = legs.distributions(make_frames, pad_pitch, punch_alpha_holes, rgb, yuv)
+        except Exception as e:  # noqa: BLE001
+            result["distributions"] = {"error": repr(e)}
+        try:
+            result["config1"] = config1_leg(np, ctx, o)
+        except Exception as e:  # noqa: BLE001
+            result["config1"] = {"error": repr(e)}
+        try:
+            from bench_stream import stream_leg
 
             result["stream"] = stream_leg(torch, np, ctx, o, seconds=1.5, dist_kind="natural")
         except Exception as e:  # noqa: BLE001
             result["stream"] = {"error": repr(e)}
 
-    # ---- BASELINE config 4 as written: one 7680x4320 batch in N row tiles, strong scaling ---------------------------
-    if (extras or args.strong) and use_dist and comm and wl in ("vectorscope", "vectorscope_rgb"):
+    # ---- BASELINE config 4 as written: one 7680x4320 batch in N row tiles, strong scaling, at every N ---------------
+    c4_wanted = (not args.no_extras and (w, h) == (W4K, H4K)) or args.strong
+    if c4_wanted and wl in ("vectorscope", "vectorscope_rgb") and not args.no_collective:
         try:
-            result["config4"] = config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream, overlap=overlap)
+            del rgb, yuv
+            dev.empty_cache()
+            c4_comm, c4_overlap = comm, overlap
+            if c4_comm is None and not args.torch_reduce:
+                c4_comm, why = make_comm(ctx, ctl, world, rank)
+                if c4_comm is None:
+                    raise RuntimeError(f"no C-ABI communicator for the config-4 leg: {why}")
+            if c4_comm is None:
+                raise RuntimeError("the config-4 leg sums through the C-ABI; this run was asked for --torch-reduce")
+            if c4_overlap is None and not args.serial_reduce:
+                c4_overlap = Overlap(dev, ocm, lib_path, stream)
+            c4w, c4h = (int(v) for v in args.config4_geometry.lower().split("x"))
+            result["config4"] = config4_leg(dev, ctl, torch, np, ctx, o, c4_comm, rank, world, c4w, c4h,
+                                            frames=args.config4_frames, overlap=c4_overlap,
+                                            seconds=0.6 if not dev.emul else 0.0)
+            result["config4"]["rccl_ranks_in_communicator"] = ctx.rccl_comm_info(c4_comm)["ranks"]
+            if c4_comm is not comm:
+                dev.sync()
+                ctx.rccl_comm_destroy(c4_comm)
+            if c4_overlap is not None and c4_overlap is not overlap:
+                c4_overlap.ctx.close()
         except Exception as e:  # noqa: BLE001
             result["config4"] = {"error": repr(e)}
         if args.strong and "error" not in result["config4"]:
@@ -661,122 +941,242 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference loop) on this host, bounded sample --------
     if rank == 0 and world == 1 and not args.no_cpu:
-        result["cpu_baseline"] = cpu_baseline(np, o, "vectorscope" if wl == "three_scope" else wl, rgb[0].cpu().numpy(),
-                                              yuv[0].cpu().numpy(), w, h, args.components, args.cpu_seconds)
+        result["cpu_baseline"] = cpu_baseline(np, o, "vectorscope" if wl == "three_scope" else wl, frame0[0], frame0[1],
+                                              w, h, args.components, args.cpu_seconds)
 
+    faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if comm:
-        torch.cuda.synchronize()
+        dev.sync()
         ctx.rccl_comm_destroy(comm)
     if overlap:
         overlap.ctx.close()
     ctx.close()
-    if use_dist:
+    if multi:
+        ctl.barrier()
         dist.destroy_process_group()
     if not parity:
         sys.exit(3)
 
 
-def config4_leg(torch, dist, np, ctx, o, comm, rank, world, stream, frames=16, seconds=0.6, overlap=None):
-    """ONE batch of 7680x4320 frames; rank r owns rows [4320 r/N, 4320 (r+1)/N) of every frame; per step every rank
-    reduces its tiles, the packed tables are summed over RCCL and clamped.  Two figures: throughput with the steps
-    enqueued back to back, and the latency of one step with its reduce waited for (nothing bucketed or deferred)."""
-    from obs_color_monitor_amd.row_tiles import tile_rows
-    from obs_color_monitor_amd.synth import make_frames
+def make_comm(ctx, ctl, world, rank):
+    """A communicator for the C-ABI's table sum: rank 0's unique id travels over the control plane, every rank creates
+    its end, and the verdict is agreed on (all ranks use it or none does).  Returns (comm or None, reason)."""
+    uid, comm, why = None, None, ""
+    if rank == 0:
+        try:
+            uid = ctx.rccl_unique_id()
+        except Exception as e:  # noqa: BLE001
+            why = repr(e)
+    uid = ctl.bcast(uid)  # every rank takes part in every control-plane collective, whatever failed before it
+    if uid is not None:
+        try:
+            comm = ctx.rccl_comm_create(uid, world, rank)
+        except Exception as e:  # noqa: BLE001
+            why = repr(e)
+    else:
+        why = why or "rank 0 could not make a unique id (no collective library)"
+    if not ctl.all_true(comm is not None):
+        if comm:
+            ctx.rccl_comm_destroy(comm)
+        return None, why or "a peer could not create its end"
+    return comm, ""
 
-    w, h = 7680, 4320
+
+class Legs:
+    """The short legs of the default one-GPU run that share the headline's frame geometry."""
+
+    def __init__(self, dev, ctl, ctx, stream, o, np, torch, w, h, n):
+        self.dev, self.ctl, self.ctx, self.stream, self.o, self.np, self.torch = dev, ctl, ctx, stream, o, np, torch
+        self.w, self.h, self.n = w, h, n
+
+    def variant(self, wl, rgb, yuv, comp, steps=20, seconds=0.5, check=True):
+        torch, np = self.torch, self.np
+        vw = Workload(torch, self.ctx, wl, rgb, yuv, self.w, self.h, self.n, comp)
+        el, sus, ln, kms = timed_run(self.dev, self.ctl, self.ctx, self.stream, vw.step, steps, 3, 0.2, seconds)
+        ok = vw.check(self.o, rgb, yuv, np, frames=[0]) if check else None
+        tr, _ = pmc_traffic(wl, self.n, self.w, self.h, comp == 0x07 and vw.linesize == 4 * self.w)
+        vr = roofline(wl, vw.algo_bytes, ln, kms, sus["ms_per_step"], tr)
+        if wl == "three_scope":
+            # SURVEY 8(d)'s config-5 bytes (ONE read of the frames + the three tables) over the whole step.  The label
+            # "hbm" would flatter this workload: with four LDS atomics and K0 per pixel its own ceiling is LDS / VALU
+            # issue, which profiles/round1/lds_atomic_microbench.txt prices at about 1.3 Tpix/s = 0.64 of the HBM peak.
+            vr["achieved"] = round(vw.algo_bytes / (sus["ms_per_step"] * 1e-3) / 1e9, 1)
+            vr["frac"] = vr["frac_whole_step"]
+            vr["bound"] = "lds/valu issue (4 LDS atomics + K0 per pixel); hbm is the yardstick, not the ceiling"
+            vr["ceiling_estimate"] = {"gpix_per_s": 1300, "frac_of_hbm_peak": 0.64,
+                                      "from": "ds_add_u32 at 4.5 clk per wave instruction, 4 per pixel, 256 CUs at 2.4 GHz"}
+            vr["note"] = "achieved = SURVEY 8(d) config-5 bytes (one read of the frames + the three tables) / whole step"
+        out = {"value": round(self.n * self.w * self.h / (sus["ms_per_step"] * 1e-3) / 1e9, 3), "unit": "Gpix/s", "components": f"{comp:#04x}",
+               "ms_per_step": sus["ms_per_step"], "steps": sus["steps"], "parity": ok, "roofline": vr}
+        del vw
+        return out
+
+    def distributions(self, make_frames, pad_pitch, punch_alpha_holes, rgb_uniform, yuv_uniform):
+        """SURVEY.md 8(d) D2-D6 (+ natural / screen stand-ins) under this clock: kernel frac of the headline kernel and of
+        the fused-K0 vectorscope on each; alpha holes only change what histogram and waveform do, so those run there."""
+        torch = self.torch
+        out = {}
+
+        def both(rgb, yuv):
+            a = self.variant("vectorscope", rgb, yuv, 0x07, steps=10, seconds=0.5)
+            b = self.variant("vectorscope_rgb", rgb, yuv, 0x07, steps=10, seconds=0.5)
+            return {"vectorscope": {"frac": a["roofline"]["frac"], "frac_whole_step": a["roofline"]["frac_whole_step"], "gpix_per_s": a["value"], "parity": a["parity"]},
+                    "vectorscope_rgb": {"frac": b["roofline"]["frac"], "frac_whole_step": b["roofline"]["frac_whole_step"], "gpix_per_s": b["value"], "parity": b["parity"]}}
+
+        for kind in ("natural", "concentrated", "flat", "screen", "ramp"):
+            rgb, yuv = make_frames(torch, self.ctx, self.n, self.w, self.h, kind, 0xD157 + len(out), device=self.dev.device)
+            out[kind] = both(rgb, yuv)
+            del rgb, yuv
+            self.dev.empty_cache()
+        prgb, pyuv = pad_pitch(torch, rgb_uniform[:self.n], self.w), pad_pitch(torch, yuv_uniform[:self.n], self.w)
+        out["padded_pitch"] = dict(both(prgb, pyuv), linesize=int(prgb.shape[2]))
+        del prgb, pyuv
+        holes = punch_alpha_holes(torch, rgb_uniform[:self.n].clone(), self.w)
+        hy = yuv_uniform[:self.n]
+        a = self.variant("histogram", holes, hy, 0x07, steps=10, seconds=0.5)
+        b = self.variant("waveform", holes, hy, 0x07, steps=10, seconds=0.5)
+        out["alpha_holes"] = {"histogram": {"frac": a["roofline"]["frac"], "gpix_per_s": a["value"], "parity": a["parity"]},
+                              "waveform": {"frac": b["roofline"]["frac"], "gpix_per_s": b["value"], "parity": b["parity"]},
+                              "note": "the vectorscope ignores alpha (src/vectorscope.c:217-238): histogram and waveform are what D5 exercises"}
+        del holes
+        self.dev.empty_cache()
+        out["what"] = (f"{self.n} frames per launch, kernel frac = algorithmic bytes / the accumulation kernel's own begin/end stamps / 8 TB/s; "
+                       "pools taken as allocated (no placement search); uniform noise is the headline")
+        return out
+
+
+def config1_leg(np, ctx, o, reps=25):
+    """BASELINE configs[0]: 256-bin RGB histogram over one 1280x720 frame on the CPU path (the oracle = this build's port of
+    src/histogram.c:330-418, one thread, counts + level pass), and the GPU's result for the same frame."""
+    w, h = 1280, 720
+    rgb = o.fill_frame(w, h, 1, 0x720)
+    times = []
+    for _ in range(5 + reps):
+        t0 = time.perf_counter()
+        want, want_hi = o.histogram(rgb, None, w, 0x07)
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[5:])
+    ms = times[len(times) // 2] * 1e3
+    got, hi, st = ctx.histogram(rgb=rgb, yuv=None, width=w, components=0x07)
+    same = st == 0 and bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))) and bool(np.array_equal(hi, want_hi))
+    return {"workload": "histogram RGB (0x07), one 1280x720 BGRA8 frame, CPU path only (oracle port, one thread, -O2)",
+            "ms_per_frame": round(ms, 4), "gpix_per_s": round(w * h / (ms * 1e-3) / 1e9, 3), "median_of": reps,
+            "gpu_tables_bit_exact": same, "kind": "port (parity unpinned)",
+            "note": "excludes the reference's GPU->CPU readback; the GPU call here is a host-buffer call (PCIe-inclusive), not timed"}
+
+
+def config4_leg(dev, ctl, torch, np, ctx, o, comm, rank, world, w, h, frames=16, seconds=0.6, overlap=None):
+    """ONE batch of w x h (7680x4320) frames, the same frames whatever N is (shared seed); rank r owns rows
+    [h r/N, h (r+1)/N) of every frame; per step every rank reduces its tiles, the packed tables are summed over RCCL
+    through the C-ABI and clamped.  Figures: throughput with the steps enqueued back to back (step i's sum under step
+    i+1's accumulation when `overlap`), the same with the sum on the accumulation's stream, and the latency of one step
+    with its reduce waited for (nothing bucketed or deferred)."""
+    from obs_color_monitor_amd.row_tiles import tile_rows
+    from obs_color_monitor_amd.synth import make_frame_tiles
+
     r0, r1 = tile_rows(h, rank, world)
     th = r1 - r0
-    # every rank generates ITS rows of the same frames: the seed is shared, the generator is advanced past other ranks' rows
-    # (cheaper than generating whole 8K frames on every GPU: a tile is all a rank ever reads)
-    rgb, yuv = make_frames(torch, ctx, frames, w, th, "uniform", 0xC0FFEE + rank)
+    rgb, yuv = make_frame_tiles(torch, ctx, frames, w, h, r0, r1, 0xC0FFEE, device=dev.device)
+    del rgb
     batch = ctx.make_device_batch(yuv, 4 * w, w, th, planes_are_rgb=False)
-    wires = [torch.empty((frames, 32768), dtype=torch.int32, device="cuda") for _ in range(2)]
-    outs = [torch.empty((frames, 65536), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    wire, out = wires[0], outs[0]
+    wires = [torch.empty((frames, 32768), dtype=torch.int32, device=dev.device) for _ in range(2)]
+    outs = [torch.empty((frames, 65536), dtype=torch.uint8, device=dev.device) for _ in range(2)]
     count = [0]
 
-    def step():
-        """steps enqueued back to back: step i's table sum overlaps step i + 1's accumulation (`overlap`), or follows it on
-        the same stream"""
+    def step(ov):
         buf = count[0] & 1
         count[0] += 1
         rctx = ctx
-        if overlap:
-            overlap.before_compute(buf)
-            rctx = overlap.ctx
+        if ov:
+            ov.before_compute(buf)
+            rctx = ov.ctx
         ctx.vectorscope_batch_dev(batch, wires[buf], sync=False, packed16=True)
-        if overlap:
-            overlap.after_compute(buf)
+        if ov:
+            ov.after_compute(buf)
         rctx.table_allreduce(comm, wires[buf], frames * 32768)
         rctx.unpack16_clamp_dev(wires[buf], outs[buf], frames * 32768)
-        if overlap:
-            overlap.after_reduce(buf)
+        if ov:
+            ov.after_reduce(buf)
+        return buf
 
-    def step_waited():
-        ctx.vectorscope_batch_dev(batch, wire, sync=False, packed16=True)
-        ctx.table_allreduce(comm, wire, frames * 32768)
-        ctx.unpack16_clamp_dev(wire, out, frames * 32768)
+    def throughput(ov):
+        """every rank runs the SAME number of steps (a step holds a collective): fixed chunks, the ranks agree after each
+        whether to go on"""
+        for _ in range(6):
+            step(ov)
+        dev.sync()
+        ctl.barrier()
+        t0 = time.perf_counter()
+        steps, chunk = 0, 40 if not dev.emul else 2
+        while True:
+            for _ in range(chunk):
+                step(ov)
+            steps += chunk
+            dev.sync()
+            if not ctl.any_true(time.perf_counter() - t0 < seconds):
+                break
+        dev.sync()
+        ctl.barrier()
+        return ctl.max(time.perf_counter() - t0) / steps * 1e3, steps
 
-    for _ in range(10):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    # every rank runs the SAME number of steps (a step holds a collective): fixed chunks, and the ranks agree after each
-    # whether to go on; the agreement drains the stream, so the chunk is long (tens of milliseconds) against that pause
-    t0 = time.perf_counter()
-    steps, chunk = 0, 40
-    while True:
-        for _ in range(chunk):
-            step()
-        steps += chunk
-        if not agree(torch, dist, time.perf_counter() - t0 < seconds):
-            break
-    torch.cuda.synchronize()
-    dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    ms = float(el.item()) / steps * 1e3
+    ms_serial, steps_serial = throughput(None)
+    ms_overlap, steps_overlap = throughput(overlap) if overlap else (None, 0)
+    dev.sync()
     lat = []
-    for _ in range(30):
-        dist.barrier()
-        torch.cuda.synchronize()
+    for _ in range(30 if not dev.emul else 2):
+        ctl.barrier()
+        dev.sync()
         t1 = time.perf_counter()
-        step_waited()
-        torch.cuda.synchronize()
+        last = step(None)
+        dev.sync()
         lat.append(time.perf_counter() - t1)
-    lat_t = torch.tensor([sorted(lat)[len(lat) // 2]], dtype=torch.float64, device="cuda")
-    dist.all_reduce(lat_t, op=dist.ReduceOp.MAX)
-    # parity of frame 0: the sum of every rank's oracle table of its tile, clamped once
-    mine = torch.from_numpy(o.vectorscope(yuv[0].cpu().numpy(), w).astype(np.int64).reshape(-1)).cuda()
-    dist.all_reduce(mine)
-    ok = torch.tensor([1 if torch.equal(out[0].to(torch.int64), mine.clamp(max=255)) else 0], dtype=torch.int32, device="cuda")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    lat_ms = ctl.max(sorted(lat)[len(lat) // 2]) * 1e3
+    # parity of frames 0 and last of the batch: the sum of every rank's oracle table of its tile, clamped once; checked on
+    # the table the serial path left AND on one the overlapped path left (the two must be the same table)
+    ok = True
+    for f in sorted({0, frames - 1}):
+        want = np.minimum(ctl.sum_array(o.vectorscope(yuv[f].cpu().numpy(), w).astype(np.int64).reshape(-1)), 255)
+        ok &= bool(np.array_equal(outs[last][f].cpu().numpy().astype(np.int64), want))
+        if overlap:
+            b2 = step(overlap)
+            dev.sync()
+            ok &= bool(np.array_equal(outs[b2][f].cpu().numpy().astype(np.int64), want))
+    ok = ctl.all_true(ok)
+    best = min(ms_serial, ms_overlap) if ms_overlap else ms_serial
     return {
-        "value": round(frames * w * h / (ms * 1e-3) / 1e9, 3), "unit": "Gpix/s", "scaling": "strong", "ms_per_step": round(ms, 4),
-        "step_latency_ms_reduce_waited": round(float(lat_t.item()) * 1e3, 4),
-        "partition": f"{frames} frames of {w}x{h}, {world} row tiles of {w}x{th} per frame + RCCL sum of 256x256 tables (C-ABI)",
-        "frames_per_step": frames, "parity": bool(ok.item()),
+        "value": round(frames * w * h / (best * 1e-3) / 1e9, 3), "unit": "Gpix/s", "scaling": "strong", "ms_per_step": round(best, 4),
+        "ms_per_step_reduce_on_the_accumulation_stream": round(ms_serial, 4),
+        "ms_per_step_reduce_overlapped_second_stream": round(ms_overlap, 4) if ms_overlap else None,
+        "step_latency_ms_reduce_waited": round(lat_ms, 4),
+        "steps_timed": [steps_serial, steps_overlap],
+        "partition": f"{frames} frames of {w}x{h} (shared seed: the same frames at every N), {world} row tile(s) of {w}x{th} per frame "
+                     f"+ RCCL sum of the 256x256 tables through the C-ABI, every step",
+        "frames_per_step": frames, "rows_of_this_rank": [r0, r1], "parity": bool(ok),
     }
 
 
 def cpu_baseline(np, o, wl, plane_rgb, plane_yuv, w, h, components, seconds):
-    def one():
-        if wl in ("vectorscope", "vectorscope_rgb"):
+    def one(kind=wl, comp=components):
+        if kind in ("vectorscope", "vectorscope_rgb"):
             return o.vectorscope(plane_yuv, w)
-        if wl == "waveform":
-            return o.waveform(plane_rgb, plane_yuv, w, components)
-        return o.histogram_counts(plane_rgb, plane_yuv, w, components)
+        if kind == "waveform":
+            return o.waveform(plane_rgb, plane_yuv, w, comp)
+        return o.histogram_counts(plane_rgb, plane_yuv, w, comp)
 
-    t_end = time.perf_counter() + seconds
-    reps, t_start = 0, time.perf_counter()
-    while time.perf_counter() < t_end or reps < 3:
-        one()
-        reps += 1
-    cpu_t = time.perf_counter() - t_start
+    def rate(kind, comp, secs):
+        t_end = time.perf_counter() + secs
+        reps, t_start = 0, time.perf_counter()
+        while time.perf_counter() < t_end or reps < 3:
+            one(kind, comp)
+            reps += 1
+        dt = time.perf_counter() - t_start
+        return reps, dt, reps * w * h / dt / 1e9
+
+    reps, cpu_t, gpix = rate(wl, components, seconds)
     res = {
-        "value": round(reps * w * h / cpu_t / 1e9, 4),
+        "value": round(gpix, 4),
         "unit": "Gpix/s",
         "cores": 1,
         "kind": "port",
@@ -784,6 +1184,14 @@ def cpu_baseline(np, o, wl, plane_rgb, plane_yuv, w, h, components, seconds):
                   f"single color-monitor thread) over frame 0 of the same batch, {cpu_t:.1f} s; "
                   f"host has {os.cpu_count()} cores; excludes the reference's GPU->CPU readback",
     }
+    # the other two loops of the path on the same frame, one thread, short samples
+    others = {}
+    for kind, comp in (("vectorscope", 0x07), ("waveform", 0x07), ("waveform", 0x20), ("histogram", 0x07)):
+        if kind == wl and comp == components:
+            continue
+        r, dt, g = rate(kind, comp, min(2.0, seconds / 4))
+        others[f"{kind}_{comp:#04x}"] = {"value": round(g, 4), "unit": "Gpix/s", "cores": 1, "passes": r, "seconds": round(dt, 2)}
+    res["other_loops_one_thread"] = others
     # courtesy: every host core, row/column tiles with private tables; same tables, checked here
     threads = os.cpu_count() or 1
     cpu_model = "?"
@@ -811,9 +1219,9 @@ def cpu_baseline(np, o, wl, plane_rgb, plane_yuv, w, h, components, seconds):
         while time.perf_counter() - t_start < min(seconds, 10.0) / 8 or calls < 1:
             all_cores(nthreads, mt_reps)
             calls += 1
-        rate = calls * mt_reps * w * h / (time.perf_counter() - t_start) / 1e9
-        if best is None or rate > best[0]:
-            best = (rate, nthreads, calls)
+        r = calls * mt_reps * w * h / (time.perf_counter() - t_start) / 1e9
+        if best is None or r > best[0]:
+            best = (r, nthreads, calls)
     res["all_cores"] = {
         "value": round(best[0], 3), "unit": "Gpix/s", "cores": best[1], "host_cores": threads, "cpu": cpu_model,
         "same_table": mt_same,

@@ -3,8 +3,9 @@ one MI355X with upload / compute / download hipStreams overlapped (scope_pipe_* 
 reference's CM_SURFACE_QUEUE_SIZE, src/common.h:46).
 
 Frames start in PINNED HOST memory (what a capture path would fill); every frame crosses PCIe, so these are the
-PCIe-inclusive rates of the whole drop-in path -- never bench.py's `value`.  Used by bench.py (`stream` object of the
-default run, `--workload stream`) and tests/tools/stream_bench.py.
+PCIe-inclusive rates of the whole drop-in path -- never bench.py's `value`.  A measurement leg, so it lives beside
+bench.py and not in the package (it takes the oracle as the checker of sampled frames): used by bench.py (`stream`
+object of the default run, `--workload stream`) and tests/tools/stream_bench.py.
 """
 from __future__ import annotations
 
@@ -47,8 +48,8 @@ def _run(pipe, ptrs, n, np, check_every=0, pace=0.0, seconds=0.0):
 
 def stream_leg(torch, np, ctx, oracle, seconds=2.0, sources=16, depth=3, dist_kind="natural"):
     """Flat out for `seconds`, then paced at 240 frames/s for `seconds`; sampled frames checked against the oracle."""
-    from . import ScopePipe
-    from .synth import make_rgb_frames
+    from obs_color_monitor_amd import ScopePipe
+    from obs_color_monitor_amd.synth import make_rgb_frames
 
     rgb = make_rgb_frames(torch, sources, W, H, dist_kind, 7)
     torch.cuda.synchronize()

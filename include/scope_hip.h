@@ -347,6 +347,12 @@ int scope_rccl_unique_id(uint8_t id[SCOPE_RCCL_ID_BYTES]);
 int scope_rccl_comm_create(scope_ctx *ctx, const uint8_t id[SCOPE_RCCL_ID_BYTES], int n_ranks, int rank, void **rccl_comm);
 int scope_rccl_comm_destroy(void *rccl_comm);
 int scope_table_allreduce(scope_ctx *ctx, void *rccl_comm, uint32_t *words, uint64_t n_words);
+/* What the collective library itself says about a communicator: ncclCommCount, ncclCommUserRank and ncclGetVersion
+ * (major*10000 + minor*100 + patch).  Any of the three pointers may be NULL; a value the library does not offer comes
+ * back as -1; rccl_comm may be NULL when only the version is asked for.  A host (bench.py) prints these next to its
+ * numbers so that a line says how many ranks RCCL saw, not how many were asked for.
+ * The environment variable SCOPE_RCCL_LIBRARY (a path or soname) names the library to bind instead of the ROCm librccl. */
+int scope_rccl_comm_info(void *rccl_comm, int *n_ranks, int *rank, int *version);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * With profiling on, every accumulation launch (the dominant kernel of a call, not the small

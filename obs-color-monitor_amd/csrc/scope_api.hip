@@ -1731,6 +1731,9 @@ struct rccl_api {
 	int (*comm_destroy)(void *comm);
 	int (*all_reduce)(const void *send, void *recv, size_t count, int datatype, int op, void *comm, hipStream_t stream);
 	const char *(*error_string)(int);
+	int (*comm_count)(const void *comm, int *count);    /* optional: scope_rccl_comm_info */
+	int (*comm_user_rank)(const void *comm, int *rank); /* optional */
+	int (*get_version)(int *version);                   /* optional */
 };
 
 const rccl_api *rccl()
@@ -1741,18 +1744,27 @@ const rccl_api *rccl()
 	std::lock_guard<std::mutex> lock(mu);
 	if (!tried) {
 		tried = true;
+		/* SCOPE_RCCL_LIBRARY names the collective library of the host (a path or a soname exporting the nccl* entry
+		 * points below); when it is set nothing else is tried, so a host never gets another RCCL than the one it asked for */
+		const char *forced = getenv("SCOPE_RCCL_LIBRARY");
 		const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-		for (const char *n : names) {
-			api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-			if (api.handle)
-				break;
-		}
+		if (forced && *forced)
+			api.handle = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+		else
+			for (const char *n : names) {
+				api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+				if (api.handle)
+					break;
+			}
 		if (api.handle) {
 			api.get_unique_id = (int (*)(rccl_id *))dlsym(api.handle, "ncclGetUniqueId");
 			api.comm_init_rank = (int (*)(void **, int, rccl_id, int))dlsym(api.handle, "ncclCommInitRank");
 			api.comm_destroy = (int (*)(void *))dlsym(api.handle, "ncclCommDestroy");
 			api.all_reduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.handle, "ncclAllReduce");
 			api.error_string = (const char *(*)(int))dlsym(api.handle, "ncclGetErrorString");
+			api.comm_count = (int (*)(const void *, int *))dlsym(api.handle, "ncclCommCount");
+			api.comm_user_rank = (int (*)(const void *, int *))dlsym(api.handle, "ncclCommUserRank");
+			api.get_version = (int (*)(int *))dlsym(api.handle, "ncclGetVersion");
 			if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_reduce)
 				api.handle = NULL;
 		}
@@ -1809,6 +1821,28 @@ int scope_rccl_comm_destroy(void *comm)
 	if (!r || !comm)
 		return SCOPE_EINVAL;
 	return r->comm_destroy(comm) ? SCOPE_EIO : SCOPE_OK;
+}
+
+int scope_rccl_comm_info(void *rccl_comm, int *n_ranks, int *rank, int *version)
+{
+	const rccl_api *r = rccl();
+	if (!r)
+		return SCOPE_ENODEV;
+	if (n_ranks)
+		*n_ranks = -1;
+	if (rank)
+		*rank = -1;
+	if (version)
+		*version = -1;
+	if (version && r->get_version && r->get_version(version) != 0)
+		return SCOPE_EIO;
+	if (!rccl_comm)
+		return (n_ranks || rank) ? SCOPE_EINVAL : SCOPE_OK;
+	if (n_ranks && r->comm_count && r->comm_count(rccl_comm, n_ranks) != 0)
+		return SCOPE_EIO;
+	if (rank && r->comm_user_rank && r->comm_user_rank(rccl_comm, rank) != 0)
+		return SCOPE_EIO;
+	return SCOPE_OK;
 }
 
 int scope_table_allreduce(scope_ctx *ctx, void *rccl_comm, uint32_t *words, uint64_t n_words)

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "scope_ctx_profile", "scope_ctx_kernel_ms",
     "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect", "scope_pipe_size",
     "scope_region_size", "scope_stage_region", "scope_surface_begin", "scope_surface_end",
-    "scope_rccl_unique_id", "scope_rccl_comm_create", "scope_rccl_comm_destroy", "scope_table_allreduce",
+    "scope_rccl_unique_id", "scope_rccl_comm_create", "scope_rccl_comm_destroy", "scope_table_allreduce", "scope_rccl_comm_info",
     "scope_display_graticule", "scope_graticule_label_strip",
     "scope_display_vectorscope", "scope_display_vectorscope_zoom", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
 )
@@ -136,6 +136,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_rccl_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
         "scope_rccl_comm_destroy": (i32, [vp]),
         "scope_table_allreduce": (i32, [vp, vp, vp, u64]),
+        "scope_rccl_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "scope_ctx_profile": (i32, [vp, i32]),
         "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
         "scope_display_vectorscope": (i32, [vp, vp, i32, i32, i32, u32, vp]),
@@ -475,6 +476,14 @@ class ScopeContext:
 
     def rccl_comm_destroy(self, comm: int):
         self.L.scope_rccl_comm_destroy(C.c_void_p(comm))
+
+    def rccl_comm_info(self, comm: int) -> dict:
+        """What the collective library reports for `comm`: {"ranks", "rank", "version"} (-1 = not offered)."""
+        n, r, v = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        st = self.L.scope_rccl_comm_info(C.c_void_p(comm), C.byref(n), C.byref(r), C.byref(v))
+        if st != OK:
+            raise ScopeError(st, "scope_rccl_comm_info")
+        return {"ranks": n.value, "rank": r.value, "version": v.value}
 
     def table_allreduce(self, comm: int, words_dev, n_words: int):
         """In-place uint32 sum over the communicator, enqueued on the context's stream."""

@@ -1,0 +1,108 @@
+"""bench.py's N-rank path on CPU: `--backend emul` runs the same file against tests/emul/libscope_emul.so (the unmodified
+kernel sources compiled for the CPU), gloo as the control plane and tests/emul/libshm_rccl_emul.so as the collective
+library the C-ABI binds (SCOPE_RCCL_LIBRARY) -- so `python bench.py --gpus 2` with no WORLD_SIZE around starts its own two
+ranks here exactly as it would on a multi-GPU node, sums the tables through scope_table_allreduce, runs BASELINE config 4
+in row tiles, and a hung or missing collective still ends in ONE JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--backend", "emul", "--geometry", "128x24", "--frames", "2", "--pool", "4", "--steps", "2", "--warmup", "1",
+         "--settle-seconds", "0", "--min-seconds", "0", "--no-cpu"]
+C4 = ["--config4-geometry", "256x40", "--config4-frames", "2", "--strong"]
+
+
+@pytest.fixture(scope="module")
+def shm_rccl(emul_lib):
+    from conftest import locked_make
+
+    d = os.path.join(ROOT, "tests", "emul")
+    locked_make(d, "libshm_rccl_emul.so")
+    return os.path.join(d, "libshm_rccl_emul.so")
+
+
+def clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SELF_LAUNCHED", "SCOPE_RCCL_LIBRARY")}
+    env.update(OMP_NUM_THREADS="1", **extra)
+    return env
+
+
+def run_bench(args, env, prefix=(), timeout=600):
+    out = subprocess.run([sys.executable, *prefix, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected, rc={out.returncode}\n{out.stdout[-2000:]}\n{out.stderr[-4000:]}"
+    return out.returncode, json.loads(lines[0]), out.stderr
+
+
+def test_gpus2_without_world_size_starts_its_own_ranks(shm_rccl):
+    rc, d, err = run_bench(["--gpus", "2", *SMALL, *C4], clean_env())
+    assert rc == 0, err[-3000:]
+    assert d["n_gpus"] == 2 and d["parity"].startswith("bit-exact") and d["unit"] == "Gpix/s"
+    la = d["launcher"]
+    assert len(la["attempts"]) == 1 and la["attempts"][0]["exit_codes"] == [0, 0] and la["attempts"][0]["failure"] is None
+    cfg = d["config"]
+    assert cfg["launch"] == "self-launched rank"
+    assert cfg["rccl"]["ranks_in_communicator"] == 2, "the line must say how many ranks the collective library saw"
+    assert cfg["reduce"].startswith("C-ABI: scope_table_allreduce")
+    c4 = d["config4"]
+    assert c4["parity"] is True and c4["scaling"] == "strong" and c4["rccl_ranks_in_communicator"] == 2
+    assert c4["rows_of_this_rank"] == [0, 20]  # rank 0's half of the 40 rows
+    assert c4["ms_per_step_reduce_on_the_accumulation_stream"] > 0 and c4["ms_per_step_reduce_overlapped_second_stream"] > 0
+    assert c4["step_latency_ms_reduce_waited"] > 0
+    assert d["scaling"] == "strong"  # --strong made config 4 the headline
+
+
+def test_gpus1_line_carries_config4_with_a_one_rank_communicator(shm_rccl):
+    rc, d, err = run_bench(["--gpus", "1", *SMALL, *C4], clean_env(SCOPE_RCCL_LIBRARY=shm_rccl))
+    assert rc == 0, err[-3000:]
+    assert d["n_gpus"] == 1 and "launcher" not in d and d["config"]["launch"] == "single process"
+    c4 = d["config4"]
+    assert c4["parity"] is True and c4["rccl_ranks_in_communicator"] == 1 and c4["rows_of_this_rank"] == [0, 40]
+
+
+def test_under_torch_distributed_run(shm_rccl):
+    env = clean_env(MASTER_ADDR="127.0.0.1")
+    prefix = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29519"]
+    rc, d, err = run_bench(["--gpus", "2", *SMALL, "--no-extras"], env, prefix=prefix)
+    assert rc == 0, err[-3000:]
+    assert d["n_gpus"] == 2 and "launcher" not in d and d["config"]["launch"] == "torch.distributed.run rank"
+    assert d["config"]["rccl"]["ranks_in_communicator"] == 2 and d["parity"].startswith("bit-exact")
+
+
+def test_hung_collective_still_prints_a_line(shm_rccl):
+    # rank 1 never enters its first ncclAllReduce: rank 0 waits, the ranks' own watchdog (deadline - 15 s) dumps stacks and
+    # leaves, the launcher ends the attempt and the next rung (torch.distributed) produces the line
+    env = clean_env(SHM_RCCL_HANG_RANK="1", SHM_RCCL_TIMEOUT_S="1000")
+    rc, d, err = run_bench(["--gpus", "2", *SMALL, "--no-extras", "--launch-timeout", "20"], env)
+    assert rc == 0, err[-3000:]
+    attempts = d["launcher"]["attempts"]
+    assert len(attempts) == 2 and attempts[0]["failure"] and attempts[1]["failure"] is None
+    assert attempts[1]["extra_args"] == ["--torch-reduce"]
+    assert d["config"]["reduce"].startswith("torch.distributed") and d["parity"].startswith("bit-exact")
+    assert "Timeout" in err  # faulthandler said where the stuck rank was
+
+
+def test_missing_collective_library_falls_back_together(shm_rccl):
+    rc, d, err = run_bench(["--gpus", "2", *SMALL, "--no-extras"], clean_env(SCOPE_RCCL_LIBRARY="/nonexistent/librccl.so"))
+    assert rc == 0, err[-3000:]
+    assert len(d["launcher"]["attempts"]) == 1, "no rung is burnt: the ranks agree on the fall-back inside the first attempt"
+    assert d["config"]["reduce"].startswith("torch.distributed") and d["config"]["rccl"] is None
+
+
+def test_replicas_rung_says_what_it_is(shm_rccl):
+    rc, d, err = run_bench(["--gpus", "2", *SMALL, "--no-extras", "--no-collective"], clean_env())
+    assert rc == 0, err[-3000:]
+    assert d["config"]["reduce"].startswith("NONE") and "NO table sum" in d["config"]["partition"]
+    assert "config4" not in d
+
+
+def test_nothing_works_still_one_line(shm_rccl, tmp_path):
+    # every rung dies at once (an unknown option value): the launcher's own line, exit code 5
+    rc, d, err = run_bench(["--gpus", "2", *SMALL, "--no-extras", "--option", "no_such_option=1", "--launch-timeout", "60"], clean_env())
+    assert rc == 5 and d["value"] == 0.0 and "error" in d and len(d["launcher"]["attempts"]) == 3

@@ -800,3 +800,59 @@ def test_table_allreduce_through_the_c_abi(hip_ctx, oracle):
                            oracle.histogram_counts(tr[f].cpu().numpy(), None, w, 0x07), f"histogram frame {f}")
     finally:
         hip_ctx.rccl_comm_destroy(comm)
+
+
+def _run_bench(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"rc={out.returncode}\n{out.stdout[-2000:]}\n{out.stderr[-5000:]}"
+    return out.returncode, json.loads(lines[0]), out.stderr
+
+
+def test_bench_two_ranks_on_one_gpu_table_sum_overlapped_and_serial(hip_ctx):
+    """`python bench.py --gpus 2` as the driver types it (no WORLD_SIZE): two self-launched ranks that SHARE this box's one
+    GPU, the real kernels, the C-ABI's scope_table_allreduce bound to tools/libshm_rccl_hip.so (a stream-ordered,
+    asynchronous all-reduce between processes; RCCL itself refuses two ranks on one device).  What it checks is this
+    repo's side of the N > 1 path: the launcher, the gloo control plane, the two-stream overlap's event order (a table
+    summed under the next step's accumulation is compared with the oracle, and in the config-4 leg the overlapped and
+    the serial path must leave the same table), the row tiles of one shared 7680x4320 batch."""
+    from conftest import ROOT, locked_make
+
+    locked_make(os.path.join(ROOT, "tools"), "libshm_rccl_hip.so")
+    lib = os.path.join(ROOT, "tools", "libshm_rccl_hip.so")
+    rc, d, err = _run_bench(["--gpus", "2", "--oversubscribe", "--frames", "8", "--pool", "8", "--steps", "20", "--warmup", "3",
+                             "--min-seconds", "0.3", "--settle-seconds", "0.1", "--placement-candidates", "1", "--no-cpu",
+                             "--config4-frames", "4", "--launch-timeout", "400"], {"SCOPE_RCCL_LIBRARY": lib})
+    assert rc == 0, err[-4000:]
+    assert d["n_gpus"] == 2 and d["parity"].startswith("bit-exact"), d["parity"]
+    assert d["config"]["gpu_shared_by_ranks"] is True and d["config"]["rccl"]["ranks_in_communicator"] == 2
+    assert d["config"]["reduce"].startswith("C-ABI") and "second hipStream" in d["config"]["reduce"]
+    assert len(d["launcher"]["attempts"]) == 1 and d["launcher"]["attempts"][0]["failure"] is None
+    c4 = d["config4"]
+    assert "error" not in c4, c4
+    assert c4["parity"] is True and c4["rccl_ranks_in_communicator"] == 2 and c4["rows_of_this_rank"] == [0, 2160]
+    assert c4["ms_per_step_reduce_overlapped_second_stream"] > 0
+    # and the same summed on the accumulation's own stream, headline included
+    rc, d2, err = _run_bench(["--gpus", "2", "--oversubscribe", "--serial-reduce", "--frames", "8", "--pool", "8", "--steps", "20",
+                              "--warmup", "3", "--min-seconds", "0.2", "--settle-seconds", "0.1", "--placement-candidates", "1",
+                              "--no-cpu", "--no-extras", "--launch-timeout", "400"], {"SCOPE_RCCL_LIBRARY": lib})
+    assert rc == 0 and d2["parity"].startswith("bit-exact") and "same stream" in d2["config"]["reduce"], err[-3000:]
+
+
+def test_bench_one_gpu_line_has_config4_and_rccl_rank_count(hip_ctx):
+    """The driver's N = 1 command: the line carries the config-4 strong leg's base point (one rank owns all 4320 rows, the
+    sum goes through RCCL itself with a one-rank communicator) and says how many ranks RCCL saw."""
+    rc, d, err = _run_bench(["--gpus", "1", "--steps", "5", "--warmup", "2", "--min-seconds", "0.2", "--no-cpu", "--no-extras", "--strong",
+                             "--workload", "vectorscope", "--frames", "8", "--pool", "8", "--placement-candidates", "1", "--config4-frames", "4"])
+    assert rc == 0, err[-4000:]
+    c4 = d["config4"]
+    assert "error" not in c4, c4
+    assert c4["parity"] is True and c4["rccl_ranks_in_communicator"] == 1 and c4["rows_of_this_rank"] == [0, 4320]
+    assert d["scaling"] == "strong" and d["value"] == c4["value"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 5 on its own: python tests/tools/stream_bench.py [--seconds 4] -- the same leg bench.py runs
-(obs-color-monitor_amd/stream.py: pinned host frames -> scope_pipe_* -> tables; flat out, then paced at 240 fps)."""
+(bench_stream.py: pinned host frames -> scope_pipe_* -> tables; flat out, then paced at 240 fps)."""
 import argparse
 import json
 import os
@@ -15,7 +15,7 @@ import torch  # noqa: E402
 
 import obs_color_monitor_amd as ocm  # noqa: E402
 import scope_oracle  # noqa: E402
-from obs_color_monitor_amd.stream import stream_leg  # noqa: E402
+from bench_stream import stream_leg  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=4.0)
