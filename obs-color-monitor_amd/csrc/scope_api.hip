@@ -54,6 +54,8 @@ struct scope_ctx {
 		const uint8_t *his_plane;
 		int his_fuse;
 		uint32_t his_chmask;
+		uint32_t his_linesize, his_width, his_height; /* the counts are those of THIS geometry ... */
+		int his_colorspace;                           /* ... and, through a fused K0, of this matrix */
 		uint32_t his_counts[SCOPE_HIS_WORDS];
 	} surf;
 	uint32_t *tickets; /* SCOPE_MAX_FRAMES arrival counters of the in-launch combine; zero between launches */
@@ -1023,6 +1025,10 @@ int scope_waveform(scope_ctx *ctx, const struct scope_surface_data *sd, uint32_t
 			ctx->surf.his_plane = plane;
 			ctx->surf.his_fuse = fuse;
 			ctx->surf.his_chmask = channel_mask(components);
+			ctx->surf.his_linesize = sd->linesize;
+			ctx->surf.his_width = sd->width;
+			ctx->surf.his_height = sd->height;
+			ctx->surf.his_colorspace = sd->colorspace;
 		}
 		return st;
 	}
@@ -1070,7 +1076,11 @@ int scope_histogram_counts(scope_ctx *ctx, const struct scope_surface_data *sd, 
 		return zero_result(ctx, counts, SCOPE_HIS_WORDS * 4, flags); /* src/histogram.c:363-373 */
 	const uint32_t chmask = channel_mask(components);
 	if (ctx->surf.active && ctx->surf.his_valid && !(flags & (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE)) &&
-	    ctx->surf.his_plane == plane && ctx->surf.his_fuse == fuse && (chmask & ~ctx->surf.his_chmask) == 0) {
+	    ctx->surf.his_plane == plane && ctx->surf.his_fuse == fuse && (chmask & ~ctx->surf.his_chmask) == 0 &&
+	    /* same pointer, other geometry or matrix: not the pass that left these counts -- fall through to run_histogram,
+	     * where stage_planes refuses a geometry change inside scope_surface_begin/end with SCOPE_EINVAL */
+	    ctx->surf.his_linesize == sd->linesize && ctx->surf.his_width == sd->width && ctx->surf.his_height == sd->height &&
+	    (!fuse || ctx->surf.his_colorspace == sd->colorspace)) {
 		for (uint32_t t = 0; t < SCOPE_HIS_WORDS; t++) {
 			const uint32_t slot = t & 3u; /* slot 0 = R = byte 2, 1 = G, 2 = B */
 			counts[t] = (slot < 3 && ((chmask >> (2u - slot)) & 1u)) ? ctx->surf.his_counts[t] : 0u;

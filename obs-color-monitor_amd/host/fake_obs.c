@@ -15,6 +15,7 @@
 struct obs_data {
 	char key[MAX_KEYS][32];
 	long long val[MAX_KEYS];
+	double dval[MAX_KEYS]; /* what obs_data_get_double returns: libobs keeps numbers as int or double and converts on read */
 	bool user[MAX_KEYS];
 	int n;
 };
@@ -53,6 +54,7 @@ static int find_key(obs_data_t *d, const char *name, bool add)
 		return -1;
 	snprintf(d->key[d->n], sizeof d->key[0], "%s", name);
 	d->val[d->n] = 0;
+	d->dval[d->n] = 0.0;
 	d->user[d->n] = false;
 	return d->n++;
 }
@@ -63,6 +65,12 @@ long long obs_data_get_int(obs_data_t *d, const char *name)
 	return i < 0 ? 0 : d->val[i];
 }
 
+double obs_data_get_double(obs_data_t *d, const char *name)
+{
+	const int i = d ? find_key(d, name, false) : -1;
+	return i < 0 ? 0.0 : d->dval[i];
+}
+
 bool obs_data_get_bool(obs_data_t *d, const char *name)
 {
 	return obs_data_get_int(d, name) != 0;
@@ -71,8 +79,19 @@ bool obs_data_get_bool(obs_data_t *d, const char *name)
 void obs_data_set_default_int(obs_data_t *d, const char *name, long long val)
 {
 	const int i = find_key(d, name, true);
-	if (i >= 0 && !d->user[i])
+	if (i >= 0 && !d->user[i]) {
 		d->val[i] = val;
+		d->dval[i] = (double)val;
+	}
+}
+
+void obs_data_set_default_double(obs_data_t *d, const char *name, double val)
+{
+	const int i = find_key(d, name, true);
+	if (i >= 0 && !d->user[i]) {
+		d->val[i] = (long long)val;
+		d->dval[i] = val;
+	}
 }
 
 void obs_data_set_default_bool(obs_data_t *d, const char *name, bool val)
@@ -103,6 +122,17 @@ void fake_obs_data_set_int(obs_data_t *d, const char *name, long long val)
 	const int i = find_key(d, name, true);
 	if (i >= 0) {
 		d->val[i] = val;
+		d->dval[i] = (double)val;
+		d->user[i] = true;
+	}
+}
+
+void fake_obs_data_set_double(obs_data_t *d, const char *name, double val)
+{
+	const int i = find_key(d, name, true);
+	if (i >= 0) {
+		d->val[i] = (long long)val;
+		d->dval[i] = val;
 		d->user[i] = true;
 	}
 }

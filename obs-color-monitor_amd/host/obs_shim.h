@@ -65,8 +65,10 @@ void *bzalloc(size_t size);
 void bfree(void *ptr);
 
 long long obs_data_get_int(obs_data_t *data, const char *name);
+double obs_data_get_double(obs_data_t *data, const char *name);
 bool obs_data_get_bool(obs_data_t *data, const char *name);
 void obs_data_set_default_int(obs_data_t *data, const char *name, long long val);
+void obs_data_set_default_double(obs_data_t *data, const char *name, double val);
 void obs_data_set_default_bool(obs_data_t *data, const char *name, bool val);
 void obs_register_source(const struct obs_source_info *info);
 

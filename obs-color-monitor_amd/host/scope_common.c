@@ -324,12 +324,15 @@ bool cm_render_target(struct cm_source *src, const uint8_t *target_rgb, uint32_t
 		PROFILE_END(PROF_RENDER_TARGET);
 		return false;
 	}
-	/* RGB rows first, YUV rows after them -- the staged surface's layout (:284-291) */
-	int st = scope_stage_region(cm_gpu(), target_rgb, linesize, target_width, target_height, &region, stacked,
+	/* RGB rows first, YUV rows after them -- the staged surface's layout (:284-291).  This is the render thread
+	 * (video_render, src/vectorscope.c:393): its two GPU calls go to the render thread's own context, so they never queue
+	 * behind a pipeline thread that holds cm_gpu() across scope_surface_begin..end (upload + three scopes). */
+	scope_ctx *gpu = cm_gpu_render();
+	int st = scope_stage_region(gpu, target_rgb, linesize, target_width, target_height, &region, stacked,
 				    out_linesize, 0);
 	if (st == SCOPE_OK && has_yuv) {
 		PROFILE_START(PROF_CONVERT_YUV);
-		st = scope_convert_rgb_yuv(cm_gpu(), stacked, out_linesize, stacked + plane, out_linesize, cx, cy,
+		st = scope_convert_rgb_yuv(gpu, stacked, out_linesize, stacked + plane, out_linesize, cx, cy,
 					   src->colorspace, 0);
 		PROFILE_END(PROF_CONVERT_YUV);
 	}
@@ -348,7 +351,7 @@ bool cm_render_target(struct cm_source *src, const uint8_t *target_rgb, uint32_t
 		src->flags = flags;
 		PROFILE_END(PROF_STAGE_SURFACE);
 	} else {
-		blog(LOG_ERROR, "[obs-color-monitor] cm_render_target: %s (%s)", scope_strerror(st), scope_last_error(cm_gpu()));
+		blog(LOG_ERROR, "[obs-color-monitor] cm_render_target: %s (%s)", scope_strerror(st), scope_last_error(gpu));
 	}
 	bfree(stacked);
 	return staged;

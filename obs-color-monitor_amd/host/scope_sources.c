@@ -454,20 +454,27 @@ static void his_update(void *data, obs_data_t *settings)
 	src->cm.flags = ((src->components & COMP_RGB) ? CM_FLAG_CONVERT_RGB : 0) |
 			((src->components & COMP_YUV) ? CM_FLAG_CONVERT_YUV : 0); /* src/histogram.c:119-121 */
 	src->logscale = obs_data_get_bool(settings, "logscale");
-	/* src/histogram.c:125-156: level_mode 0 none, 1 pixel count, 2 per-mille of the frame */
+	/* src/histogram.c:131-156: level_mode 0 none, 1 pixel count, 2 share of the frame.  Keys, types and conversions are the
+	 * reference's, so a settings blob saved by the real plugin reads the same here: the ratio is a double PERCENTAGE kept in
+	 * tenths ((int)(v * 10 + 0.5), :146-147), the graticule steps are doubles (:140-141, :149-150). */
 	const int level_mode = (int)obs_data_get_int(settings, "level_mode");
-	src->level_fixed_value = level_mode == 1 ? (int)obs_data_get_int(settings, "level_fixed_value") : 0;
-	src->level_ratio_value = level_mode == 2 ? (int)obs_data_get_int(settings, "level_ratio_value") : 0;
+	src->level_fixed_value = 0;
+	src->level_ratio_value = 0;
+	src->graticule_horizontal_step = 0.0f;
+	if (level_mode == 1) {
+		src->level_fixed_value = (int)obs_data_get_int(settings, "level_fixed_value");
+		src->graticule_horizontal_step = (float)obs_data_get_double(settings, "graticule_horizontal_step_fixed");
+	} else if (level_mode == 2) {
+		src->level_ratio_value = (int)(obs_data_get_double(settings, "level_ratio_value") * 10.0 + 0.5);
+		src->graticule_horizontal_step = (float)obs_data_get_double(settings, "graticule_horizontal_step_ratio");
+	} else if (level_mode != 0) {
+		blog(LOG_ERROR, "histogram: Invalid level_mode %d", level_mode); /* :153-155 */
+	}
 	src->display = (int)obs_data_get_int(settings, "display");
 	src->level_height = (int)obs_data_get_int(settings, "level_height"); /* src/histogram.c:123 */
 	if (src->level_height < 1)
 		src->level_height = 1;
-	/* :137-159; the reference's step settings are doubles, the shim's settings are integers: the step travels in 1/1000 */
-	src->graticule_vertical_lines = (int)obs_data_get_int(settings, "graticule_vertical_lines");
-	src->graticule_horizontal_step =
-		level_mode == 1   ? (float)obs_data_get_int(settings, "graticule_horizontal_step_fixed_milli") / 1000.0f
-		: level_mode == 2 ? (float)obs_data_get_int(settings, "graticule_horizontal_step_ratio_milli") / 1000.0f
-				  : 0.0f;
+	src->graticule_vertical_lines = (int)obs_data_get_int(settings, "graticule_vertical_lines"); /* :158-159 */
 }
 
 static void *his_create(obs_data_t *settings, obs_source_t *source)
@@ -526,6 +533,8 @@ static void his_get_defaults(obs_data_t *settings)
 	obs_data_set_default_int(settings, "display", 0);
 	obs_data_set_default_int(settings, "level_height", 200); /* src/histogram.c:168 */
 	obs_data_set_default_int(settings, "graticule_vertical_lines", 5); /* :169 */
+	obs_data_set_default_int(settings, "level_fixed_value", 1000);     /* :170 */
+	obs_data_set_default_double(settings, "level_ratio_value", 10.0);  /* :171: a percentage */
 }
 
 static uint32_t his_get_width(void *data)

@@ -36,6 +36,7 @@ class Host:
         L.fake_obs_find_source.argtypes = [C.c_char_p]
         L.fake_obs_data_create.restype = C.c_void_p
         L.fake_obs_data_set_int.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+        L.fake_obs_data_set_double.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.fake_obs_data_release.argtypes = [C.c_void_p]
         L.scope_host_cm.restype = C.c_void_p
         L.scope_host_cm.argtypes = [C.c_void_p]
@@ -75,7 +76,10 @@ class Host:
         d = self.L.fake_obs_data_create()
         info.get_defaults(d)
         for k, v in settings.items():
-            self.L.fake_obs_data_set_int(d, k.encode(), int(v))
+            if isinstance(v, float):
+                self.L.fake_obs_data_set_double(d, k.encode(), v)  # the reference's double-typed settings
+            else:
+                self.L.fake_obs_data_set_int(d, k.encode(), int(v))
         obj = info.create(d, None)
         self.L.fake_obs_data_release(d)
         return info, obj
@@ -327,7 +331,10 @@ def run_host_checks(host, oracle, w=96, h=40):
     x0, y0, x1, y1 = 3, 2, 3 + 41, 2 + 17  # rectangle in SCALED pixels (common.c:272-282)
     roi_info, roi = host.create("colormonitor_roi", interleave=0, target_scale=3, roi_x0=x0, roi_y0=y0, roi_x1=x1, roi_y1=y1)
     winfo, wvs = host.create("waveform_source", components=0x07)
-    hinfo, his = host.create("histogram_source", components=0x70)
+    # level settings with the reference's keys and types: level_ratio_value is a double PERCENTAGE that the plugin keeps in
+    # tenths, (int)(v * 10 + 0.5) (src/histogram.c:146-147) -- 12.5 % = 125 per mille of the frame's pixels
+    hinfo, his = host.create("histogram_source", components=0x70, level_mode=2, level_ratio_value=12.5,
+                             graticule_horizontal_step_ratio=2.5)
     for info_, obj in ((winfo, wvs), (hinfo, his)):
         host.L.roi_register_source(roi, host.L.scope_host_cm(obj))
         info_.video_tick(obj, 0.0)
@@ -339,9 +346,10 @@ def run_host_checks(host, oracle, w=96, h=40):
     crop = oracle.stage_region(target, tw, 3, x0, y0, x1 - x0, y1 - y0)
     crop_yuv = oracle.rgb_to_yuv(crop, x1 - x0, 2)
     assert np.array_equal(host.wvs_table(wvs), oracle.waveform(crop, crop_yuv, x1 - x0, 0x07))
-    want_f, want_hi = oracle.histogram(crop, crop_yuv, x1 - x0, 0x70)
+    want_f, want_hi = oracle.histogram(crop, crop_yuv, x1 - x0, 0x70, level_ratio=125)
     got_f, got_hi = host.his_table(his)
     assert np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32)) and got_hi == list(want_hi)
+    assert got_hi == [(x1 - x0) * (y1 - y0) * 125 // 1000] * 3
     for obj in (wvs, his):
         host.L.roi_unregister_source(roi, host.L.scope_host_cm(obj))
     for info_, obj in ((winfo, wvs), (hinfo, his), (roi_info, roi)):

@@ -285,6 +285,13 @@ def check_surface_waveform_feeds_histogram(ctx, oracle, w, h):
     assert st == 0 and np.array_equal(hi, want_hi) and np.array_equal(f.view(np.uint32), want_f.view(np.uint32))
     cnt, st = ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w, components=0x70)  # another plane: its own pass
     assert_same(cnt, oracle.histogram_counts(rgb, yuv, w, 0x70), "dock histogram YUV")
+    # the side table belongs to the geometry it was counted on: the same plane pointer with another width is NOT served
+    # from it (it used to be, with SCOPE_OK and stale counts) but refused like any geometry change inside begin/end
+    try:
+        _, st = ctx.histogram_counts(rgb=rgb, yuv=yuv, width=w // 2, components=0x07)
+    except Exception as e:  # noqa: BLE001
+        st = getattr(e, "status", None)
+    assert st == -22, f"histogram of another geometry inside scope_surface_begin/end: status {st}"
     assert ctx.surface_end() == (2, 4)  # RGB and YUV uploaded once; four histogram calls served without an upload
 
 
