@@ -63,7 +63,8 @@ struct ScopeTuning {
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
 	int wvs_wide;        /* 1: 8-byte texel-pair loads where width and alignment allow; 0: always 4-byte */
 	int wvs_deep;        /* 1: batches keep WVS_DEEP_SETS more loads in flight across each unit's flush */
-	int dock;            /* 1: scope_three_scopes_batch reads small launches once (scope_dock_kernel); 0: always two passes */
+	int dock;            /* scope_three_scopes_batch: 1 = one read for any launch (scope_trio_kernel); 2 = round 2's form, one read
+			      * for launches of one round of strips only (scope_dock_kernel), two passes otherwise; 0 = always two passes */
 	int wvs_strip;       /* 0: 16-column strips for launches that would otherwise need row bands, 64 elsewhere; 64 / 16: always */
 	int nt_loads;        /* 1: non-temporal pixel loads */
 };
@@ -134,6 +135,16 @@ uint32_t scope_wvs_strips(uint32_t width, int narrow);
 bool scope_dock_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, uint32_t num_cu, const ScopeTuning &tn);
 hipError_t scope_launch_dock(const ScopeFrameSet &fs, uint32_t chmask, int colorspace, uint8_t *wvs_dst, const ScopeHisSink *his,
 			     uint8_t *vss_part, uint8_t *vss_mask, hipStream_t st, const ScopeTiming *tm = NULL);
+
+/* The same three tables from ONE read for any number of frames (scope_trio_kernel): both the vectorscope's table and a
+ * one-replica waveform table of a 16-column strip are resident in LDS, a workgroup streams the strips of one slice of one
+ * frame.  slices = scope_trio_slices(fs, num_cu) workgroups per frame; slices == 1: vss_dst = the final uint8[n][65536]
+ * tables, vss_mask unused; else vss_dst / vss_mask = sparse partials as scope_launch_vss writes them with 1024 mask bytes
+ * per slice, for scope_launch_sat_reduce_sparse.  Where scope_trio_fits says so (vector shape, height <= 4080). */
+bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const ScopeTuning &tn);
+uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu);
+hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int colorspace, uint8_t *wvs_dst,
+			     const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st, const ScopeTiming *tm = NULL);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
  * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */

@@ -65,6 +65,17 @@ __device__ __forceinline__ scope_u2 scope_load_row2_nt(const unsigned char *row,
 	return __builtin_nontemporal_load((const __attribute__((address_space(1))) scope_u2 *)(base + lane_off));
 }
 
+/* ... and the same as a plain (cacheable) load: lines a partner workgroup on the same XCD will want stay in the L2. */
+__device__ __forceinline__ scope_u2 scope_load_row2(const unsigned char *row, unsigned lane_off)
+{
+	typedef const __attribute__((address_space(1))) unsigned char *gptr;
+	const unsigned long long a = (unsigned long long)row;
+	const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+	const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+	gptr base = (gptr)(((unsigned long long)hi << 32) | lo);
+	return *(const __attribute__((address_space(1))) scope_u2 *)(base + lane_off);
+}
+
 /* v_perm_b32: byte i of the result is byte sel[i] of the 8 bytes {hi (4..7), lo (0..3)}; 0x0c gives 0x00, 0x0d gives 0xff. */
 __device__ __forceinline__ unsigned scope_perm(unsigned hi, unsigned lo, unsigned sel)
 {
