@@ -300,8 +300,9 @@ class Ctl:
 class Workload:
     """One scope workload over a pool of HBM-resident frames, `n` frames per step, rotating through the pool."""
 
-    def __init__(self, torch, ctx, wl, rgb, yuv, w, h, n, components=0x07):
+    def __init__(self, torch, ctx, wl, rgb, yuv, w, h, n, components=0x07, side_reduce=False):
         self.torch, self.ctx, self.wl, self.w, self.h, self.n, self.comp = torch, ctx, wl, w, h, n, components
+        self.side = side_reduce  # vectorscope only: SCOPE_SIDE_REDUCE, the reduction of call i under the accumulation of call i + 1
         pool = rgb.shape[0]
         dev = rgb.device
         self.groups = pool // n
@@ -324,7 +325,7 @@ class Workload:
         ctx, b, buf = self.ctx, self.batches[i % self.groups], i & 1
         wl = self.wl
         if wl in ("vectorscope", "vectorscope_rgb"):
-            ctx.vectorscope_batch_dev(b, self.tables[buf], sync=False)
+            ctx.vectorscope_batch_dev(b, self.tables[buf], sync=False, side_reduce=self.side)
         elif wl == "waveform":
             ctx.waveform_batch_dev(b, self.comp, self.tables[buf], sync=False)
         elif wl == "histogram":
@@ -332,6 +333,11 @@ class Workload:
         else:
             ctx.three_scopes_batch_dev(b, self.comp, self.comp, self.vss[buf], self.wvs[buf], self.his[buf], sync=False)
         self.last = (i % self.groups, buf)
+
+    def finish(self):
+        """What a host does before it reads a table of a side_reduce call: the context's stream waits for the side stream."""
+        if self.side:
+            self.ctx.fence()
 
     def check(self, o, rgb, yuv, np, frames=None):
         """Tables of the most recent step against the oracle (frames: indices inside the step's batch)."""
@@ -352,7 +358,7 @@ class Workload:
         return ok
 
 
-def timed_run(dev, ctl, ctx, stream, step, steps, warmup, settle_s, min_s, multi=False):
+def timed_run(dev, ctl, ctx, stream, step, steps, warmup, settle_s, min_s, multi=False, finish=None):
     """settle -> warm-up -> EXACTLY `steps` steps between barrier + synchronize -> at least min_s more of the same ->
     a short leg with the accumulation kernel bracketed by its own begin/end stamps.
     Loops that run 'for so many seconds' run the SAME number of steps on every rank (a step may hold a collective, and a
@@ -379,6 +385,8 @@ def timed_run(dev, ctl, ctx, stream, step, steps, warmup, settle_s, min_s, multi
     t0 = time.perf_counter()
     for j in range(steps):
         step(j)
+    if finish:
+        finish()
     dev.sync()
     ctl.barrier()
     elapsed = time.perf_counter() - t0
@@ -394,6 +402,8 @@ def timed_run(dev, ctl, ctx, stream, step, steps, warmup, settle_s, min_s, multi
         if not go_on(time.perf_counter() - t1 < min_s):
             break
     host_s = time.perf_counter() - t1
+    if finish:
+        finish()
     e1.record(stream)
     dev.sync()
     sustained = {"seconds": round(time.perf_counter() - t1, 3), "steps": s_steps,
@@ -408,35 +418,33 @@ def timed_run(dev, ctl, ctx, stream, step, steps, warmup, settle_s, min_s, multi
     return elapsed, sustained, launches, kernel_ms
 
 
-def place_pool(dev, ctx, frames, probe, candidates, good_us=0.0):
+def kernel_us(ctx, fn, warm=12, reps=24):
+    """Average duration of the accumulation kernel fn() launches: the kernel's own begin / end stamps."""
+    for _ in range(warm):
+        fn()
+    ctx.sync()
+    ctx.profile(True)
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    nl, ms = ctx.kernel_ms()
+    ctx.profile(False)
+    return round(ms / max(nl, 1) * 1e3, 2)
+
+
+def place_pool(torch, dev, ctx, frames, candidates, keep_alive):
     """WHERE a frame pool lies in HBM decides a few per cent of every streaming kernel's rate, and the first pools a
-    process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt).  A host
-    that keeps a long-lived pool can afford to look: allocate `candidates` copies, time the accumulation kernel on each
-    (its own begin/end stamps), keep the fastest and give the rest back; when none of them is as fast as `good_us`, up
-    to as many again are tried.  Untimed set-up, rank-local, no collective.  (The C-ABI offers the same to any host:
-    scope_frame_pool_alloc.)  Returns (the pool to use, kernel microseconds per candidate, index kept)."""
-    pools, us = [frames], []
-    k = 0
-    while k < candidates or (good_us and k < 2 * candidates and min(us) > good_us):
-        if k:
-            pools.append(frames.clone())
-        fn = probe(pools[k])
-        for _ in range(12):
-            fn()
-        ctx.sync()
-        ctx.profile(True)
-        for _ in range(24):
-            fn()
-        ctx.sync()
-        nl, ms = ctx.kernel_ms()
-        ctx.profile(False)
-        us.append(round(ms / max(nl, 1) * 1e3, 2))
-        k += 1
-    best = min(range(len(us)), key=lambda i: us[i])
-    keep = pools[best]
-    del pools
-    dev.empty_cache()
-    return keep, us, best
+    process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt).  The
+    product offers a host that keeps a long-lived pool a way to look before it settles -- scope_frame_pool_alloc:
+    `candidates` allocations held at once, each read with the accumulation kernel timed by its own stamps, the fastest
+    kept -- and this bench is such a host: the frames move into a pool the LIBRARY placed.  Untimed set-up, rank-local.
+    Returns (the frames in the placed pool, read GB/s per candidate with the kept one first)."""
+    pool, rates = ctx.frame_pool_alloc(frames.numel(), candidates)
+    keep_alive.append(pool)
+    placed = pool.tensor(torch, tuple(frames.shape))
+    placed.copy_(frames)
+    dev.sync()
+    return placed, rates
 
 
 class Overlap:
@@ -499,7 +507,7 @@ def code_only(src):
 def kernel_fingerprint():
     """sha256 of the kernel sources the library was built from: PMC traffic files are only believed for this build."""
     hsh = hashlib.sha256()
-    for f in ("scope_kernels.hip", "scope_kernels.h", "scope_vec.h", "scope_api.hip"):
+    for f in ("scope_kernels.hip", "scope_trio.hip", "scope_device.h", "scope_kernels.h", "scope_vec.h", "scope_api.hip"):
         with open(os.path.join(ROOT, "obs-color-monitor_amd", "csrc", f), "rb") as fh:
             hsh.update(code_only(fh.read()))
     return hsh.hexdigest()[:16]
@@ -576,6 +584,7 @@ def parse_args(argv=None):
                     help="let ranks share a GPU when there are fewer GPUs than ranks (the table sum then needs SCOPE_RCCL_LIBRARY "
                          "= tools/libshm_rccl_hip.so or --torch-reduce over gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
+    ap.add_argument("--lib", default=None, help="another build of libscope_hip.so (A/B of kernel variants; the line names it)")
     return ap.parse_args(argv)
 
 
@@ -614,7 +623,7 @@ def run_rank(args):
     from obs_color_monitor_amd.synth import make_frames, pad_pitch, punch_alpha_holes
 
     dev = Dev(torch, args, local_rank)
-    lib_path = os.path.join(ROOT, "tests", "emul", "libscope_emul.so") if dev.emul else None
+    lib_path = os.path.join(ROOT, "tests", "emul", "libscope_emul.so") if dev.emul else (os.path.abspath(args.lib) if args.lib else None)
     if dev.emul:
         os.environ.setdefault("SCOPE_RCCL_LIBRARY", os.path.join(ROOT, "tests", "emul", "libshm_rccl_emul.so"))
     multi = world > 1
@@ -641,7 +650,7 @@ def run_rank(args):
         ctx.set_option(k, int(v))
     info = ctx.device_info()
     o = scope_oracle.COracle()
-    plain = not args.option and args.dist == "uniform" and args.components == 0x07 and not args.geometry
+    plain = not args.option and args.dist == "uniform" and args.components == 0x07 and not args.geometry and not args.lib
 
     if args.workload == "stream":
         from bench_stream import stream_leg
@@ -672,7 +681,7 @@ def run_rank(args):
     wl = args.workload
     rgb, yuv = make_frames(torch, ctx, pool, w, h, args.dist, 0x9E3779B9 + rank, device=dev.device)
     dev.sync()
-    placement = None
+    placement, pools = None, []
     if args.placement_candidates > 1 and not dev.emul:
         pn = min(pool, 64)  # the probe reads the whole pool (one launch takes at most 64 frames)
         ptab = torch.empty((pn, 65536), dtype=torch.uint8, device=dev.device)
@@ -681,22 +690,23 @@ def run_rank(args):
             b = ctx.make_device_batch(t[:pn], 4 * w, w, h, planes_are_rgb=False)
             return lambda: ctx.vectorscope_batch_dev(b, ptab, sync=False)
 
-        def probe_rgb(t):
-            b = ctx.make_device_batch(t[:pn], 4 * w, w, h, planes_are_rgb=True, colorspace=2)
-            return lambda: ctx.histogram_counts_batch_dev(b, 0x07, ptab.view(-1)[:pn * 4096], sync=False)
-
-        # "as fast as a well-placed pool": 0.84 of the HBM peak for the probe's bytes (the kernels reach 0.85 there)
-        # (full-size launches of the headline's kernel only: a probe of fewer than 64 frames does not reach that rate anywhere)
-        good = (pn * (4 * w * h + 65536) / (0.84 * HBM_PEAK_GBPS * 1e9) * 1e6) if pn == 64 else 0.0
-        yuv, us_y, ky = place_pool(dev, ctx, yuv, probe_yuv, args.placement_candidates, good)
-        rgb, us_r, kr = place_pool(dev, ctx, rgb, probe_rgb, args.placement_candidates)
-        placement = {"candidates": args.placement_candidates,
-                     "yuv_pool_vectorscope_kernel_us": us_y, "yuv_pool_kept": ky,
-                     "rgb_pool_histogram_kernel_us": us_r, "rgb_pool_kept": kr,
-                     "first_allocation_frac": round(pn * (4 * w * h + 65536) / (us_y[0] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-                     "what": "copies of the frame pool allocated one after the other, the accumulation kernel timed on each "
-                             "(own begin/end stamps), the fastest kept, the others freed; as many again when none reads at 0.84 of "
-                             "peak: untimed set-up (DESIGN.md section 5)"}
+        # the headline kernel on the pool as this process first allocated it, then on the pool the library placed
+        us_first = kernel_us(ctx, probe_yuv(yuv))
+        yuv_first = yuv
+        yuv, rates_y = place_pool(torch, dev, ctx, yuv_first, args.placement_candidates, pools)
+        del yuv_first
+        rgb_first = rgb
+        rgb, rates_r = place_pool(torch, dev, ctx, rgb_first, args.placement_candidates, pools)
+        del rgb_first
+        dev.empty_cache()
+        us_placed = kernel_us(ctx, probe_yuv(yuv))
+        probe_bytes = pn * (4 * w * h + 65536)
+        placement = {"candidates": args.placement_candidates, "by": "scope_frame_pool_alloc (C-ABI): candidates held at once, each read "
+                     "by the vectorscope accumulation kernel timed with its own begin/end stamps, the fastest kept, the rest freed; untimed set-up",
+                     "yuv_pool_read_gbps": rates_y, "rgb_pool_read_gbps": rates_r,
+                     "vectorscope_kernel_us_first_allocation": us_first, "vectorscope_kernel_us_placed_pool": us_placed,
+                     "first_allocation_frac": round(probe_bytes / (us_first * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "placed_frac": round(probe_bytes / (us_placed * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
         del ptab
     work = Workload(torch, ctx, wl, rgb, yuv, w, h, n, args.components)
     table_bytes = work.tbytes
@@ -851,6 +861,7 @@ def run_rank(args):
             "device": info["name"],
             "compute_units": info["compute_units"],
             "options": args.option,
+            "library": args.lib or "obs-color-monitor_amd/libscope_hip.so",
             "kernel_sources_sha256_16": kernel_fingerprint(),
         },
         "roofline": rf,
@@ -874,18 +885,24 @@ def run_rank(args):
         # the reference's call shape: one surface per callback, ring of three
         latency = {}
         for nf in (1, 3):
-            for v in ("vectorscope", "vectorscope_rgb", "histogram", "waveform", "three_scope"):
-                lw = Workload(torch, ctx, v, rgb[:24], yuv[:24], w, h, nf, 0x07)
-                el, sus, ln, kms = timed_run(dev, ctl, ctx, stream, lw.step, 200, 50, 0.15, 0.3)
+            for v in ("vectorscope", "vectorscope_rgb", "histogram", "waveform", "three_scope", "vectorscope+side", "vectorscope_rgb+side"):
+                base, side = v.split("+")[0], v.endswith("+side")
+                lw = Workload(torch, ctx, base, rgb[:24], yuv[:24], w, h, nf, 0x07, side_reduce=side)
+                el, sus, ln, kms = timed_run(dev, ctl, ctx, stream, lw.step, 200, 50, 0.15, 0.3, finish=lw.finish)
                 lw.step(0)
+                lw.finish()
                 dev.sync()
                 ok = lw.check(o, rgb, yuv, np, frames=[nf - 1])
                 us = sus["ms_per_step"] * 1e3
-                latency[f"{v}_x{nf}"] = {
+                latency[f"{base}_x{nf}" + ("_side_reduce" if side else "")] = {
                     "frames_per_call": nf, "us_per_call": round(us, 2), "us_host_enqueue_per_call": round(sus["host_enqueue_ms_per_step"] * 1e3, 2),
                     "us_accumulation_kernel": round(kms / ln * 1e3, 2) if ln else None,
                     "gbps": round(lw.algo_bytes / (us * 1e-6) / 1e9, 1), "frac_of_peak": round(lw.algo_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                     "parity": bool(ok)}
+                if side:
+                    latency[f"{base}_x{nf}_side_reduce"]["what"] = (
+                        "SCOPE_SIDE_REDUCE: the partial-table reduction of call i on the context's second stream, under the accumulation "
+                        "of call i + 1; tables complete after scope_ctx_fence (enqueued once, at the end of the timed calls)")
                 del lw
         latency["note"] = ("us_per_call = stream time per call in steady state, calls back to back on one stream over 24 rotating "
                            "frames: every kernel of the call (accumulation + partial-table reduction) and the gaps between them, no "
@@ -952,6 +969,8 @@ def run_rank(args):
         ctx.rccl_comm_destroy(comm)
     if overlap:
         overlap.ctx.close()
+    for fp in pools:
+        fp.free()
     ctx.close()
     if multi:
         ctl.barrier()

@@ -51,6 +51,13 @@ extern "C" {
 #define SCOPE_OUT_PACKED16 0x10u /* scope_vectorscope_batch with SCOPE_OUT_DEVICE: out = uint32[n][32768], two bins per
 			       * word (lo | hi << 16) -- the wire format of the multi-GPU table sum, saving the
 			       * scope_table_pack_u8_u16x2 pass */
+#define SCOPE_SIDE_REDUCE 0x20u /* scope_vectorscope_batch with SCOPE_ASYNC: where the launch needs a partial-table reduction (few
+				 * frames per call: the reference's call shape, src/common.c:366-368) that reduction is enqueued on
+				 * a SECOND stream of the context, ordered behind the accumulation by an event, and the context's
+				 * stream is free for the next call at once: the reduction of call i runs under the accumulation of
+				 * call i + 1 (two sets of partial tables).  The output table of such a call is complete only after
+				 * scope_ctx_fence() (no host synchronisation), scope_ctx_sync(), or the next call on the context
+				 * without this flag -- which fences first. */
 
 /* ---- component masks, identical to the reference ------------------------------------------- */
 #define SCOPE_COMP_RGB 0x07u /* src/waveform.c:26, src/histogram.c:27 */
@@ -103,6 +110,9 @@ void scope_ctx_destroy(scope_ctx *ctx);
 int scope_ctx_set_stream(scope_ctx *ctx, void *hip_stream);
 void *scope_ctx_get_stream(scope_ctx *ctx);
 int scope_ctx_sync(scope_ctx *ctx);
+/* Makes the context's stream wait (on the device: an event, no host synchronisation) for whatever SCOPE_SIDE_REDUCE calls
+ * still have on the context's second stream.  After it, work enqueued on the context's stream sees their tables. */
+int scope_ctx_fence(scope_ctx *ctx);
 int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
 /* Tunables for A/B measurements (the defaults are the measured best, profiles/):
  *   "vss.merge" 0|2|3        plain adds | absorb mode always | absorb mode by wave vote
@@ -353,6 +363,23 @@ int scope_table_allreduce(scope_ctx *ctx, void *rccl_comm, uint32_t *words, uint
  * numbers so that a line says how many ranks RCCL saw, not how many were asked for.
  * The environment variable SCOPE_RCCL_LIBRARY (a path or soname) names the library to bind instead of the ROCm librccl. */
 int scope_rccl_comm_info(void *rccl_comm, int *n_ranks, int *rank, int *version);
+
+/* ---- frame pools ----------------------------------------------------------------------------
+ * Where a long-lived pool of frames lies in HBM decides a few per cent of every streaming kernel's rate on this chip
+ * (allocations come in fast and slow physical ranges, +-2.5 %, and the first ones a process makes
+ * are regularly the slow ones).  A host that keeps frames resident -- a ring of staged surfaces, a batch it reduces again
+ * and again -- can let the library look before it settles: scope_frame_pool_alloc makes up to `candidates` device
+ * allocations of `bytes` (all held at the same time: candidates x bytes of HBM for a few milliseconds), reads each with the
+ * vectorscope accumulation kernel itself (the bytes taken as frames; timed by the kernel's own begin / end stamps), keeps the
+ * fastest and frees the rest.
+ * candidates <= 1 is a plain allocation.  read_gbps (optional, room for `candidates` floats) receives the measured rates,
+ * the kept allocation's first; *tried (optional) how many were made (fewer than asked for when memory ran out).  The
+ * pool is ordinary device memory (use it with SCOPE_IN_DEVICE); give it back with scope_frame_pool_free.
+ * The reference has no counterpart (its frames live in libobs textures); this replaces nothing in it. */
+#define SCOPE_POOL_MAX_CANDIDATES 16
+int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **pool, float *read_gbps,
+			   uint32_t *tried);
+int scope_frame_pool_free(scope_ctx *ctx, void *pool);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * With profiling on, every accumulation launch (the dominant kernel of a call, not the small

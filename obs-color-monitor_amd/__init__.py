@@ -9,4 +9,4 @@ The directory name carries the reference's hyphen; `import obs_color_monitor_amd
 repo root) resolves to this package.
 """
 from .scope_hip import *  # noqa: F401,F403
-from .scope_hip import ScopeContext, ScopeError, ScopePipe, load_library, DEFAULT_LIB, ABI_SYMBOLS  # noqa: F401
+from .scope_hip import FramePool, ScopeContext, ScopeError, ScopePipe, load_library, DEFAULT_LIB, ABI_SYMBOLS  # noqa: F401

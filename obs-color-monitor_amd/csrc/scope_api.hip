@@ -29,6 +29,15 @@ struct scope_ctx {
 	size_t partial_bytes;
 	uint8_t *pmask; /* which 16-bin groups of the vectorscope's sparse partials were written */
 	size_t pmask_bytes;
+	/* SCOPE_SIDE_REDUCE: a second stream that carries the partial-table reductions, two sets of partial tables used in
+	 * turn, and the events that order them: acc_done[k] (the accumulation has filled set k, recorded on `stream`),
+	 * side_done[k] (the reduction has read set k, recorded on `side`) */
+	hipStream_t side;
+	uint8_t *side_partial[2], *side_pmask[2];
+	size_t side_partial_bytes[2], side_pmask_bytes[2];
+	hipEvent_t acc_done[2], side_done[2];
+	bool side_busy[2], side_pending;
+	uint32_t side_slot;
 	uint32_t *his_acc; /* SCOPE_MAX_FRAMES x 1024 accumulators of the histogram's in-launch combine; zero between launches */
 	uint8_t *stage_in; /* host planes uploaded here */
 	size_t stage_in_bytes;
@@ -247,10 +256,25 @@ int resolve_region(uint32_t width, uint32_t height, const struct scope_region *r
 	return SCOPE_OK;
 }
 
+/* The context's stream waits for the side stream's outstanding reductions (device-side: one event). */
+int side_fence(scope_ctx *ctx)
+{
+	if (!ctx->side_pending)
+		return SCOPE_OK;
+	const uint32_t k = ctx->side_slot & 1u; /* the most recent reduction; the side stream runs them in order */
+	HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done[k], 0));
+	ctx->side_pending = false;
+	return SCOPE_OK;
+}
+
 int check_flags(scope_ctx *ctx, uint32_t flags)
 {
 	if ((flags & SCOPE_ASYNC) && (flags & (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE)) != (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE))
 		return fail(ctx, SCOPE_EINVAL, "SCOPE_ASYNC needs device input and output", hipSuccess);
+	if ((flags & SCOPE_SIDE_REDUCE) && !(flags & SCOPE_ASYNC))
+		return fail(ctx, SCOPE_EINVAL, "SCOPE_SIDE_REDUCE needs SCOPE_ASYNC", hipSuccess);
+	if (!(flags & SCOPE_SIDE_REDUCE))
+		return side_fence(ctx); /* a call without the flag sees every earlier table complete */
 	return SCOPE_OK;
 }
 
@@ -351,6 +375,28 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 		const uint32_t mask_block = ctx->tn.vss_sparse ? scope_vss_mask_block(ctx->tn) : 0u;
 		if (slices == 1 && !packed) {
 			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, NULL, ctx->tn, ctx->stream, tm_));
+		} else if ((flags & SCOPE_SIDE_REDUCE) && mask_block) {
+			/* the accumulation on the context's stream, its reduction on the side stream: the next call's accumulation does
+			 * not wait for it (it fills the OTHER set of partial tables) */
+			const uint32_t k = (ctx->side_slot += 1u) & 1u;
+			if ((size_t)nf * slices * SCOPE_VSS_BINS > ctx->side_partial_bytes[k] || (size_t)nf * slices * mask_block > ctx->side_pmask_bytes[k])
+				HIP_TRY(ctx, hipStreamSynchronize(ctx->side)); /* grow() frees: nothing of the side stream may still read the set */
+			st = grow(ctx, &ctx->side_partial[k], &ctx->side_partial_bytes[k], (size_t)nf * slices * SCOPE_VSS_BINS);
+			if (!st)
+				st = grow(ctx, &ctx->side_pmask[k], &ctx->side_pmask_bytes[k], (size_t)nf * slices * mask_block);
+			if (st)
+				return st;
+			if (ctx->side_busy[k]) /* the reduction that last read this set (two calls ago) must be through */
+				HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done[k], 0));
+			TIMED_LAUNCH(ctx, scope_launch_vss(fs, slices, fuse, colorspace, ctx->side_partial[k], ctx->side_pmask[k], ctx->tn,
+							   ctx->stream, tm_));
+			HIP_TRY(ctx, hipEventRecord(ctx->acc_done[k], ctx->stream));
+			HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->acc_done[k], 0));
+			HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->side_partial[k], ctx->side_pmask[k], dst, nf, slices, mask_block, packed,
+								    ctx->side));
+			HIP_TRY(ctx, hipEventRecord(ctx->side_done[k], ctx->side));
+			ctx->side_busy[k] = true;
+			ctx->side_pending = true;
 		} else {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * SCOPE_VSS_BINS);
 			if (!st && mask_block)
@@ -455,35 +501,59 @@ int run_waveform(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint3
 	return SCOPE_OK;
 }
 
-/* The dock's three scopes from ONE read of device-resident RGB planes (scope_dock_kernel): 1 = done (enqueued, and waited
- * for unless SCOPE_ASYNC), 0 = this launch does not qualify (the caller runs the separate passes), < 0 = error.
- * cw / ch: the waveform's and the histogram's RGB channel masks, ch a subset of cw. */
+/* The dock's three scopes from ONE read of device-resident RGB planes: 1 = done (enqueued, and waited for unless
+ * SCOPE_ASYNC), 0 = this launch does not qualify (the caller runs the separate passes), < 0 = error.
+ * cw / ch: the waveform's and the histogram's RGB channel masks, ch a subset of cw.
+ * dock = 1 (default): scope_trio_kernel -- both tables resident in LDS, any number of frames per launch, one vectorscope
+ * partial per slice; dock = 2: round 2's scope_dock_kernel where one round of strips covers the launch (else not done). */
 int run_dock(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t linesize, uint32_t width, uint32_t height,
 	     uint32_t cw, uint32_t ch, int colorspace, uint32_t flags, uint8_t *vss_out, uint8_t *wvs_out, uint32_t *his_counts)
 {
 	const uint32_t dev = SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE;
-	if (!ctx->tn.dock || (flags & dev) != dev || (flags & SCOPE_OUT_PACKED16) || !cw || (ch & ~cw) || !width || !height ||
-	    n == 0 || n > SCOPE_MAX_FRAMES)
+	if (!ctx->tn.dock || (flags & dev) != dev || (flags & SCOPE_OUT_PACKED16) || !cw || (ch & ~cw) || !width || !height || n == 0)
 		return 0;
 	int st = check_geometry(ctx, linesize, width, height);
 	if (st)
 		return st;
-	ScopeFrameSet fs;
-	st = stage_planes(ctx, planes, n, linesize, width, height, flags, &fs);
-	if (st)
-		return st;
-	if (!scope_dock_fits(fs, wvs_out, (uint32_t)ctx->num_cu, ctx->tn))
-		return 0;
-	const uint32_t strips = scope_wvs_strips(width, 1), mask_block = SCOPE_BLOCK;
-	st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)n * strips * SCOPE_VSS_BINS);
-	if (!st)
-		st = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)n * strips * mask_block);
-	if (st)
-		return st;
-	const ScopeHisSink sink = {ctx->his_acc, ctx->tickets, his_counts, ch};
-	TIMED_LAUNCH(ctx, scope_launch_dock(fs, cw, colorspace, wvs_out, his_counts ? &sink : NULL, ctx->partial, ctx->pmask, ctx->stream,
-					    tm_));
-	HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, vss_out, n, strips, mask_block, 0, ctx->stream));
+	const uint32_t mask_block = SCOPE_BLOCK;
+	const size_t wvs_table = (size_t)SCOPE_WV_SIZE * width * 4;
+	bool launched = false;
+	for (uint32_t f0 = 0; f0 < n; f0 += SCOPE_MAX_FRAMES) {
+		const uint32_t nf = (n - f0 < SCOPE_MAX_FRAMES) ? n - f0 : SCOPE_MAX_FRAMES;
+		ScopeFrameSet fs;
+		st = stage_planes(ctx, planes + f0, nf, linesize, width, height, flags, &fs);
+		if (st)
+			return st;
+		uint8_t *wvs_dst = wvs_out + (size_t)f0 * wvs_table;
+		uint8_t *vss_dst = vss_out + (size_t)f0 * SCOPE_VSS_BINS;
+		uint32_t *his_dst = his_counts ? his_counts + (size_t)f0 * SCOPE_HIS_WORDS : NULL;
+		const ScopeHisSink sink = {ctx->his_acc, ctx->tickets, his_dst, ch};
+		const bool old_form = ctx->tn.dock == 2;
+		if (old_form ? !scope_dock_fits(fs, wvs_dst, (uint32_t)ctx->num_cu, ctx->tn) : !scope_trio_fits(fs, wvs_dst, ctx->tn)) {
+			if (launched) /* cannot happen: every chunk has the same geometry and table alignment */
+				return fail(ctx, SCOPE_EINVAL, "three scopes: chunks of one call disagree on the launch shape", hipSuccess);
+			return 0;
+		}
+		const uint32_t slices = old_form ? scope_wvs_strips(width, 1) : scope_trio_slices(fs, (uint32_t)ctx->num_cu);
+		const bool partials = slices > 1 || old_form; /* scope_dock_kernel always writes a sparse partial per strip */
+		if (partials) {
+			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * SCOPE_VSS_BINS);
+			if (!st)
+				st = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)nf * slices * mask_block);
+			if (st)
+				return st;
+		}
+		if (old_form) {
+			TIMED_LAUNCH(ctx, scope_launch_dock(fs, cw, colorspace, wvs_dst, his_dst ? &sink : NULL, ctx->partial, ctx->pmask,
+							    ctx->stream, tm_));
+		} else {
+			TIMED_LAUNCH(ctx, scope_launch_trio(fs, slices, cw, colorspace, wvs_dst, his_dst ? &sink : NULL,
+							    slices > 1 ? ctx->partial : vss_dst, ctx->pmask, ctx->stream, tm_));
+		}
+		if (partials)
+			HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, vss_dst, nf, slices, mask_block, 0, ctx->stream));
+		launched = true;
+	}
 	if (!(flags & SCOPE_ASYNC))
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return 1;
@@ -671,6 +741,10 @@ int scope_ctx_create(int device, scope_ctx **out)
 	}
 	ctx->stream = ctx->own_stream;
 	bool ok = scope_kernels_init() == hipSuccess;
+	ok = ok && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
+	for (int k = 0; ok && k < 2; k++)
+		ok = hipEventCreateWithFlags(&ctx->acc_done[k], hipEventDisableTiming) == hipSuccess &&
+		     hipEventCreateWithFlags(&ctx->side_done[k], hipEventDisableTiming) == hipSuccess;
 	const size_t acc_bytes = (size_t)SCOPE_MAX_FRAMES * SCOPE_HIS_WORDS * sizeof(uint32_t);
 	ok = ok && hipMalloc((void **)&ctx->tickets, SCOPE_MAX_FRAMES * sizeof(uint32_t)) == hipSuccess &&
 	     hipMemsetAsync(ctx->tickets, 0, SCOPE_MAX_FRAMES * sizeof(uint32_t), ctx->stream) == hipSuccess &&
@@ -721,6 +795,20 @@ void scope_ctx_destroy(scope_ctx *ctx)
 		(void)hipFree(ctx->his_acc);
 	if (ctx->pmask)
 		(void)hipFree(ctx->pmask);
+	if (ctx->side)
+		(void)hipStreamSynchronize(ctx->side);
+	for (int k = 0; k < 2; k++) {
+		if (ctx->side_partial[k])
+			(void)hipFree(ctx->side_partial[k]);
+		if (ctx->side_pmask[k])
+			(void)hipFree(ctx->side_pmask[k]);
+		if (ctx->acc_done[k])
+			(void)hipEventDestroy(ctx->acc_done[k]);
+		if (ctx->side_done[k])
+			(void)hipEventDestroy(ctx->side_done[k]);
+	}
+	if (ctx->side)
+		(void)hipStreamDestroy(ctx->side);
 	for (int k = 0; k < 2; k++)
 		if (ctx->surf.dev[k])
 			(void)hipFree(ctx->surf.dev[k]);
@@ -737,6 +825,8 @@ int scope_ctx_set_stream(scope_ctx *ctx, void *hip_stream)
 	if (st)
 		return st;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+	ctx->side_pending = ctx->side_busy[0] = ctx->side_busy[1] = false;
 	ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
 	return SCOPE_OK;
 }
@@ -752,7 +842,19 @@ int scope_ctx_sync(scope_ctx *ctx)
 	if (st)
 		return st;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->side_pending || ctx->side_busy[0] || ctx->side_busy[1]) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+		ctx->side_pending = ctx->side_busy[0] = ctx->side_busy[1] = false;
+	}
 	return SCOPE_OK;
+}
+
+int scope_ctx_fence(scope_ctx *ctx)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	return side_fence(ctx);
 }
 
 int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info)
@@ -813,7 +915,7 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 	else if (!strcmp(key, "wvs.deep"))
 		ctx->tn.wvs_deep = value != 0;
 	else if (!strcmp(key, "dock"))
-		ctx->tn.dock = value != 0;
+		ctx->tn.dock = value < 0 ? 0 : (value > 2 ? 1 : value);
 	else if (!strcmp(key, "slices"))
 		ctx->slices_override = value;
 	else
@@ -1296,6 +1398,114 @@ int scope_table_unpack_clamp_u16x2_u8(scope_ctx *ctx, const uint32_t *in, uint8_
 	if (!in || !out)
 		return SCOPE_EINVAL;
 	HIP_TRY(ctx, scope_launch_unpack16_clamp(in, out, n_pairs, ctx->stream));
+	return SCOPE_OK;
+}
+
+/* ---- frame pools: WHERE in HBM a long-lived pool lies decides a few per cent of every streaming kernel's rate ---------- */
+int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **pool, float *read_gbps,
+			   uint32_t *tried)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if (!pool || bytes == 0)
+		return fail(ctx, SCOPE_EINVAL, "scope_frame_pool_alloc: NULL pool or zero bytes", hipSuccess);
+	*pool = NULL;
+	if (tried)
+		*tried = 0;
+	if (candidates == 0)
+		candidates = 1;
+	if (candidates > SCOPE_POOL_MAX_CANDIDATES)
+		candidates = SCOPE_POOL_MAX_CANDIDATES;
+	/* All candidates are held at once (freeing one and allocating again hands out the same virtual range over OTHER
+	 * physical memory, fast or slow: profiles/round2/placement2_r2f.txt).  Each is read a few times by the kernel the pool
+	 * is for -- the vectorscope accumulation itself, the pool taken as up to 64 "frames" of 4 KiB rows (any bytes are
+	 * pixels) -- timed by the kernel's own begin / end stamps; the fastest stays.  (A plain streaming-read kernel was tried
+	 * as the yardstick first: its ranking of four candidates did not predict the accumulation kernel's, profiles/round3.) */
+	void *cand[SCOPE_POOL_MAX_CANDIDATES] = {NULL};
+	float rate[SCOPE_POOL_MAX_CANDIDATES] = {0};
+	hipEvent_t ev[2] = {NULL, NULL};
+	int rc = SCOPE_OK;
+	uint32_t n = 0, best = 0;
+	if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)
+		rc = fail(ctx, SCOPE_EIO, "hipEventCreate", hipGetLastError());
+	ScopeFrameSet fs;
+	memset(&fs, 0, sizeof fs);
+	fs.linesize = 4096;
+	fs.width = 1024;
+	fs.n_frames = bytes >= ((uint64_t)SCOPE_MAX_FRAMES << 20) ? SCOPE_MAX_FRAMES : (uint32_t)((bytes >> 20) ? (bytes >> 20) : 1);
+	uint64_t frame_bytes = (bytes / fs.n_frames) & ~(uint64_t)4095;
+	if (frame_bytes >= (1ull << 31))
+		frame_bytes = (1ull << 31) - 4096; /* 32-bit offsets inside a slice's span: a huge pool is probed on its first 128 GiB */
+	fs.height = (uint32_t)(frame_bytes / 4096);
+	const uint64_t probe_bytes = (uint64_t)fs.n_frames * fs.height * 4096;
+	uint32_t slices = pick_slices(ctx, fs.n_frames, 1);
+	const uint32_t mask_block = ctx->tn.vss_sparse ? scope_vss_mask_block(ctx->tn) : 0u;
+	if (rc == SCOPE_OK && candidates > 1 && probe_bytes) {
+		rc = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)fs.n_frames * slices * SCOPE_VSS_BINS);
+		if (rc == SCOPE_OK && mask_block)
+			rc = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)fs.n_frames * slices * mask_block);
+	}
+	for (; rc == SCOPE_OK && n < candidates; n++) {
+		const hipError_t e = hipMalloc(&cand[n], (size_t)bytes);
+		if (e != hipSuccess) {
+			cand[n] = NULL;
+			if (n == 0)
+				rc = fail(ctx, SCOPE_ENOMEM, "hipMalloc (frame pool)", e);
+			break; /* fewer candidates than asked for: the best of those there are */
+		}
+		if (candidates == 1 || probe_bytes == 0)
+			continue; /* nothing to compare */
+		for (uint32_t f = 0; f < fs.n_frames; f++)
+			fs.plane[f] = (const uint8_t *)cand[n] + (size_t)f * frame_bytes;
+		const ScopeTiming tm = {ev[0], ev[1]};
+		float best_ms = 0.0f;
+		for (int rep = 0; rep < 8 && rc == SCOPE_OK; rep++) { /* three to warm up, the fastest of five counts */
+			if (scope_launch_vss(fs, slices, 0, 2, ctx->partial, (slices > 1 && mask_block) ? ctx->pmask : NULL, ctx->tn, ctx->stream,
+					     &tm) != hipSuccess ||
+			    hipEventSynchronize(ev[1]) != hipSuccess) {
+				rc = fail(ctx, SCOPE_EIO, "frame pool probe", hipGetLastError());
+				break;
+			}
+			float ms = 0.0f;
+			(void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+			if (rep >= 3 && ms > 0.0f && (best_ms == 0.0f || ms < best_ms))
+				best_ms = ms;
+		}
+		rate[n] = best_ms > 0.0f ? (float)((double)probe_bytes / ((double)best_ms * 1e-3) / 1e9) : 0.0f;
+		if (rate[n] > rate[best])
+			best = n;
+	}
+	if (rc == SCOPE_OK) {
+		*pool = cand[best];
+		cand[best] = NULL;
+		if (tried)
+			*tried = n;
+		if (read_gbps) {
+			/* the kept one first, then the others in the order they were tried */
+			read_gbps[0] = rate[best];
+			for (uint32_t i = 0, k = 1; i < n; i++)
+				if (i != best)
+					read_gbps[k++] = rate[i];
+		}
+	}
+	for (uint32_t i = 0; i < SCOPE_POOL_MAX_CANDIDATES; i++)
+		if (cand[i])
+			(void)hipFree(cand[i]);
+	if (ev[0])
+		(void)hipEventDestroy(ev[0]);
+	if (ev[1])
+		(void)hipEventDestroy(ev[1]);
+	return rc;
+}
+
+int scope_frame_pool_free(scope_ctx *ctx, void *pool)
+{
+	SCOPE_ENTER(ctx);
+	if (st)
+		return st;
+	if (pool && hipFree(pool) != hipSuccess)
+		return fail(ctx, SCOPE_EIO, "hipFree (frame pool)", hipGetLastError());
 	return SCOPE_OK;
 }
 

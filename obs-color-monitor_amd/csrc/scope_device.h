@@ -1,0 +1,360 @@
+/*
+ * scope_device.h -- device-side vocabulary shared by the kernel translation units (scope_kernels.hip, scope_trio.hip):
+ * K0 (fp32 definition + the 24-bit fixed-point fast path), the vectorscope's LDS table (bin key, swizzled address,
+ * absorb mode, clamp pass), the arrival ticket of the in-launch combines, the launch macro.  Internal to libscope_hip.so.
+ */
+#ifndef SCOPE_DEVICE_H
+#define SCOPE_DEVICE_H
+
+#include "scope_kernels.h"
+#include <hip/hip_ext.h>
+#include <type_traits>
+#include <scope_vec.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+/* All LDS scratch lives in the dynamic region so its base stays 16-byte aligned. */
+extern __shared__ __attribute__((aligned(16))) u32 scope_lds[];
+typedef u32 scope_v4 __attribute__((vector_size(16)));
+
+/* ------------------------------------------------------------------------------------------
+ * K0: per-texel RGB -> Y'CbCr, bit-exact with oracle/scope_oracle.c:k0_texel
+ * ---------------------------------------------------------------------------------------- */
+
+/* byte/255 correctly rounded to fp32 without a divide: fma(b, hi, b*lo) with hi+lo ~= 1/255
+ * (checked exhaustively for the 256 inputs in tests/test_k0_constants.py). */
+__device__ __forceinline__ float scope_unorm8(u32 byte)
+{
+	const float b = (float)byte;
+	return __fmaf_rn(b, 0x1.010102p-8f, __fmul_rn(b, -0x1.fdfdfep-33f));
+}
+
+/* FLOAT -> UNORM8 store rule pinned by the build: floor(clamp01(x)*255 + 0.5). */
+__device__ __forceinline__ u32 scope_k0_quantise(float x)
+{
+	x = fminf(fmaxf(x, 0.0f), 1.0f);
+	return (u32)__fadd_rn(__fmul_rn(x, 255.0f), 0.5f);
+}
+
+/* px bytes B,G,R,A -> bytes U,Y,V,255 (data/common.effect:23-43; the shader returns
+ * float4(V,Y,U,1) into a BGRA target).  need_uv / need_y are wave-uniform. */
+__device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool need_uv, bool need_y)
+{
+	const float b = scope_unorm8(px & 0xffu);
+	const float g = scope_unorm8((px >> 8) & 0xffu);
+	const float r = scope_unorm8((px >> 16) & 0xffu);
+	u32 out = 0xff000000u;
+	if (need_uv) {
+		/* U and V side by side in one 2-vector: the same operations in the same order on both halves,
+		 * so they issue as v_pk_mul_f32 / v_pk_add_f32 (no FMA: -ffp-contract=off).  V's "- 0" is exact. */
+		scope_f2 uv = scope_f2_make(k.ur, k.vr) * scope_f2_make(r, r);
+		uv = uv + scope_f2_make(k.ug, k.vg) * scope_f2_make(g, g);
+		uv = uv + scope_f2_make(k.ub, k.vb) * scope_f2_make(b, b);
+		uv = uv + scope_f2_make(0.5f, 0.5f);
+		uv = uv - scope_f2_make(0.00390625f, 0.0f);
+		out |= scope_k0_quantise(scope_f2_lo(uv)) | (scope_k0_quantise(scope_f2_hi(uv)) << 16);
+	}
+	if (need_y) {
+		float y = __fmul_rn(k.yr, r);
+		y = __fadd_rn(y, __fmul_rn(k.yg, g));
+		y = __fadd_rn(y, __fmul_rn(k.yb, b));
+		out |= scope_k0_quantise(y) << 8;
+	}
+	return out;
+}
+
+/* ---- the fast path ------------------------------------------------------------------------------
+ * The fp32 chain above costs ~33 VALU instructions per texel and makes every fused kernel VALU-bound.
+ * The value it approximates is T = c_r R + c_g G + c_b B + 255 off + 0.5 with output floor(T) (no clamp is
+ * ever active for 8-bit inputs), which three 24-bit integer multiply-adds give directly in 2^-24 fixed
+ * point: E = C_r R + C_g G + C_b B + K, and the output is byte 3 of E (chroma |c| < 0.5 fits v_mul_i32_i24,
+ * luma 0 <= c < 1 fits v_mul_u32_u24; the sum is taken mod 2^32 and ends below 256 * 2^24).  The two disagree
+ * only where T is within ~2.5e-5 of an integer, i.e. where fp32 rounding decides: an exhaustive run over all
+ * 2^24 colours, both matrices and all three rows finds every such colour within 422 units (2^-24) of a step.
+ * So K carries a guard of 512 units and a value whose fraction is below 1024 -- bytes 1..2 of E, read as a
+ * number, below 4 -- is "near a step": its cell is recomputed with the fp32 chain (a wave votes per cell;
+ * 6e-5 .. 1e-3 of all colours).  Two rows' fractions travel as the halves of one register (v_perm_b32) and the
+ * running minimum over a cell is a v_pk_min_u16.  Black is an exact tie (V = 128.0) on which both paths agree,
+ * and common (letterbox bars): cells that are black throughout are exempt.
+ * tests/test_parity_gpu.py runs all 2^24 colours through this code against the oracle. */
+__device__ __forceinline__ int scope_mad24(int a, int b, int c)
+{
+	return __mul24(a, b) + c; /* v_mad_i32_i24 */
+}
+
+__device__ __forceinline__ u32 scope_umad24(u32 a, u32 b, u32 c)
+{
+	return __umul24(a, b) + c; /* v_mad_u32_u24: the luma coefficients are positive and may exceed 0.5 */
+}
+
+#define SCOPE_K0_NEAR 4u /* 2 * SCOPE_K0_FX_GUARD >> 8 */
+
+/* The vectorscope's bin key of a Y'CbCr texel: U in byte 1, V in byte 2, bytes 0 and 3 zero (see vss_add). */
+__device__ __forceinline__ u32 vss_bin(u32 px)
+{
+	return scope_perm(0u, px, 0x0c02000cu);
+}
+
+/* One row of the matrix in 2^-24 fixed point: f[0] R + f[1] G + f[2] B + f[3] (mod 2^32), texel bytes B, G, R, A.
+ * Four instructions, the masked blue byte `b` is shared by the rows: two byte multiplies, a multiply-add, a 3-way add. */
+__device__ __forceinline__ u32 scope_k0_row(u32 px, int b, const int (&f)[4])
+{
+	return (u32)(scope_mad24(f[2], b, f[3]) + scope_mul24_byte1(px, f[1]) + scope_mul24_byte2(px, f[0]));
+}
+__device__ __forceinline__ u32 scope_k0_row_y(u32 px, u32 b, const int (&f)[4])
+{
+	return scope_umad24((u32)f[2], b, (u32)f[3]) + scope_umul24_byte1(px, (u32)f[1]) + scope_umul24_byte2(px, (u32)f[0]);
+}
+
+/* worst: running per-half minimum of the fractions' upper 16 bits.  VSSKEY: the result is the vectorscope's bin key
+ * (0, U, V, 0) instead of the texel (U, Y, V, 255) -- the same single v_perm_b32 with another selector. */
+template <bool VSSKEY>
+__device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool need_uv, bool need_y, u32 &worst)
+{
+	const u32 b = px & 0xffu;
+	u32 out = 0xff000000u;
+	if (need_uv) {
+		const u32 eu = scope_k0_row(px, (int)b, k.fu);
+		const u32 ev = scope_k0_row(px, (int)b, k.fv);
+		worst = scope_pk_min_u16(worst, scope_perm(ev, eu, 0x06050201u));
+		out = scope_perm(ev, eu, VSSKEY ? 0x0c07030cu : 0x0d070c03u); /* 0, U, V, 0 or U, 0, V, 255 */
+	}
+	if (need_y) {
+		const u32 ey = scope_k0_row_y(px, b, k.fy);
+		worst = scope_pk_min_u16(worst, scope_perm(ey, ey, 0x06050201u));
+		out = scope_perm(ey, out, 0x03020700u);
+	}
+	return out;
+}
+
+/* N texels of one lane, in place.  The votes are wave-wide: a cell is redone in fp32 by the whole wave when any
+ * lane holds a texel near a step (identical results for the other lanes, that is what the exhaustive test says).
+ * Cells that are black throughout are exempt (black is an exact tie both paths agree on); a black texel next to
+ * other colours just sends its cell to the fp32 path, which is as right as the fast one. */
+template <int N, bool VSSKEY = false>
+__device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, bool need_uv, bool need_y)
+{
+	u32 t[N], worst = 0xffffffffu;
+#pragma unroll
+	for (int j = 0; j < N; j++)
+		t[j] = scope_k0_fixed<VSSKEY>(p[j], k, need_uv, need_y, worst);
+	const bool near_step = min(worst & 0xffffu, worst >> 16) < SCOPE_K0_NEAR;
+	if (__ballot(near_step) != 0) { /* rare, except on black */
+		u32 any = 0;
+#pragma unroll
+		for (int j = 0; j < N; j++)
+			any |= p[j];
+		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
+#pragma unroll
+			for (int j = 0; j < N; j++) {
+				p[j] = scope_k0_texel(p[j], k, need_uv, need_y);
+				if (VSSKEY)
+					p[j] = vss_bin(p[j]);
+			}
+			return;
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < N; j++)
+		p[j] = t[j];
+}
+
+/* The matrix with the rows' constant terms pinned into vector registers (scope_pin_vgpr): what a fused kernel hands to
+ * scope_k0_cell.  -DSCOPE_PIN_K0=0 keeps them scalar (A/B). */
+#ifndef SCOPE_PIN_K0
+#define SCOPE_PIN_K0 1
+#endif
+__device__ __forceinline__ ScopeK0 scope_k0_pinned(const ScopeK0 &k, bool need_uv, bool need_y)
+{
+	ScopeK0 r = k;
+	if (SCOPE_PIN_K0 && need_uv) {
+		r.fu[3] = scope_pin_vgpr(k.fu[3]);
+		r.fv[3] = scope_pin_vgpr(k.fv[3]);
+	}
+	if (SCOPE_PIN_K0 && need_y)
+		r.fy[3] = scope_pin_vgpr(k.fy[3]);
+	return r;
+}
+
+/* "Last workgroup finishes the frame": every workgroup of a group (the slices of one frame) calls this after it has
+ * added its table to the frame's accumulator with agent-scope atomics; it returns true, in every thread, for the
+ * workgroup that arrives last, which may then read (exchange) the accumulator.  The caller resets the ticket when
+ * done, so a zero-initialised ticket array serves every launch on the stream.
+ *
+ * This is the "agent atomics on both sides" hand-off of MI355X_MICROARCH.md (Workgroup dispatch, XCD placement &
+ * inter-workgroup visibility): the payload is written AND read with device-scope atomic read-modify-writes, which are
+ * performed at the memory side, below the per-XCD L2s, so no cache can hold a stale or an unwritten copy and no
+ * L2 write-back / invalidate (buffer_wbl2 / buffer_inv, ~1.7 us each) is needed.  Every wave waits until its atomics
+ * have been acknowledged (the asm wait: hipcc may drop a builtin one) before the barrier, and one lane then takes an
+ * agent-scope ticket.  Round 1 handed over sc1-stored partial tables here; that form is gone.
+ * tests: test_histogram_in_kernel_combine_stress (thousands of launches, every count checked). */
+#ifndef SCOPE_TICKET_ORDER
+#define SCOPE_TICKET_ORDER __ATOMIC_RELAXED /* A/B: -DSCOPE_TICKET_ORDER=__ATOMIC_ACQ_REL (what it costs: DESIGN.md 3.3) */
+#endif
+__device__ __forceinline__ bool scope_last_arrival(u32 *ticket, u32 group_size, u32 *lds_flag)
+{
+	scope_drain_vmem(); /* this wave's atomics have been performed */
+	__syncthreads();
+	if (threadIdx.x == 0)
+		*lds_flag = __hip_atomic_fetch_add(ticket, 1u, SCOPE_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == group_size - 1u;
+	__syncthreads();
+	return *lds_flag != 0;
+}
+
+/* Slice s of S of `total` cells. */
+__device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
+{
+	return (u32)(((u64)total * s) / S);
+}
+/* ------------------------------------------------------------------------------------------
+ * K1 vectorscope
+ *
+ * LDS table: 32768 words, two u16 counters per word.  Bin (u, v) lives in table row v (the flush turns the
+ * table upside down into output rows 255 - v), half u & 1 of
+ *   HASH 0: word v*128 + ((u >> 1) ^ 8 (v & 15))     (default)
+ *   HASH 1: word v*128 + (u >> 1)                     (kept for A/B: two instructions fewer, but the rows of a
+ *                                                      chroma cluster then share their banks: -17 % on
+ *                                                      concentrated chroma, +1..5 % elsewhere)
+ * With HASH 0 sixteen consecutive rows start on sixteen different multiples of eight words, so a chroma cluster
+ * of 16 x 16 bins is spread over all banks.  (Round 2 also tried getting that spread from a row pitch of 136 words,
+ * with the LDS address from one multiply-add and the pixel travelling as (address, increment): five VALU
+ * instructions per pixel instead of six, yet 1-2 % slower on every kind of content -- the adds of a cell then issue
+ * back to back instead of between the address arithmetic of their neighbours.  Not kept.)
+ *
+ * A pixel's bin travels as a KEY = u << 8 | v << 16 (vss_bin: one v_perm_b32 from the texel, or straight from the
+ * fixed-point sums when K0 is fused).  Equal keys <=> equal bins; the bin index u + 256*(255 - v) is never
+ * materialised, the LDS byte address comes straight from the key's bits: key >> 7 = v << 9 | u << 1 is already
+ * "row base + 4 * (u >> 1)" up to bit 1 (each VALU instruction occupies a SIMD for a quad-cycle here, so
+ * instructions are what counts).
+ *
+ * Counters are 16 bit: between two clamp passes a workgroup adds at most 65280 pixels, and
+ * every counter is <= 255 after a pass, so no counter can exceed 65535.  The clamp is exact
+ * because the reference saturates at 255 (src/vectorscope.c:233-234).
+ * ---------------------------------------------------------------------------------------- */
+
+#define VSS_WORDS 32768u
+#define VSS_EPOCH_PIXELS 65280u
+
+template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u32 n)
+{
+	const u32 t = key >> 7; /* v << 9 | u << 1 */
+	u32 byte;
+	if (HASH == 1)
+		byte = t & 0x1fffcu;
+	else
+		byte = scope_bitop3<0x78>(t, key >> 11, 0x1e0u) & 0x1fffcu; /* t ^ (v << 5 & 0x1e0); key >> 11 = v << 5 | u >> 3 */
+	/* half u & 1 = bit 8 of the key; bits 4..7 are zero, so the shift count is 0 or 16 */
+	scope_lds_add_at(tab, byte, n << ((key >> 4) & 31u));
+}
+
+/* Flat content (screen capture, graphics, letterbox, a paused scene): almost every pixel of a lane's
+ * stream has the colour the lane saw last.  Same-address LDS atomics serialise at ~4 clk per lane
+ * (profiles/round1/lds_atomic_microbench.txt) -- a flat frame costs 127 clk per wave instruction --
+ * so in *absorb mode* a lane keeps (colour, count) in two registers, counts matching pixels there and
+ * only sends the others to LDS; the pair is added when the colour changes, before every clamp pass and
+ * at the end of the slice.  Whether a batch runs in absorb mode is one wave vote (vss_region). */
+struct VssLane {
+	u32 colour; /* key of the pending pixels; 0xffffffff = none (no key has bits in bytes 0 and 3) */
+	u32 count;
+};
+
+template <int HASH> __device__ __forceinline__ void vss_absorb4(u32 *tab, VssLane &st, u32 k0, u32 k1, u32 k2, u32 k3)
+{
+	bool e0 = k0 == st.colour, e1 = k1 == st.colour, e2 = k2 == st.colour, e3 = k3 == st.colour;
+	if (!(e0 | e1 | e2 | e3)) { /* none of the four is the lane's colour: it changed (rare; divergent) */
+		if (st.count)
+			vss_add<HASH>(tab, st.colour, st.count); /* hand in the old one ... */
+		st.colour = k0;                                /* ... and start counting the new one */
+		st.count = 0;
+		e0 = true;
+		e1 = k1 == k0;
+		e2 = k2 == k0;
+		e3 = k3 == k0;
+	}
+	st.count += (u32)e0 + (u32)e1 + (u32)e2 + (u32)e3;
+	if (!(e0 & e1 & e2 & e3)) { /* one exec test skips all four when the whole wave was absorbed */
+		if (!e0)
+			vss_add<HASH>(tab, k0, 1);
+		if (!e1)
+			vss_add<HASH>(tab, k1, 1);
+		if (!e2)
+			vss_add<HASH>(tab, k2, 1);
+		if (!e3)
+			vss_add<HASH>(tab, k3, 1);
+	}
+}
+
+/* Add what the lanes still hold.  Called by whole waves (uniform control flow).  When every pending
+ * lane of the wave holds the same colour -- the flat-frame case -- one lane adds the wave's total. */
+template <int HASH> __device__ __forceinline__ void vss_flush_lane(u32 *tab, VssLane &st)
+{
+	const u64 pending = __ballot(st.count != 0);
+	if (pending == 0)
+		return;
+	const u32 leader = (u32)(__ffsll((long long)pending) - 1);
+	const u32 colour = __builtin_amdgcn_readlane(st.colour, leader);
+	if (__all(st.count == 0 || st.colour == colour)) {
+		const u32 total = scope_wave_sum(st.count);
+		if ((threadIdx.x & 63u) == leader)
+			vss_add<HASH>(tab, colour, total);
+	} else if (st.count) {
+		vss_add<HASH>(tab, st.colour, st.count);
+	}
+	st.count = 0;
+}
+
+__device__ __forceinline__ u32 vss_clamp_word(u32 w)
+{
+	const u32 lo = min(w & 0xffffu, 255u);
+	const u32 hi = min(w >> 16, 255u);
+	return lo | (hi << 16);
+}
+
+/* two table words = four consecutive bins -> four clamped bytes */
+__device__ __forceinline__ u32 vss_clamp_pair(u32 w0, u32 w1)
+{
+	return min(w0 & 0xffffu, 255u) | (min(w0 >> 16, 255u) << 8) | (min(w1 & 0xffffu, 255u) << 16) | (min(w1 >> 16, 255u) << 24);
+}
+
+__device__ __forceinline__ void vss_clamp_pass(u32 *tab)
+{
+	for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4) {
+		uint4 x = *(uint4 *)&tab[i];
+		if ((x.x | x.y | x.z | x.w) & 0xff00ff00u) {
+			x.x = vss_clamp_word(x.x);
+			x.y = vss_clamp_word(x.y);
+			x.z = vss_clamp_word(x.z);
+			x.w = vss_clamp_word(x.w);
+			*(uint4 *)&tab[i] = x;
+		}
+	}
+}
+
+/* HIS: the histogram of the same channels comes out of this pass for nothing.  A strip's table IS a histogram per
+ * column -- exact 16-bit counts until the flush clamps them -- so the flush, which reads every counter anyway, also
+ * adds up each value's 64 columns (the same texels pass the same alpha test in both loops, src/waveform.c:247-248 and
+ * src/histogram.c:386-387), a 16-lane row sum hands the totals to LDS, and 12 wave instructions per unit add them to
+ * the frame's accumulator his.acc[frame][slot][value] with device-scope atomics.  The workgroup that finishes a
+ * frame's last unit (ticket) moves the sums to his.out[frame][value][slot] and leaves accumulator and ticket zero.
+ * No LDS atomic per pixel is added: the dock's waveform + histogram cost one read of the plane (src/roi.c:329-341
+ * hands one staged surface to every scope). */
+struct ScopeWvsHis {
+	u32 *acc;     /* [SCOPE_MAX_FRAMES][4][256], zero between launches */
+	u32 *tickets; /* [SCOPE_MAX_FRAMES], zero between launches */
+	u32 *out;     /* [n_frames][256][4]: slots R,G,B,unused as scope_his_kernel writes them */
+	u32 chmask;   /* channels the caller wants counted (a subset of CH); the others stay zero */
+};
+
+/* A launch, optionally with the kernel's own begin / end time stamps delivered into two HIP events
+ * (hipExtLaunchKernelGGL: the stamps come out of the dispatch packet, as rocprofv3's do -- events recorded around a
+ * launch also time the gap the command processor leaves in front of the kernel, 5 % of a 0.3 ms launch). */
+#define SCOPE_LAUNCH(kernel, grid, block, lds, st, tm, ...)                                                        \
+	do {                                                                                                       \
+		if (tm)                                                                                            \
+			hipExtLaunchKernelGGL(kernel, grid, block, lds, st, (tm)->start, (tm)->stop, 0, __VA_ARGS__); \
+		else                                                                                               \
+			hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                             \
+	} while (0)
+
+#endif

@@ -77,8 +77,10 @@ struct ScopeTiming {
 
 ScopeK0 scope_k0_matrix(int colorspace);
 
-/* Dynamic-LDS opt-in for every instantiation; call once per device before launching. */
+/* Dynamic-LDS opt-in for every instantiation; call once per device before launching (scope_trio_init: the part of it that
+ * lives in scope_trio.hip; scope_kernels_init calls it). */
 hipError_t scope_kernels_init(void);
+hipError_t scope_trio_init(void);
 
 /* K0 standalone: src plane (B,G,R,A) -> dst plane (U,Y,V,255); replaces the ConvertRGB_YUV* pass
  * of render_rgb_yuv (src/common.c:202-213). */
@@ -154,6 +156,10 @@ hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n
 /* The same over sparse partials: part / pmask as scope_launch_vss wrote them with `mask_block` threads per workgroup. */
 hipError_t scope_launch_sat_reduce_sparse(const uint8_t *part, const uint8_t *pmask, uint8_t *out, uint32_t n_frames,
 					  uint32_t slices, uint32_t mask_block, int packed16, hipStream_t st);
+
+/* A plain streaming read of `bytes` (a multiple of 16) at p: what scope_frame_pool_alloc times a candidate with. */
+hipError_t scope_launch_read_probe(const void *p, uint64_t bytes, uint32_t num_cu, uint32_t *sink, hipStream_t st,
+				   const ScopeTiming *tm);
 
 hipError_t scope_launch_sum_reduce(const uint32_t *part, uint32_t *out, uint32_t n_frames, uint32_t slices,
 				   uint32_t len, hipStream_t st);

@@ -26,16 +26,9 @@
  *
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (K0 must not be FMA-contracted).
  */
-#include "scope_kernels.h"
-#include <hip/hip_ext.h>
-#include <type_traits>
-#include <scope_vec.h>
+#include "scope_device.h"
 
-typedef uint32_t u32;
-typedef uint64_t u64;
 
-/* All LDS scratch lives in the dynamic region so its base stays 16-byte aligned. */
-extern __shared__ __attribute__((aligned(16))) u32 scope_lds[];
 #ifdef SCOPE_TRACE_WG
 __device__ unsigned long long scope_dbg_times[1024 * 4];
 extern "C" int scope_debug_read(unsigned long long *out)
@@ -46,148 +39,6 @@ extern "C" int scope_debug_read(unsigned long long *out)
 #else
 #define SCOPE_STAMP(k) do { } while (0)
 #endif
-
-/* ------------------------------------------------------------------------------------------
- * K0: per-texel RGB -> Y'CbCr, bit-exact with oracle/scope_oracle.c:k0_texel
- * ---------------------------------------------------------------------------------------- */
-
-/* byte/255 correctly rounded to fp32 without a divide: fma(b, hi, b*lo) with hi+lo ~= 1/255
- * (checked exhaustively for the 256 inputs in tests/test_k0_constants.py). */
-__device__ __forceinline__ float scope_unorm8(u32 byte)
-{
-	const float b = (float)byte;
-	return __fmaf_rn(b, 0x1.010102p-8f, __fmul_rn(b, -0x1.fdfdfep-33f));
-}
-
-/* FLOAT -> UNORM8 store rule pinned by the build: floor(clamp01(x)*255 + 0.5). */
-__device__ __forceinline__ u32 scope_k0_quantise(float x)
-{
-	x = fminf(fmaxf(x, 0.0f), 1.0f);
-	return (u32)__fadd_rn(__fmul_rn(x, 255.0f), 0.5f);
-}
-
-/* px bytes B,G,R,A -> bytes U,Y,V,255 (data/common.effect:23-43; the shader returns
- * float4(V,Y,U,1) into a BGRA target).  need_uv / need_y are wave-uniform. */
-__device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool need_uv, bool need_y)
-{
-	const float b = scope_unorm8(px & 0xffu);
-	const float g = scope_unorm8((px >> 8) & 0xffu);
-	const float r = scope_unorm8((px >> 16) & 0xffu);
-	u32 out = 0xff000000u;
-	if (need_uv) {
-		/* U and V side by side in one 2-vector: the same operations in the same order on both halves,
-		 * so they issue as v_pk_mul_f32 / v_pk_add_f32 (no FMA: -ffp-contract=off).  V's "- 0" is exact. */
-		scope_f2 uv = scope_f2_make(k.ur, k.vr) * scope_f2_make(r, r);
-		uv = uv + scope_f2_make(k.ug, k.vg) * scope_f2_make(g, g);
-		uv = uv + scope_f2_make(k.ub, k.vb) * scope_f2_make(b, b);
-		uv = uv + scope_f2_make(0.5f, 0.5f);
-		uv = uv - scope_f2_make(0.00390625f, 0.0f);
-		out |= scope_k0_quantise(scope_f2_lo(uv)) | (scope_k0_quantise(scope_f2_hi(uv)) << 16);
-	}
-	if (need_y) {
-		float y = __fmul_rn(k.yr, r);
-		y = __fadd_rn(y, __fmul_rn(k.yg, g));
-		y = __fadd_rn(y, __fmul_rn(k.yb, b));
-		out |= scope_k0_quantise(y) << 8;
-	}
-	return out;
-}
-
-/* ---- the fast path ------------------------------------------------------------------------------
- * The fp32 chain above costs ~33 VALU instructions per texel and makes every fused kernel VALU-bound.
- * The value it approximates is T = c_r R + c_g G + c_b B + 255 off + 0.5 with output floor(T) (no clamp is
- * ever active for 8-bit inputs), which three 24-bit integer multiply-adds give directly in 2^-24 fixed
- * point: E = C_r R + C_g G + C_b B + K, and the output is byte 3 of E (chroma |c| < 0.5 fits v_mul_i32_i24,
- * luma 0 <= c < 1 fits v_mul_u32_u24; the sum is taken mod 2^32 and ends below 256 * 2^24).  The two disagree
- * only where T is within ~2.5e-5 of an integer, i.e. where fp32 rounding decides: an exhaustive run over all
- * 2^24 colours, both matrices and all three rows finds every such colour within 422 units (2^-24) of a step.
- * So K carries a guard of 512 units and a value whose fraction is below 1024 -- bytes 1..2 of E, read as a
- * number, below 4 -- is "near a step": its cell is recomputed with the fp32 chain (a wave votes per cell;
- * 6e-5 .. 1e-3 of all colours).  Two rows' fractions travel as the halves of one register (v_perm_b32) and the
- * running minimum over a cell is a v_pk_min_u16.  Black is an exact tie (V = 128.0) on which both paths agree,
- * and common (letterbox bars): cells that are black throughout are exempt.
- * tests/test_parity_gpu.py runs all 2^24 colours through this code against the oracle. */
-__device__ __forceinline__ int scope_mad24(int a, int b, int c)
-{
-	return __mul24(a, b) + c; /* v_mad_i32_i24 */
-}
-
-__device__ __forceinline__ u32 scope_umad24(u32 a, u32 b, u32 c)
-{
-	return __umul24(a, b) + c; /* v_mad_u32_u24: the luma coefficients are positive and may exceed 0.5 */
-}
-
-#define SCOPE_K0_NEAR 4u /* 2 * SCOPE_K0_FX_GUARD >> 8 */
-
-/* The vectorscope's bin key of a Y'CbCr texel: U in byte 1, V in byte 2, bytes 0 and 3 zero (see vss_add). */
-__device__ __forceinline__ u32 vss_bin(u32 px)
-{
-	return scope_perm(0u, px, 0x0c02000cu);
-}
-
-/* One row of the matrix in 2^-24 fixed point: f[0] R + f[1] G + f[2] B + f[3] (mod 2^32), texel bytes B, G, R, A.
- * Four instructions, the masked blue byte `b` is shared by the rows: two byte multiplies, a multiply-add, a 3-way add. */
-__device__ __forceinline__ u32 scope_k0_row(u32 px, int b, const int (&f)[4])
-{
-	return (u32)(scope_mad24(f[2], b, f[3]) + scope_mul24_byte1(px, f[1]) + scope_mul24_byte2(px, f[0]));
-}
-__device__ __forceinline__ u32 scope_k0_row_y(u32 px, u32 b, const int (&f)[4])
-{
-	return scope_umad24((u32)f[2], b, (u32)f[3]) + scope_umul24_byte1(px, (u32)f[1]) + scope_umul24_byte2(px, (u32)f[0]);
-}
-
-/* worst: running per-half minimum of the fractions' upper 16 bits.  VSSKEY: the result is the vectorscope's bin key
- * (0, U, V, 0) instead of the texel (U, Y, V, 255) -- the same single v_perm_b32 with another selector. */
-template <bool VSSKEY>
-__device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool need_uv, bool need_y, u32 &worst)
-{
-	const u32 b = px & 0xffu;
-	u32 out = 0xff000000u;
-	if (need_uv) {
-		const u32 eu = scope_k0_row(px, (int)b, k.fu);
-		const u32 ev = scope_k0_row(px, (int)b, k.fv);
-		worst = scope_pk_min_u16(worst, scope_perm(ev, eu, 0x06050201u));
-		out = scope_perm(ev, eu, VSSKEY ? 0x0c07030cu : 0x0d070c03u); /* 0, U, V, 0 or U, 0, V, 255 */
-	}
-	if (need_y) {
-		const u32 ey = scope_k0_row_y(px, b, k.fy);
-		worst = scope_pk_min_u16(worst, scope_perm(ey, ey, 0x06050201u));
-		out = scope_perm(ey, out, 0x03020700u);
-	}
-	return out;
-}
-
-/* N texels of one lane, in place.  The votes are wave-wide: a cell is redone in fp32 by the whole wave when any
- * lane holds a texel near a step (identical results for the other lanes, that is what the exhaustive test says).
- * Cells that are black throughout are exempt (black is an exact tie both paths agree on); a black texel next to
- * other colours just sends its cell to the fp32 path, which is as right as the fast one. */
-template <int N, bool VSSKEY = false>
-__device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, bool need_uv, bool need_y)
-{
-	u32 t[N], worst = 0xffffffffu;
-#pragma unroll
-	for (int j = 0; j < N; j++)
-		t[j] = scope_k0_fixed<VSSKEY>(p[j], k, need_uv, need_y, worst);
-	const bool near_step = min(worst & 0xffffu, worst >> 16) < SCOPE_K0_NEAR;
-	if (__ballot(near_step) != 0) { /* rare, except on black */
-		u32 any = 0;
-#pragma unroll
-		for (int j = 0; j < N; j++)
-			any |= p[j];
-		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
-#pragma unroll
-			for (int j = 0; j < N; j++) {
-				p[j] = scope_k0_texel(p[j], k, need_uv, need_y);
-				if (VSSKEY)
-					p[j] = vss_bin(p[j]);
-			}
-			return;
-		}
-	}
-#pragma unroll
-	for (int j = 0; j < N; j++)
-		p[j] = t[j];
-}
 
 static void k0_fixed_row(const float c[3], double offset, int out[4])
 {
@@ -235,7 +86,6 @@ ScopeK0 scope_k0_matrix(int colorspace)
  * and which of them are real.  Row pitch is honoured.
  * ---------------------------------------------------------------------------------------- */
 
-typedef u32 scope_v4 __attribute__((vector_size(16)));
 
 template <int VECW> struct ScopeVec;
 template <> struct ScopeVec<4> {
@@ -250,31 +100,6 @@ template <bool NT, typename V> __device__ __forceinline__ V scope_load(const V *
 	if (NT)
 		return __builtin_nontemporal_load(p);
 	return *p;
-}
-
-/* "Last workgroup finishes the frame": every workgroup of a group (the slices of one frame) calls this after it has
- * added its table to the frame's accumulator with agent-scope atomics; it returns true, in every thread, for the
- * workgroup that arrives last, which may then read (exchange) the accumulator.  The caller resets the ticket when
- * done, so a zero-initialised ticket array serves every launch on the stream.
- *
- * This is the "agent atomics on both sides" hand-off of MI355X_MICROARCH.md (Workgroup dispatch, XCD placement &
- * inter-workgroup visibility): the payload is written AND read with device-scope atomic read-modify-writes, which are
- * performed at the memory side, below the per-XCD L2s, so no cache can hold a stale or an unwritten copy and no
- * L2 write-back / invalidate (buffer_wbl2 / buffer_inv, ~1.7 us each) is needed.  Every wave waits until its atomics
- * have been acknowledged (the asm wait: hipcc may drop a builtin one) before the barrier, and one lane then takes an
- * agent-scope ticket.  Round 1 handed over sc1-stored partial tables here; that form is gone.
- * tests: test_histogram_in_kernel_combine_stress (thousands of launches, every count checked). */
-#ifndef SCOPE_TICKET_ORDER
-#define SCOPE_TICKET_ORDER __ATOMIC_RELAXED /* A/B: -DSCOPE_TICKET_ORDER=__ATOMIC_ACQ_REL (what it costs: DESIGN.md 3.3) */
-#endif
-__device__ __forceinline__ bool scope_last_arrival(u32 *ticket, u32 group_size, u32 *lds_flag)
-{
-	scope_drain_vmem(); /* this wave's atomics have been performed */
-	__syncthreads();
-	if (threadIdx.x == 0)
-		*lds_flag = __hip_atomic_fetch_add(ticket, 1u, SCOPE_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == group_size - 1u;
-	__syncthreads();
-	return *lds_flag != 0;
 }
 
 /* min(sum over `slices` partial tables, 255) for 16 byte-wide bins; slices <= 256, so the packed 16-bit lanes
@@ -300,11 +125,6 @@ __device__ __forceinline__ uint4 scope_sat_sum16(const uint4 *p, u64 stride, u32
 	return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
-/* Slice s of S of `total` cells. */
-__device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
-{
-	return (u32)(((u64)total * s) / S);
-}
 #ifndef SCOPE_SLICE_ALIGN
 #define SCOPE_SLICE_ALIGN 32 /* 16-byte cells: 512 bytes */
 #endif
@@ -409,130 +229,6 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 #undef SCOPE_BIN
 }
 
-/* ------------------------------------------------------------------------------------------
- * K1 vectorscope
- *
- * LDS table: 32768 words, two u16 counters per word.  Bin (u, v) lives in table row v (the flush turns the
- * table upside down into output rows 255 - v), half u & 1 of
- *   HASH 0: word v*128 + ((u >> 1) ^ 8 (v & 15))     (default)
- *   HASH 1: word v*128 + (u >> 1)                     (kept for A/B: two instructions fewer, but the rows of a
- *                                                      chroma cluster then share their banks: -17 % on
- *                                                      concentrated chroma, +1..5 % elsewhere)
- * With HASH 0 sixteen consecutive rows start on sixteen different multiples of eight words, so a chroma cluster
- * of 16 x 16 bins is spread over all banks.  (Round 2 also tried getting that spread from a row pitch of 136 words,
- * with the LDS address from one multiply-add and the pixel travelling as (address, increment): five VALU
- * instructions per pixel instead of six, yet 1-2 % slower on every kind of content -- the adds of a cell then issue
- * back to back instead of between the address arithmetic of their neighbours.  Not kept.)
- *
- * A pixel's bin travels as a KEY = u << 8 | v << 16 (vss_bin: one v_perm_b32 from the texel, or straight from the
- * fixed-point sums when K0 is fused).  Equal keys <=> equal bins; the bin index u + 256*(255 - v) is never
- * materialised, the LDS byte address comes straight from the key's bits: key >> 7 = v << 9 | u << 1 is already
- * "row base + 4 * (u >> 1)" up to bit 1 (each VALU instruction occupies a SIMD for a quad-cycle here, so
- * instructions are what counts).
- *
- * Counters are 16 bit: between two clamp passes a workgroup adds at most 65280 pixels, and
- * every counter is <= 255 after a pass, so no counter can exceed 65535.  The clamp is exact
- * because the reference saturates at 255 (src/vectorscope.c:233-234).
- * ---------------------------------------------------------------------------------------- */
-
-#define VSS_WORDS 32768u
-#define VSS_EPOCH_PIXELS 65280u
-
-template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u32 n)
-{
-	const u32 t = key >> 7; /* v << 9 | u << 1 */
-	u32 byte;
-	if (HASH == 1)
-		byte = t & 0x1fffcu;
-	else
-		byte = scope_bitop3<0x78>(t, key >> 11, 0x1e0u) & 0x1fffcu; /* t ^ (v << 5 & 0x1e0); key >> 11 = v << 5 | u >> 3 */
-	/* half u & 1 = bit 8 of the key; bits 4..7 are zero, so the shift count is 0 or 16 */
-	scope_lds_add_at(tab, byte, n << ((key >> 4) & 31u));
-}
-
-/* Flat content (screen capture, graphics, letterbox, a paused scene): almost every pixel of a lane's
- * stream has the colour the lane saw last.  Same-address LDS atomics serialise at ~4 clk per lane
- * (profiles/round1/lds_atomic_microbench.txt) -- a flat frame costs 127 clk per wave instruction --
- * so in *absorb mode* a lane keeps (colour, count) in two registers, counts matching pixels there and
- * only sends the others to LDS; the pair is added when the colour changes, before every clamp pass and
- * at the end of the slice.  Whether a batch runs in absorb mode is one wave vote (vss_region). */
-struct VssLane {
-	u32 colour; /* key of the pending pixels; 0xffffffff = none (no key has bits in bytes 0 and 3) */
-	u32 count;
-};
-
-template <int HASH> __device__ __forceinline__ void vss_absorb4(u32 *tab, VssLane &st, u32 k0, u32 k1, u32 k2, u32 k3)
-{
-	bool e0 = k0 == st.colour, e1 = k1 == st.colour, e2 = k2 == st.colour, e3 = k3 == st.colour;
-	if (!(e0 | e1 | e2 | e3)) { /* none of the four is the lane's colour: it changed (rare; divergent) */
-		if (st.count)
-			vss_add<HASH>(tab, st.colour, st.count); /* hand in the old one ... */
-		st.colour = k0;                                /* ... and start counting the new one */
-		st.count = 0;
-		e0 = true;
-		e1 = k1 == k0;
-		e2 = k2 == k0;
-		e3 = k3 == k0;
-	}
-	st.count += (u32)e0 + (u32)e1 + (u32)e2 + (u32)e3;
-	if (!(e0 & e1 & e2 & e3)) { /* one exec test skips all four when the whole wave was absorbed */
-		if (!e0)
-			vss_add<HASH>(tab, k0, 1);
-		if (!e1)
-			vss_add<HASH>(tab, k1, 1);
-		if (!e2)
-			vss_add<HASH>(tab, k2, 1);
-		if (!e3)
-			vss_add<HASH>(tab, k3, 1);
-	}
-}
-
-/* Add what the lanes still hold.  Called by whole waves (uniform control flow).  When every pending
- * lane of the wave holds the same colour -- the flat-frame case -- one lane adds the wave's total. */
-template <int HASH> __device__ __forceinline__ void vss_flush_lane(u32 *tab, VssLane &st)
-{
-	const u64 pending = __ballot(st.count != 0);
-	if (pending == 0)
-		return;
-	const u32 leader = (u32)(__ffsll((long long)pending) - 1);
-	const u32 colour = __builtin_amdgcn_readlane(st.colour, leader);
-	if (__all(st.count == 0 || st.colour == colour)) {
-		const u32 total = scope_wave_sum(st.count);
-		if ((threadIdx.x & 63u) == leader)
-			vss_add<HASH>(tab, colour, total);
-	} else if (st.count) {
-		vss_add<HASH>(tab, st.colour, st.count);
-	}
-	st.count = 0;
-}
-
-__device__ __forceinline__ u32 vss_clamp_word(u32 w)
-{
-	const u32 lo = min(w & 0xffffu, 255u);
-	const u32 hi = min(w >> 16, 255u);
-	return lo | (hi << 16);
-}
-
-/* two table words = four consecutive bins -> four clamped bytes */
-__device__ __forceinline__ u32 vss_clamp_pair(u32 w0, u32 w1)
-{
-	return min(w0 & 0xffffu, 255u) | (min(w0 >> 16, 255u) << 8) | (min(w1 & 0xffffu, 255u) << 16) | (min(w1 >> 16, 255u) << 24);
-}
-
-__device__ __forceinline__ void vss_clamp_pass(u32 *tab)
-{
-	for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4) {
-		uint4 x = *(uint4 *)&tab[i];
-		if ((x.x | x.y | x.z | x.w) & 0xff00ff00u) {
-			x.x = vss_clamp_word(x.x);
-			x.y = vss_clamp_word(x.y);
-			x.z = vss_clamp_word(x.z);
-			x.w = vss_clamp_word(x.w);
-			*(uint4 *)&tab[i] = x;
-		}
-	}
-}
-
 template <int VECW, int U, bool NT, int MERGE, bool FUSE, int HASH, typename Pro>
 __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
 					   u32 slice, u32 slices, u32 glog2, const ScopeK0 &k0, u32 &since_clamp, VssLane &st,
@@ -635,8 +331,9 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
  * twice the partials' bytes) -- are in profiles/round2/flush_microbench_r2a.txt. */
 template <int U, bool NT, int MERGE, bool FUSE, int HASH>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
-							       u32 xbyte_b, u32 glog2, ScopeK0 k0, uint8_t *dst, uint8_t *pmask)
+							       u32 xbyte_b, u32 glog2, ScopeK0 k0_arg, uint8_t *dst, uint8_t *pmask)
 {
+	const ScopeK0 k0 = FUSE ? scope_k0_pinned(k0_arg, true, false) : k0_arg;
 	u32 *tab = scope_lds;
 	scope_lds_is_at_zero(tab);
 	const u32 unit = blockIdx.x;
@@ -773,8 +470,9 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
  * (scope_last_arrival).  One launch, no partial tables, whatever the number of slices. */
 template <int U, bool NT, bool FUSE>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
-							       u32 xbyte_b, u32 chmask, ScopeK0 k0, u32 *dst, u32 *acc, u32 *tickets)
+							       u32 xbyte_b, u32 chmask, ScopeK0 k0_arg, u32 *dst, u32 *acc, u32 *tickets)
 {
+	const ScopeK0 k0 = FUSE ? scope_k0_pinned(k0_arg, (chmask & 5u) != 0, (chmask & 2u) != 0) : k0_arg;
 	u32 *tab = scope_lds;
 	const u32 unit = blockIdx.x;
 	const u32 frame = unit / slices;
@@ -919,20 +617,6 @@ template <int SW> __device__ __forceinline__ WvsUnit wvs_unit(const ScopeFrameSe
  * table is flushed and stay in flight across the flush and the zero-fill -- so the memory pipeline does
  * not drain at every unit boundary (a unit is only ~0.5 MB).  Batch n of a unit = row pairs 4n..4n+3;
  * wave w takes batches w, w + nwaves, ... */
-/* HIS: the histogram of the same channels comes out of this pass for nothing.  A strip's table IS a histogram per
- * column -- exact 16-bit counts until the flush clamps them -- so the flush, which reads every counter anyway, also
- * adds up each value's 64 columns (the same texels pass the same alpha test in both loops, src/waveform.c:247-248 and
- * src/histogram.c:386-387), a 16-lane row sum hands the totals to LDS, and 12 wave instructions per unit add them to
- * the frame's accumulator his.acc[frame][slot][value] with device-scope atomics.  The workgroup that finishes a
- * frame's last unit (ticket) moves the sums to his.out[frame][value][slot] and leaves accumulator and ticket zero.
- * No LDS atomic per pixel is added: the dock's waveform + histogram cost one read of the plane (src/roi.c:329-341
- * hands one staged surface to every scope). */
-struct ScopeWvsHis {
-	u32 *acc;     /* [SCOPE_MAX_FRAMES][4][256], zero between launches */
-	u32 *tickets; /* [SCOPE_MAX_FRAMES], zero between launches */
-	u32 *out;     /* [n_frames][256][4]: slots R,G,B,unused as scope_his_kernel writes them */
-	u32 chmask;   /* channels the caller wants counted (a subset of CH); the others stay zero */
-};
 
 /* DEEP (batches: every unit has the same, sufficiently many, slots): a unit's flush -- barrier, 96 KiB of LDS read, 64 KiB
  * stored, zero-fill, barrier -- takes the workgroup 3-4 us, and the two batches of the steady state (32 KiB per CU, the
@@ -945,9 +629,10 @@ struct ScopeWvsHis {
  * its LDS reads, packing and stores 2.3 %, its two barriers 2.2 %, the zero-fill 0.8 % -- the table's own bytes are
  * a tenth of the traffic and stay. */
 template <int CH, bool FUSE, bool WIDE, bool HIS, int SW, bool DEEP>
-__global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, ScopeK0 k0,
+__global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs, u32 strips, u32 bands, ScopeK0 k0_arg,
 							       uint8_t *dst, ScopeWvsHis his)
 {
+	const ScopeK0 k0 = FUSE ? scope_k0_pinned(k0_arg, (CH & 5) != 0, (CH & 2) != 0) : k0_arg;
 	static_assert(SW == 64 || (SW == WVS_NARROW && WIDE), "narrow strips exist in the vector shape only");
 	constexpr int U = SW == WVS_NARROW ? WVS_NARROW_U : WVS_U;
 	constexpr u32 LR = SW / 2u;   /* lanes per row (two texels each) */
@@ -1457,286 +1142,6 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_dock_kernel(ScopeFrameSet f
 	}
 }
 
-/* ------------------------------------------------------------------------------------------
- * The dock's three scopes from ONE read, for ANY number of frames: scope_trio_kernel (round 3).
- *
- * scope_dock_kernel above reads a frame once but only where one round of strips covers the launch (one 4K frame), because it
- * time-shares the LDS between the waveform's and the vectorscope's table and has to hold a strip's texels in registers in
- * between; the ring of three and every batch fell back to two reads of the planes (1.91 x the algorithmic traffic).
- *
- * Here BOTH tables are resident: the vectorscope's 128 KiB (16-bit counters, swizzled rows, as scope_vss_kernel) plus a
- * waveform table of ONE replica for a 16-column strip -- 256 values x 8 column pairs x 4 bytes = 8 KiB per channel, 24 KiB
- * for RGB -- 152 KiB of the CU's 160.  A workgroup owns the strips of one slice of one frame and streams them like any
- * other kernel here: every texel is loaded once, counted in the waveform table (alpha test, src/waveform.c:247-248), sent
- * through the fixed-point K0 and counted in the vectorscope table, with TRIO_D loads per lane in flight and no register-held
- * strip.  Per strip: barrier, the waveform's 256 x 16 output texels leave (the thread that reads a counter zeroes it, the
- * histogram's totals accumulate in three registers per thread over all strips of the slice), the vectorscope's clamp
- * pass when the next strip could overflow 16 bits, barrier; the loads of the next strip are in flight across it.  Per
- * slice: ONE vectorscope partial (sparse, as scope_vss_kernel writes them; the final table when the frame has one slice)
- * and <= 768 device atomics for the histogram.  64 frames: 4 slices of 60 strips per frame; three frames: 80 slices of
- * three strips; one frame: 240 slices of one -- the dock kernel's shape.
- *
- * What the single replica costs: a half wave is 4 rows x 8 column pairs, word = value * 8 + pair, so two rows whose values
- * agree mod 4 meet in one bank (2.1 x the conflict-free time on noise by the bank model of profiles/round1/
- * lds_atomic_microbench.txt) -- LDS issue, not HBM, bounds this kernel.  The eight rows of a wave instruction lie H/8 apart
- * (as in scope_dock_kernel), so that the equal values of vertically neighbouring texels do not meet on one ADDRESS.
- *
- * A strip's row segment is 64 bytes, half a cache line.  Slices come in pairs that split a range of strips even / odd, and
- * the two workgroups of a pair are b and b + 8 (same XCD, same L2, same moment): the other half of every line is wanted by
- * the partner while it is still in the L2.
- * Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables), H <= 4080 (a strip's texels fit the
- * vectorscope's 16-bit counters between two clamp passes).
- * ---------------------------------------------------------------------------------------- */
-#ifndef TRIO_D
-#define TRIO_D 6 /* 8-byte loads in flight per lane; a strip's loads per lane are rounded up to a multiple of it */
-#endif
-#ifndef TRIO_NT
-#define TRIO_NT 1
-#endif
-#define TRIO_CH_BYTES 8192u
-#define TRIO_WVS_BASE (VSS_WORDS * 4u)
-
-template <int CH> __device__ __forceinline__ void trio_count(u32 *tab, u32 px, u32 lane_base, u32 inc)
-{
-	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1);
-	if (CH & 1)
-		scope_lds_add_at(tab, lane_base + ((px & 0xffu) << 5), inc);
-	if (CH & 2)
-		scope_lds_add_at(tab, lane_base + slot1 * TRIO_CH_BYTES + (((px >> 8) & 0xffu) << 5), inc);
-	if (CH & 4)
-		scope_lds_add_at(tab, lane_base + slot2 * TRIO_CH_BYTES + (((px >> 16) & 0xffu) << 5), inc);
-}
-
-template <int CH, bool HIS>
-__global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet fs, u32 strips, u32 slices, ScopeK0 k0,
-								uint8_t *wvs_dst, ScopeWvsHis his, uint8_t *vss_dst, uint8_t *vss_mask)
-{
-	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1), nch = slot2 + ((CH >> 2) & 1);
-	constexpr u32 slot_of[3] = {0, slot1, slot2};
-	constexpr int D = TRIO_D;
-	u32 *tab = scope_lds;
-	scope_lds_is_at_zero(tab);
-	u32 *wt = tab + VSS_WORDS; /* [nch][256 values][8 column pairs] */
-	const u32 W = fs.width, H = fs.height;
-	const u32 lane = threadIdx.x & 63u;
-	const u32 pair = lane & 7u, rsub = lane >> 3;
-	const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const u32 nwaves = blockDim.x >> 6;
-
-	/* ---- which strips are mine ------------------------------------------------------------------------------------ */
-	const u32 b = blockIdx.x, total = gridDim.x;
-	u32 frame, slice, first, last, stride;
-	if ((slices & 1u) == 0) {
-		/* pairs: workgroups b and b + 8 of a block of 16 share a range of strip PAIRS (a pair = one 128-byte line per row) and
-		 * take its even / odd strips */
-		const u32 half = slices >> 1, base = total & ~15u;
-		u32 p, parity;
-		if (b < base) {
-			p = ((b >> 4) << 3) + (b & 7u);
-			parity = (b >> 3) & 1u;
-		} else {
-			p = (base >> 1) + ((b - base) >> 1);
-			parity = (b - base) & 1u;
-		}
-		frame = p / half;
-		const u32 q = p - frame * half;
-		const u32 spairs = (strips + 1u) >> 1;
-		first = 2u * scope_slice_begin(spairs, q, half) + parity;
-		last = min(2u * scope_slice_begin(spairs, q + 1u, half), strips);
-		stride = 2;
-		slice = 2u * q + parity;
-	} else {
-		frame = b / slices;
-		slice = b - frame * slices;
-		first = scope_slice_begin(strips, slice, slices);
-		last = scope_slice_begin(strips, slice + 1u, slices);
-		stride = 1;
-	}
-	const u32 nst = first < last ? (last - first + stride - 1u) / stride : 0u;
-	const uint8_t *plane = fs.plane[frame];
-
-	/* rows of a lane: rsub * rps + i, i = wave, wave + nwaves, ...; G loads per lane and strip, rounded up to whole rounds of D */
-	const u32 rps = (H + 7u) >> 3;
-	const u32 row0 = rsub * rps;
-	const u32 G = (rps + nwaves - 1u) / nwaves;
-	const u32 Gp = ((G + (u32)D - 1u) / (u32)D) * (u32)D;
-	const u32 dstep = nwaves * fs.linesize;
-	const u32 lane_base = TRIO_WVS_BASE + (pair << 2);
-
-	/* ---- issue side ------------------------------------------------------------------------------------------------ */
-	u32 px[D][2];
-	bool ok[D];
-	u32 s_i = 0, g_i = 0, off_i = 0;
-	bool live_i = false;
-	auto strip_start = [&](u32 s) {
-		const u32 x0 = (first + s * stride) * 16u + 2u * pair;
-		live_i = s < nst && x0 < W; /* W % 4 == 0: both texels of the pair or none */
-		off_i = (row0 + wave) * fs.linesize + x0 * 4u;
-	};
-	strip_start(0);
-#define TRIO_ISSUE(d)                                                                                                  \
-	do {                                                                                                           \
-		const u32 i_ = wave + g_i * nwaves;                                                                    \
-		ok[d] = live_i && i_ < rps && row0 + i_ < H;                                                           \
-		scope_u2 t_;                                                                                           \
-		if (TRIO_NT)                                                                                           \
-			t_ = scope_load_row2_nt(plane, ok[d] ? off_i : 0u);                                            \
-		else                                                                                                   \
-			t_ = scope_load_row2(plane, ok[d] ? off_i : 0u);                                               \
-		px[d][0] = t_.x;                                                                                       \
-		px[d][1] = t_.y;                                                                                       \
-		off_i += dstep;                                                                                        \
-		if (++g_i == Gp) {                                                                                     \
-			g_i = 0;                                                                                       \
-			strip_start(++s_i);                                                                            \
-		}                                                                                                      \
-	} while (0)
-#pragma unroll
-	for (int d = 0; d < D; d++)
-		TRIO_ISSUE(d);
-
-	/* both tables zeroed under the first loads */
-	{
-		const uint4 zero = make_uint4(0, 0, 0, 0);
-		for (u32 i = threadIdx.x * 4; i < VSS_WORDS + nch * (TRIO_CH_BYTES / 4u); i += blockDim.x * 4)
-			*(uint4 *)&tab[i] = zero;
-	}
-	__syncthreads();
-
-	VssLane st = {0xffffffffu, 0};
-	bool absorb = false; /* wave-uniform */
-	u32 since = 0;       /* texels the vectorscope table may have taken since its last clamp pass (uniform) */
-	const u32 strip_px = 16u * H;
-	u32 hs[3] = {0, 0, 0}; /* HIS: this thread's (value, column group) totals over the slice's strips */
-	const u32 value = threadIdx.x >> 2, g4 = threadIdx.x & 3u;
-
-	for (u32 s_b = 0; s_b < nst; s_b++) {
-		for (u32 g_b = 0; g_b < Gp; g_b += (u32)D) {
-#pragma unroll
-			for (int d = 0; d < D; d++) {
-				const u32 p0 = px[d][0], p1 = px[d][1];
-				if (ok[d]) {
-					if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
-						trio_count<CH>(tab, p0, lane_base, 1u);
-					if ((p1 >> 24) != 0)
-						trio_count<CH>(tab, p1, lane_base, 65536u);
-				}
-				u32 key[2] = {p0, p1};
-				scope_k0_cell<2, true>(key, k0, true, false); /* wave votes inside: every lane goes through, valid or not */
-				const bool v = ok[d];
-				if (((g_b + (u32)d) & 3u) == 0) /* content is coherent: the verdict holds for four loads */
-					absorb = __popcll(__ballot(!v || key[0] == key[1])) >= 48;
-				TRIO_ISSUE(d);
-				if (!v)
-					continue;
-				if (absorb) {
-					bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
-					if (!(e0 | e1)) {
-						if (st.count)
-							vss_add<0>(tab, st.colour, st.count);
-						st.colour = key[0];
-						st.count = 0;
-						e0 = true;
-						e1 = key[1] == key[0];
-					}
-					st.count += (u32)e0 + (u32)e1;
-					if (!e0)
-						vss_add<0>(tab, key[0], 1);
-					if (!e1)
-						vss_add<0>(tab, key[1], 1);
-				} else {
-					vss_add<0>(tab, key[0], 1);
-					vss_add<0>(tab, key[1], 1);
-				}
-			}
-		}
-		since += strip_px;
-		const bool last_strip = s_b + 1u == nst;
-		const bool clamp = !last_strip && since + strip_px > VSS_EPOCH_PIXELS;
-		if (last_strip || clamp)
-			vss_flush_lane<0>(tab, st); /* pending texels belong to the epoch that ends here */
-		__syncthreads();
-		{
-			/* the strip's 256 x 16 waveform texels: thread -> (value, group of four columns); the reader of a counter zeroes it */
-			const u32 xs = (first + s_b * stride) * 16u;
-			const u32 groups = (min(W - xs, 16u)) >> 2;
-			u32 o[4] = {0, 0, 0, 0};
-#pragma unroll
-			for (u32 c = 0; c < 3; c++) {
-				if (!((CH >> c) & 1))
-					continue;
-				uint2 *w = (uint2 *)&wt[slot_of[c] * (TRIO_CH_BYTES / 4u) + (value << 3) + 2u * g4];
-				const uint2 q = *w;
-				*w = make_uint2(0, 0);
-				o[0] |= min(q.x & 0xffffu, 255u) << (8u * c);
-				o[1] |= min(q.x >> 16, 255u) << (8u * c);
-				o[2] |= min(q.y & 0xffffu, 255u) << (8u * c);
-				o[3] |= min(q.y >> 16, 255u) << (8u * c);
-				if (HIS) /* columns past the right edge were never counted: their counters are zero */
-					hs[c] += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16);
-			}
-			if (g4 < groups) {
-				uint8_t *table = wvs_dst + (size_t)frame * ((size_t)SCOPE_WVS_ROWS * W * 4);
-				const scope_v4 t = {o[0], o[1], o[2], o[3]};
-				__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g4 << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
-			}
-		}
-		if (last_strip)
-			break;
-		if (clamp) {
-			vss_clamp_pass(tab);
-			since = 0;
-		}
-		__syncthreads();
-	}
-#undef TRIO_ISSUE
-
-	/* ---- the slice's vectorscope table: final (one slice per frame) or a sparse partial, as scope_vss_kernel ---------- */
-	{
-		const u32 unit = frame * slices + slice;
-		uint4 *out = (uint4 *)(vss_dst + (size_t)unit * SCOPE_VSS_BINS);
-		uint4 *outs = (uint4 *)vss_dst + ((size_t)frame * 256u * slices + slice) * 16u;
-		u32 wrote = 0, k = 0;
-		for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
-			const u32 row = 255u - (g >> 4);
-			const u32 w0 = (row << 7) + (((g & 15u) << 3) ^ ((row & 15u) << 3));
-			const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
-			if (!vss_mask) {
-				out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
-						    vss_clamp_pair(hi.z, hi.w));
-			} else if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0) {
-				const scope_v4 t = {vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
-						    vss_clamp_pair(hi.z, hi.w)};
-				__builtin_nontemporal_store(t, (scope_v4 *)outs + ((size_t)(g >> 4) * slices * 16u + (g & 15u)));
-				wrote |= 1u << k;
-			}
-		}
-		if (vss_mask)
-			vss_mask[(((size_t)frame * (blockDim.x >> 4) + (threadIdx.x >> 4)) * slices + slice) * 16u + (threadIdx.x & 15u)] =
-				(uint8_t)wrote;
-	}
-	if (HIS) {
-		/* the slice's totals -> the frame's accumulator (slot-major: a wave instruction covers 16 consecutive values), then
-		 * the arrival ticket; the workgroup that completes the frame moves the sums out and leaves accumulator and ticket zero */
-		u32 *acc_g = his.acc + (size_t)frame * SCOPE_HIS_WORDS;
-#pragma unroll
-		for (u32 c = 0; c < 3; c++)
-			if (((CH & his.chmask) >> c) & 1u)
-				if (hs[c])
-					__hip_atomic_fetch_add(&acc_g[(2u - c) * 256u + value], hs[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		/* (the barrier inside scope_last_arrival comes after every thread's reads of the table: word 0 may carry the verdict) */
-		if (scope_last_arrival(&his.tickets[frame], slices, &tab[0])) {
-			for (u32 t2 = threadIdx.x; t2 < SCOPE_HIS_WORDS; t2 += blockDim.x) {
-				const u32 val = t2 >> 2, slot = t2 & 3u;
-				his.out[(size_t)frame * SCOPE_HIS_WORDS + t2] =
-					__hip_atomic_exchange(&acc_g[slot * 256u + val], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			if (threadIdx.x == 0)
-				__hip_atomic_store(&his.tickets[frame], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-	}
-}
-
 /* Capture-side pre-steps: point-sampled 1/scale down-scale and ROI crop in one pass (cm_render_target,
  * src/common.c:249-250,272-282).  `src` points at the first sampled texel, `row_pitch` is the distance in
  * bytes between sampled rows and `col_step` the distance in texels between sampled columns.  A lane
@@ -1920,6 +1325,25 @@ __global__ __launch_bounds__(256) void scope_sat_reduce_sparse_kernel(const uint
 	wire[1] = make_uint4(b[8] | b[9] << 16, b[10] | b[11] << 16, b[12] | b[13] << 16, b[14] | b[15] << 16);
 }
 
+/* Plain streaming read of n 16-byte cells -- the yardstick scope_frame_pool_alloc times a candidate allocation with: 256
+ * threads per workgroup, four loads per lane in flight (the depth at which this chip reads fastest).
+ * The result goes nowhere; the comparison only keeps the loads alive. */
+__global__ __launch_bounds__(256) void scope_read_probe_kernel(const scope_v4 *p, u64 n, u32 *sink)
+{
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	scope_v4 acc = {0, 0, 0, 0};
+	for (; i + 3 * stride < n; i += 4 * stride) {
+		const scope_v4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+		const scope_v4 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+		acc ^= a ^ b ^ c ^ d;
+	}
+	for (; i < n; i += stride)
+		acc ^= __builtin_nontemporal_load(p + i);
+	if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink)
+		*sink = 1u;
+}
+
 __global__ __launch_bounds__(256) void scope_sum_reduce_kernel(const u32 *part, u32 *out, u32 slices, u32 len)
 {
 	const u32 frame = blockIdx.y;
@@ -1968,17 +1392,6 @@ __global__ __launch_bounds__(256) void scope_unpack16_clamp_kernel(const u32 *in
  * Launchers
  * ---------------------------------------------------------------------------------------- */
 
-
-/* A launch, optionally with the kernel's own begin / end time stamps delivered into two HIP events
- * (hipExtLaunchKernelGGL: the stamps come out of the dispatch packet, as rocprofv3's do -- events recorded around a
- * launch also time the gap the command processor leaves in front of the kernel, 5 % of a 0.3 ms launch). */
-#define SCOPE_LAUNCH(kernel, grid, block, lds, st, tm, ...)                                                        \
-	do {                                                                                                       \
-		if (tm)                                                                                            \
-			hipExtLaunchKernelGGL(kernel, grid, block, lds, st, (tm)->start, (tm)->stop, 0, __VA_ARGS__); \
-		else                                                                                               \
-			hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                             \
-	} while (0)
 
 namespace {
 
@@ -2193,46 +1606,6 @@ template <bool HIS> hipError_t dock_pick_ch(u32 chmask, const DockArgs *a)
 	}
 }
 
-struct TrioArgs {
-	const ScopeFrameSet *fs;
-	u32 strips, slices;
-	ScopeK0 k0;
-	uint8_t *wvs_dst;
-	ScopeWvsHis his;
-	uint8_t *vss_dst, *vss_mask;
-	hipStream_t st;
-	const ScopeTiming *tm;
-};
-template <int CH, bool HIS> hipError_t trio_variant(const TrioArgs *a)
-{
-	constexpr u32 nch = (CH & 1) + ((CH >> 1) & 1) + ((CH >> 2) & 1);
-	constexpr u32 lds = VSS_LDS_BYTES + nch * TRIO_CH_BYTES;
-	if (!a)
-		return hipFuncSetAttribute((const void *)scope_trio_kernel<CH, HIS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	SCOPE_LAUNCH((scope_trio_kernel<CH, HIS>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), lds, a->st, a->tm, *a->fs,
-		     a->strips, a->slices, a->k0, a->wvs_dst, a->his, a->vss_dst, a->vss_mask);
-	return hipGetLastError();
-}
-template <bool HIS> hipError_t trio_pick_ch(u32 chmask, const TrioArgs *a)
-{
-	switch (chmask & 7u) {
-	case 1:
-		return trio_variant<1, HIS>(a);
-	case 2:
-		return trio_variant<2, HIS>(a);
-	case 3:
-		return trio_variant<3, HIS>(a);
-	case 4:
-		return trio_variant<4, HIS>(a);
-	case 5:
-		return trio_variant<5, HIS>(a);
-	case 6:
-		return trio_variant<6, HIS>(a);
-	default:
-		return trio_variant<7, HIS>(a);
-	}
-}
-
 } // namespace
 
 hipError_t scope_kernels_init(void)
@@ -2257,11 +1630,9 @@ hipError_t scope_kernels_init(void)
 			e = dock_pick_ch<false>(chmask, NULL);
 		if (e == hipSuccess)
 			e = dock_pick_ch<true>(chmask, NULL);
-		if (e == hipSuccess)
-			e = trio_pick_ch<false>(chmask, NULL);
-		if (e == hipSuccess)
-			e = trio_pick_ch<true>(chmask, NULL);
 	}
+	if (e == hipSuccess)
+		e = scope_trio_init();
 	return e;
 }
 
@@ -2421,40 +1792,6 @@ hipError_t scope_launch_dock(const ScopeFrameSet &fs, uint32_t chmask, int color
 	return his ? dock_pick_ch<true>(chmask, &a) : dock_pick_ch<false>(chmask, &a);
 }
 
-bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const ScopeTuning &tn)
-{
-	/* the vector shape, a strip (16 x H texels) within the 16-bit counters' budget between two clamp passes, 32-bit offsets */
-	return scope_wvs_vector_shape(fs, wvs_dst, tn) && fs.height >= 1 && 16u * fs.height <= VSS_EPOCH_PIXELS &&
-	       (u64)fs.height * fs.linesize < (1ull << 31);
-}
-
-uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu)
-{
-	/* one workgroup per CU, every slice the same number of strips where that divides: 64 frames -> 4 slices of 60 strips,
-	 * three frames -> 80 of three, one -> 240 of one; even counts so that slices pair up (see the kernel) */
-	const u32 strips = scope_wvs_strips(fs.width, 1);
-	u32 s0 = max(1u, num_cu / max(1u, fs.n_frames));
-	s0 = min(min(s0, strips), 256u);
-	const u32 per = (strips + s0 - 1u) / s0;
-	u32 s = (strips + per - 1u) / per;
-	if (s > 1u && (s & 1u))
-		s++;
-	return min(s, 256u);
-}
-
-hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int colorspace, uint8_t *wvs_dst,
-			     const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st, const ScopeTiming *tm)
-{
-	if ((chmask & 7u) == 0 || slices == 0 || slices > 256u || (slices > 1 && !vss_mask))
-		return hipErrorInvalidValue;
-	ScopeWvsHis h = {NULL, NULL, NULL, 0};
-	if (his)
-		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
-	const TrioArgs a = {&fs, scope_wvs_strips(fs.width, 1), slices, scope_k0_matrix(colorspace), wvs_dst, h, vss_dst,
-			    slices > 1 ? vss_mask : NULL, st, tm};
-	return his ? trio_pick_ch<true>(chmask, &a) : trio_pick_ch<false>(chmask, &a);
-}
-
 hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n_frames, uint32_t slices, uint64_t len,
 				   int packed16, hipStream_t st)
 {
@@ -2475,6 +1812,13 @@ hipError_t scope_launch_sat_reduce_sparse(const uint8_t *part, const uint8_t *pm
 	const u32 lds = sl_log2 ? 8192u + 32u * gpw : 0u;
 	hipLaunchKernelGGL(scope_sat_reduce_sparse_kernel, dim3(SCOPE_VSS_BINS / 16 / gpw, n_frames), dim3(256), lds, st, part,
 			   pmask, out, slices, mask_block, sl_log2, packed16 ? 1u : 0u);
+	return hipGetLastError();
+}
+
+hipError_t scope_launch_read_probe(const void *p, uint64_t bytes, uint32_t num_cu, uint32_t *sink, hipStream_t st, const ScopeTiming *tm)
+{
+	const u32 grid = max(1u, num_cu) * 8u; /* eight 256-thread workgroups per CU: 32 KiB of loads in flight per CU */
+	SCOPE_LAUNCH(scope_read_probe_kernel, dim3(grid), dim3(256), 0, st, tm, (const scope_v4 *)p, (u64)(bytes / 16), sink);
 	return hipGetLastError();
 }
 

@@ -1,0 +1,408 @@
+/*
+ * scope_trio.hip -- scope_trio_kernel: the dock's three scopes (vectorscope through the fused K0, waveform, histogram) of
+ * every frame of a launch from ONE read of its RGB plane, both LDS tables resident (src/roi.c:329-341 hands one staged
+ * surface to every registered scope; the reference walks it three times).  A translation unit of its own: it is the
+ * kernel under development this round and compiles in a fraction of scope_kernels.hip's time.
+ *
+ * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (K0 must not be FMA-contracted).
+ */
+#include "scope_device.h"
+
+/* ------------------------------------------------------------------------------------------
+ * The dock's three scopes from ONE read, for ANY number of frames: scope_trio_kernel (round 3).
+ *
+ * scope_dock_kernel above reads a frame once but only where one round of strips covers the launch (one 4K frame), because it
+ * time-shares the LDS between the waveform's and the vectorscope's table and has to hold a strip's texels in registers in
+ * between; the ring of three and every batch fell back to two reads of the planes (1.91 x the algorithmic traffic).
+ *
+ * Here BOTH tables are resident: the vectorscope's 128 KiB (16-bit counters, swizzled rows, as scope_vss_kernel) plus a
+ * waveform table of ONE replica for a 16-column strip -- 256 values x 8 column pairs x 4 bytes = 8 KiB per channel, 24 KiB
+ * for RGB -- 152 KiB of the CU's 160.  A workgroup owns the strips of one slice of one frame and streams them like any
+ * other kernel here: every texel is loaded once, counted in the waveform table (alpha test, src/waveform.c:247-248), sent
+ * through the fixed-point K0 and counted in the vectorscope table, with TRIO_D loads per lane in flight and no register-held
+ * strip.  Per strip: barrier, the waveform's 256 x 16 output texels leave (the thread that reads a counter zeroes it, the
+ * histogram's totals accumulate in three registers per thread over all strips of the slice), the vectorscope's clamp
+ * pass when the next strip could overflow 16 bits, barrier; the loads of the next strip are in flight across it.  Per
+ * slice: ONE vectorscope partial (sparse, as scope_vss_kernel writes them; the final table when the frame has one slice)
+ * and <= 768 device atomics for the histogram.  64 frames: 4 slices of 60 strips per frame; three frames: 80 slices of
+ * three strips; one frame: 240 slices of one -- the dock kernel's shape.
+ *
+ * What the single replica costs: a half wave is 4 rows x 8 column pairs, word = value * 8 + pair, so two rows whose values
+ * agree mod 4 meet in one bank (2.1 x the conflict-free time on noise by the bank model of profiles/round1/
+ * lds_atomic_microbench.txt) -- LDS issue, not HBM, bounds this kernel.  The eight rows of a wave instruction lie H/8 apart
+ * (as in scope_dock_kernel), so that the equal values of vertically neighbouring texels do not meet on one ADDRESS.
+ *
+ * A strip's row segment is 64 bytes, half a cache line.  Slices come in pairs that split a range of strips even / odd, and
+ * the two workgroups of a pair are b and b + 8 (same XCD, same L2, same moment): the other half of every line is wanted by
+ * the partner while it is still in the L2.
+ * Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables), H <= 4080 (a strip's texels fit the
+ * vectorscope's 16-bit counters between two clamp passes).
+ * ---------------------------------------------------------------------------------------- */
+#ifndef TRIO_D
+#define TRIO_D 6 /* 8-byte loads in flight per lane; a strip's loads per lane are rounded up to a multiple of it */
+#endif
+#ifndef TRIO_NT
+#define TRIO_NT 1
+#endif
+#ifndef TRIO_SKIP
+#define TRIO_SKIP 0 /* 1: skip the K0 / vote work of slots that are empty for the whole wave (one of 18 at 4K).  Measured: 8 % SLOWER
+		     * (64 x 4K: 632 -> 685 us) -- the uniform branch around the slot's work costs hipcc's schedule of the whole
+		     * round more than the empty slot's instructions; profiles/round3/trio_variants.txt */
+#endif
+#ifndef TRIO_EXP
+#define TRIO_EXP 0 /* measurement only (wrong tables): bit 0 no waveform adds, 1 no vectorscope adds, 2 no K0, 3 no clamp pass */
+#endif
+#define TRIO_CH_BYTES 8192u
+#define TRIO_WVS_BASE (VSS_WORDS * 4u)
+
+template <int CH> __device__ __forceinline__ void trio_count(u32 *tab, u32 px, u32 lane_base, u32 inc)
+{
+	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1);
+	if (CH & 1)
+		scope_lds_add_at(tab, lane_base + ((px & 0xffu) << 5), inc);
+	if (CH & 2)
+		scope_lds_add_at(tab, lane_base + slot1 * TRIO_CH_BYTES + (((px >> 8) & 0xffu) << 5), inc);
+	if (CH & 4)
+		scope_lds_add_at(tab, lane_base + slot2 * TRIO_CH_BYTES + (((px >> 16) & 0xffu) << 5), inc);
+}
+
+template <int CH, bool HIS>
+__global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet fs, u32 strips, u32 slices, ScopeK0 k0_arg,
+								uint8_t *wvs_dst, ScopeWvsHis his, uint8_t *vss_dst, uint8_t *vss_mask)
+{
+	const ScopeK0 k0 = scope_k0_pinned(k0_arg, true, false);
+	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1), nch = slot2 + ((CH >> 2) & 1);
+	constexpr u32 slot_of[3] = {0, slot1, slot2};
+	constexpr int D = TRIO_D;
+	u32 *tab = scope_lds;
+	scope_lds_is_at_zero(tab);
+	u32 *wt = tab + VSS_WORDS; /* [nch][256 values][8 column pairs] */
+	const u32 W = fs.width, H = fs.height;
+	const u32 lane = threadIdx.x & 63u;
+	const u32 pair = lane & 7u, rsub = lane >> 3;
+	const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const u32 nwaves = blockDim.x >> 6;
+
+	/* ---- which strips are mine ------------------------------------------------------------------------------------ */
+	const u32 b = blockIdx.x, total = gridDim.x;
+	u32 frame, slice, first, last, stride;
+	if ((slices & 1u) == 0) {
+		/* pairs: workgroups b and b + 8 of a block of 16 share a range of strip PAIRS (a pair = one 128-byte line per row) and
+		 * take its even / odd strips */
+		const u32 half = slices >> 1, base = total & ~15u;
+		u32 p, parity;
+		if (b < base) {
+			p = ((b >> 4) << 3) + (b & 7u);
+			parity = (b >> 3) & 1u;
+		} else {
+			p = (base >> 1) + ((b - base) >> 1);
+			parity = (b - base) & 1u;
+		}
+		frame = p / half;
+		const u32 q = p - frame * half;
+		const u32 spairs = (strips + 1u) >> 1;
+		first = 2u * scope_slice_begin(spairs, q, half) + parity;
+		last = min(2u * scope_slice_begin(spairs, q + 1u, half), strips);
+		stride = 2;
+		slice = 2u * q + parity;
+	} else {
+		frame = b / slices;
+		slice = b - frame * slices;
+		first = scope_slice_begin(strips, slice, slices);
+		last = scope_slice_begin(strips, slice + 1u, slices);
+		stride = 1;
+	}
+	const u32 nst = first < last ? (last - first + stride - 1u) / stride : 0u;
+	const uint8_t *plane = fs.plane[frame];
+
+	/* rows of a lane: rsub * rps + i, i = wave, wave + nwaves, ...; G loads per lane and strip, rounded up to whole rounds of D */
+	const u32 rps = (H + 7u) >> 3;
+	const u32 row0 = rsub * rps;
+	const u32 G = (rps + nwaves - 1u) / nwaves;
+	const u32 Gp = ((G + (u32)D - 1u) / (u32)D) * (u32)D;
+	const u32 dstep = nwaves * fs.linesize;
+	const u32 lane_base = TRIO_WVS_BASE + (pair << 2);
+
+	/* ---- issue side ------------------------------------------------------------------------------------------------ */
+	u32 px[D][2];
+	bool ok[D];
+	bool wok[D]; /* wave-uniform: does this slot hold rows for anybody in the wave?  (the rounding of G up to whole rounds, and
+		      * the last waves' last rows, leave slots that are empty for the whole wave: their K0 and votes are skipped) */
+	u32 s_i = 0, g_i = 0, off_i = 0;
+	bool live_i = false;
+	auto strip_start = [&](u32 s) {
+		const u32 x0 = (first + s * stride) * 16u + 2u * pair;
+		live_i = s < nst && x0 < W; /* W % 4 == 0: both texels of the pair or none */
+		off_i = (row0 + wave) * fs.linesize + x0 * 4u;
+	};
+	strip_start(0);
+#define TRIO_ISSUE(d)                                                                                                  \
+	do {                                                                                                           \
+		const u32 i_ = wave + g_i * nwaves;                                                                    \
+		wok[d] = s_i < nst && i_ < rps;                                                                        \
+		ok[d] = live_i && i_ < rps && row0 + i_ < H;                                                           \
+		scope_u2 t_;                                                                                           \
+		if (TRIO_NT)                                                                                           \
+			t_ = scope_load_row2_nt(plane, ok[d] ? off_i : 0u);                                            \
+		else                                                                                                   \
+			t_ = scope_load_row2(plane, ok[d] ? off_i : 0u);                                               \
+		px[d][0] = t_.x;                                                                                       \
+		px[d][1] = t_.y;                                                                                       \
+		off_i += dstep;                                                                                        \
+		if (++g_i == Gp) {                                                                                     \
+			g_i = 0;                                                                                       \
+			strip_start(++s_i);                                                                            \
+		}                                                                                                      \
+	} while (0)
+#pragma unroll
+	for (int d = 0; d < D; d++)
+		TRIO_ISSUE(d);
+
+	/* both tables zeroed under the first loads */
+	{
+		const uint4 zero = make_uint4(0, 0, 0, 0);
+		for (u32 i = threadIdx.x * 4; i < VSS_WORDS + nch * (TRIO_CH_BYTES / 4u); i += blockDim.x * 4)
+			*(uint4 *)&tab[i] = zero;
+	}
+	__syncthreads();
+
+	VssLane st = {0xffffffffu, 0};
+	bool absorb = false; /* wave-uniform */
+	u32 since = 0;       /* texels the vectorscope table may have taken since its last clamp pass (uniform) */
+	const u32 strip_px = 16u * H;
+	u32 hs[3] = {0, 0, 0}; /* HIS: this thread's (value, column group) totals over the slice's strips */
+	const u32 value = threadIdx.x >> 2, g4 = threadIdx.x & 3u;
+
+	for (u32 s_b = 0; s_b < nst; s_b++) {
+		for (u32 g_b = 0; g_b < Gp; g_b += (u32)D) {
+#pragma unroll
+			for (int d = 0; d < D; d++) {
+				const bool w = TRIO_SKIP ? wok[d] : true, v = ok[d]; /* w: wave-uniform */
+				const u32 p0 = px[d][0], p1 = px[d][1];
+				u32 key[2] = {p0, p1};
+				if (w) {
+					if (v && !(TRIO_EXP & 1)) {
+						if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
+							trio_count<CH>(tab, p0, lane_base, 1u);
+						if ((p1 >> 24) != 0)
+							trio_count<CH>(tab, p1, lane_base, 65536u);
+					}
+					if (TRIO_EXP & 4) {
+						key[0] = vss_bin(p0);
+						key[1] = vss_bin(p1);
+					} else {
+						scope_k0_cell<2, true>(key, k0, true, false); /* wave votes inside: every lane goes through, valid or not */
+					}
+					if (((g_b + (u32)d) & 3u) == 0) /* content is coherent: the verdict holds for four loads */
+						absorb = __popcll(__ballot(!v || key[0] == key[1])) >= 48;
+				}
+				TRIO_ISSUE(d); /* ONE issue point per slot, whatever the slot held: the load queue has the same shape on every path */
+				if (!(w && v) || (TRIO_EXP & 2))
+					continue;
+				if (absorb) {
+					bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
+					if (!(e0 | e1)) {
+						if (st.count)
+							vss_add<0>(tab, st.colour, st.count);
+						st.colour = key[0];
+						st.count = 0;
+						e0 = true;
+						e1 = key[1] == key[0];
+					}
+					st.count += (u32)e0 + (u32)e1;
+					if (!e0)
+						vss_add<0>(tab, key[0], 1);
+					if (!e1)
+						vss_add<0>(tab, key[1], 1);
+				} else {
+					vss_add<0>(tab, key[0], 1);
+					vss_add<0>(tab, key[1], 1);
+				}
+			}
+		}
+		since += strip_px;
+		const bool last_strip = s_b + 1u == nst;
+		const bool clamp = !last_strip && since + strip_px > VSS_EPOCH_PIXELS;
+		if (last_strip || clamp)
+			vss_flush_lane<0>(tab, st); /* pending texels belong to the epoch that ends here */
+		__syncthreads();
+		{
+			/* the strip's 256 x 16 waveform texels: thread -> (value, group of four columns); the reader of a counter zeroes it */
+			const u32 xs = (first + s_b * stride) * 16u;
+			const u32 groups = (min(W - xs, 16u)) >> 2;
+			u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+			for (u32 c = 0; c < 3; c++) {
+				if (!((CH >> c) & 1))
+					continue;
+				uint2 *w = (uint2 *)&wt[slot_of[c] * (TRIO_CH_BYTES / 4u) + (value << 3) + 2u * g4];
+				const uint2 q = *w;
+				*w = make_uint2(0, 0);
+				o[0] |= min(q.x & 0xffffu, 255u) << (8u * c);
+				o[1] |= min(q.x >> 16, 255u) << (8u * c);
+				o[2] |= min(q.y & 0xffffu, 255u) << (8u * c);
+				o[3] |= min(q.y >> 16, 255u) << (8u * c);
+				if (HIS) /* columns past the right edge were never counted: their counters are zero */
+					hs[c] += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16);
+			}
+			if (g4 < groups) {
+				uint8_t *table = wvs_dst + (size_t)frame * ((size_t)SCOPE_WVS_ROWS * W * 4);
+				const scope_v4 t = {o[0], o[1], o[2], o[3]};
+				__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g4 << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
+			}
+		}
+		if (last_strip)
+			break;
+		if (clamp && !(TRIO_EXP & 8)) {
+			vss_clamp_pass(tab);
+			since = 0;
+		}
+		__syncthreads();
+	}
+#undef TRIO_ISSUE
+
+	/* ---- the slice's vectorscope table: final (one slice per frame) or a sparse partial, as scope_vss_kernel ---------- */
+	{
+		const u32 unit = frame * slices + slice;
+		uint4 *out = (uint4 *)(vss_dst + (size_t)unit * SCOPE_VSS_BINS);
+		uint4 *outs = (uint4 *)vss_dst + ((size_t)frame * 256u * slices + slice) * 16u;
+		u32 wrote = 0, k = 0;
+		for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
+			const u32 row = 255u - (g >> 4);
+			const u32 w0 = (row << 7) + (((g & 15u) << 3) ^ ((row & 15u) << 3));
+			const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
+			if (!vss_mask) {
+				out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
+						    vss_clamp_pair(hi.z, hi.w));
+			} else if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0) {
+				const scope_v4 t = {vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
+						    vss_clamp_pair(hi.z, hi.w)};
+				__builtin_nontemporal_store(t, (scope_v4 *)outs + ((size_t)(g >> 4) * slices * 16u + (g & 15u)));
+				wrote |= 1u << k;
+			}
+		}
+		if (vss_mask)
+			vss_mask[(((size_t)frame * (blockDim.x >> 4) + (threadIdx.x >> 4)) * slices + slice) * 16u + (threadIdx.x & 15u)] =
+				(uint8_t)wrote;
+	}
+	if (HIS) {
+		/* the slice's totals -> the frame's accumulator, then the arrival ticket; the workgroup that completes the frame moves the
+		 * sums out and leaves accumulator and ticket zero.  The four column groups of a value meet in LDS first (the vectorscope
+		 * table's space, read out by now): ONE device atomic per value and channel and workgroup.  (Four lanes of a wave
+		 * instruction on one address cost dearly at the memory side: a one-frame launch of 240 workgroups took 440 us that way.) */
+		u32 *acc_g = his.acc + (size_t)frame * SCOPE_HIS_WORDS;
+		__syncthreads();
+#pragma unroll
+		for (u32 c = 0; c < 3; c++)
+			tab[c * 1024u + threadIdx.x] = hs[c];
+		__syncthreads();
+		for (u32 t2 = threadIdx.x; t2 < 768u; t2 += blockDim.x) {
+			const u32 c = t2 >> 8, val = t2 & 255u;
+			const uint4 q = *(const uint4 *)&tab[c * 1024u + 4u * val];
+			const u32 sum = q.x + q.y + q.z + q.w;
+			if (sum && (((CH & his.chmask) >> c) & 1u))
+				__hip_atomic_fetch_add(&acc_g[(2u - c) * 256u + val], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		/* (the barrier inside scope_last_arrival comes after every thread's reads of the table: word 0 may carry the verdict) */
+		if (scope_last_arrival(&his.tickets[frame], slices, &tab[0])) {
+			for (u32 t2 = threadIdx.x; t2 < SCOPE_HIS_WORDS; t2 += blockDim.x) {
+				const u32 val = t2 >> 2, slot = t2 & 3u;
+				his.out[(size_t)frame * SCOPE_HIS_WORDS + t2] =
+					__hip_atomic_exchange(&acc_g[slot * 256u + val], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (threadIdx.x == 0)
+				__hip_atomic_store(&his.tickets[frame], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
+namespace {
+
+struct TrioArgs {
+	const ScopeFrameSet *fs;
+	u32 strips, slices;
+	ScopeK0 k0;
+	uint8_t *wvs_dst;
+	ScopeWvsHis his;
+	uint8_t *vss_dst, *vss_mask;
+	hipStream_t st;
+	const ScopeTiming *tm;
+};
+template <int CH, bool HIS> hipError_t trio_variant(const TrioArgs *a)
+{
+	constexpr u32 nch = (CH & 1) + ((CH >> 1) & 1) + ((CH >> 2) & 1);
+	constexpr u32 lds = VSS_WORDS * 4u + nch * TRIO_CH_BYTES;
+	if (!a)
+		return hipFuncSetAttribute((const void *)scope_trio_kernel<CH, HIS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	SCOPE_LAUNCH((scope_trio_kernel<CH, HIS>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), lds, a->st, a->tm, *a->fs,
+		     a->strips, a->slices, a->k0, a->wvs_dst, a->his, a->vss_dst, a->vss_mask);
+	return hipGetLastError();
+}
+template <bool HIS> hipError_t trio_pick_ch(u32 chmask, const TrioArgs *a)
+{
+	switch (chmask & 7u) {
+	case 1:
+		return trio_variant<1, HIS>(a);
+	case 2:
+		return trio_variant<2, HIS>(a);
+	case 3:
+		return trio_variant<3, HIS>(a);
+	case 4:
+		return trio_variant<4, HIS>(a);
+	case 5:
+		return trio_variant<5, HIS>(a);
+	case 6:
+		return trio_variant<6, HIS>(a);
+	default:
+		return trio_variant<7, HIS>(a);
+	}
+}
+
+} // namespace
+
+hipError_t scope_trio_init(void)
+{
+	hipError_t e = hipSuccess;
+	for (u32 chmask = 1; chmask <= 7; chmask++) {
+		if (e == hipSuccess)
+			e = trio_pick_ch<false>(chmask, NULL);
+		if (e == hipSuccess)
+			e = trio_pick_ch<true>(chmask, NULL);
+	}
+	return e;
+}
+
+bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const ScopeTuning &tn)
+{
+	/* the vector shape, a strip (16 x H texels) within the 16-bit counters' budget between two clamp passes, 32-bit offsets */
+	return scope_wvs_vector_shape(fs, wvs_dst, tn) && fs.height >= 1 && 16u * fs.height <= VSS_EPOCH_PIXELS &&
+	       (u64)fs.height * fs.linesize < (1ull << 31);
+}
+
+uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu)
+{
+	/* one workgroup per CU, every slice the same number of strips where that divides: 64 frames -> 4 slices of 60 strips,
+	 * three frames -> 80 of three, one -> 240 of one; even counts so that slices pair up (see the kernel) */
+	const u32 strips = scope_wvs_strips(fs.width, 1);
+	u32 s0 = max(1u, num_cu / max(1u, fs.n_frames));
+	s0 = min(min(s0, strips), 256u);
+	const u32 per = (strips + s0 - 1u) / s0;
+	u32 s = (strips + per - 1u) / per;
+	if (s > 1u && (s & 1u))
+		s++;
+	return min(s, 256u);
+}
+
+hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int colorspace, uint8_t *wvs_dst,
+			     const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st, const ScopeTiming *tm)
+{
+	if ((chmask & 7u) == 0 || slices == 0 || slices > 256u || (slices > 1 && !vss_mask))
+		return hipErrorInvalidValue;
+	ScopeWvsHis h = {NULL, NULL, NULL, 0};
+	if (his)
+		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
+	const TrioArgs a = {&fs, scope_wvs_strips(fs.width, 1), slices, scope_k0_matrix(colorspace), wvs_dst, h, vss_dst,
+			    slices > 1 ? vss_mask : NULL, st, tm};
+	return his ? trio_pick_ch<true>(chmask, &a) : trio_pick_ch<false>(chmask, &a);
+}
+

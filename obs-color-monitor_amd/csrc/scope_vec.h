@@ -131,6 +131,17 @@ SCOPE_MUL24_BYTE(scope_umul24_byte1, "v_mul_u32_u24_sdwa", unsigned, "BYTE_1")
 SCOPE_MUL24_BYTE(scope_umul24_byte2, "v_mul_u32_u24_sdwa", unsigned, "BYTE_2")
 #undef SCOPE_MUL24_BYTE
 
+/* A wave-uniform value pinned into a VECTOR register for the rest of the kernel.  v_mad_i32_i24 takes one scalar operand
+ * (gfx9 constant bus): with coefficient AND constant term in SGPRs hipcc moves the constant into a VGPR again before every
+ * multiply-add -- one VALU instruction per matrix row and cell in the fused kernels.  The asm is opaque, so the copy is
+ * made once and kept. */
+__device__ __forceinline__ int scope_pin_vgpr(int uniform)
+{
+	int v;
+	asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
+	return v;
+}
+
 /* Every VMEM operation of this wave (loads, stores, atomics without return) has been acknowledged.  Inline asm:
  * hipcc (ROCm 7.2) drops a builtin wait when its own scoreboard says nothing is outstanding (MI355X_MICROARCH.md). */
 __device__ __forceinline__ void scope_drain_vmem()

@@ -19,13 +19,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libscope_hip.so")
 
 OK, EINVAL, ENOMEM, ENODEV, EIO, ENODATA, EAGAIN = 0, -22, -12, -19, -5, -61, -11
-IN_DEVICE, OUT_DEVICE, ASYNC, FUSE_K0, OUT_PACKED16 = 0x1, 0x2, 0x4, 0x8, 0x10
+IN_DEVICE, OUT_DEVICE, ASYNC, FUSE_K0, OUT_PACKED16, SIDE_REDUCE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 COMP_RGB, COMP_Y, COMP_UV, COMP_YUV = 0x07, 0x20, 0x50, 0x70
 
 # every symbol include/scope_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "scope_abi_version", "scope_strerror", "scope_last_error",
-    "scope_ctx_create", "scope_ctx_destroy", "scope_ctx_set_stream", "scope_ctx_get_stream", "scope_ctx_sync",
+    "scope_ctx_create", "scope_ctx_destroy", "scope_ctx_set_stream", "scope_ctx_get_stream", "scope_ctx_sync", "scope_ctx_fence",
     "scope_ctx_device_info", "scope_ctx_set_option",
     "scope_convert_rgb_yuv",
     "scope_vectorscope", "scope_waveform", "scope_histogram_counts", "scope_histogram", "scope_histogram_level",
@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "scope_pipe_create", "scope_pipe_destroy", "scope_pipe_submit", "scope_pipe_collect", "scope_pipe_size",
     "scope_region_size", "scope_stage_region", "scope_surface_begin", "scope_surface_end",
     "scope_rccl_unique_id", "scope_rccl_comm_create", "scope_rccl_comm_destroy", "scope_table_allreduce", "scope_rccl_comm_info",
+    "scope_frame_pool_alloc", "scope_frame_pool_free",
     "scope_display_graticule", "scope_graticule_label_strip",
     "scope_display_vectorscope", "scope_display_vectorscope_zoom", "scope_display_waveform", "scope_display_histogram", "scope_display_size",
 )
@@ -114,6 +115,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_ctx_set_stream": (i32, [vp, vp]),
         "scope_ctx_get_stream": (vp, [vp]),
         "scope_ctx_sync": (i32, [vp]),
+        "scope_ctx_fence": (i32, [vp]),
         "scope_ctx_device_info": (i32, [vp, C.POINTER(DeviceInfo)]),
         "scope_ctx_set_option": (i32, [vp, C.c_char_p, i32]),
         "scope_convert_rgb_yuv": (i32, [vp, vp, u32, vp, u32, u32, u32, i32, u32]),
@@ -137,6 +139,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_rccl_comm_destroy": (i32, [vp]),
         "scope_table_allreduce": (i32, [vp, vp, vp, u64]),
         "scope_rccl_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "scope_frame_pool_alloc": (i32, [vp, u64, u32, C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(u32)]),
+        "scope_frame_pool_free": (i32, [vp, vp]),
         "scope_ctx_profile": (i32, [vp, i32]),
         "scope_ctx_kernel_ms": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
         "scope_display_vectorscope": (i32, [vp, vp, i32, i32, i32, u32, vp]),
@@ -224,6 +228,10 @@ class ScopeContext:
 
     def sync(self):
         self._check(self.L.scope_ctx_sync(self.h))
+
+    def fence(self):
+        """The context's stream waits (on the device) for the side stream's reductions of side_reduce=True calls."""
+        self._check(self.L.scope_ctx_fence(self.h))
 
     # -- host-buffer calls (the plugin's situation: a mapped staging surface) --------------------
     @staticmethod
@@ -384,11 +392,13 @@ class ScopeContext:
             ptrs = [int(t.data_ptr()) for t in frames_dev]
         return self._batch(ptrs, linesize, width, height, planes_are_rgb, colorspace)
 
-    def vectorscope_batch_dev(self, batch, out_dev, sync=True, packed16=False):
-        """packed16: out_dev is int32[n][32768], two bins per word (the wire format of TableAllReduce)."""
+    def vectorscope_batch_dev(self, batch, out_dev, sync=True, packed16=False, side_reduce=False):
+        """packed16: out_dev is int32[n][32768], two bins per word (the wire format of TableAllReduce).
+        side_reduce (with sync=False): the partial-table reduction goes to the context's second stream; the table is
+        complete after fence() / sync() / the next call without it."""
         self._check(self.L.scope_vectorscope_batch(self.h, C.byref(batch),
-                                                   IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC) | (OUT_PACKED16 if packed16 else 0),
-                                                   _dptr(out_dev)))
+                                                   IN_DEVICE | OUT_DEVICE | (0 if sync else ASYNC) | (OUT_PACKED16 if packed16 else 0) |
+                                                   (SIDE_REDUCE if side_reduce else 0), _dptr(out_dev)))
 
     def waveform_batch_dev(self, batch, components, out_dev, sync=True):
         self._check(self.L.scope_waveform_batch(self.h, C.byref(batch), components,
@@ -489,6 +499,13 @@ class ScopeContext:
         """In-place uint32 sum over the communicator, enqueued on the context's stream."""
         self._check(self.L.scope_table_allreduce(self.h, C.c_void_p(comm), _dptr(words_dev), n_words))
 
+    # -- frame pools placed by the library (scope_frame_pool_alloc) ---------------------------------------------------
+    def frame_pool_alloc(self, n_bytes: int, candidates: int = 6):
+        """(FramePool, read GB/s per candidate -- the kept one first).  FramePool.tensor(torch, shape) views the memory."""
+        ptr, rates, tried = C.c_void_p(), (C.c_float * 16)(), C.c_uint32()
+        self._check(self.L.scope_frame_pool_alloc(self.h, n_bytes, candidates, C.byref(ptr), rates, C.byref(tried)))
+        return FramePool(self, int(ptr.value), n_bytes), [round(float(rates[i]), 1) for i in range(tried.value)]
+
     def profile(self, enable: bool):
         self._check(self.L.scope_ctx_profile(self.h, int(enable)))
 
@@ -497,6 +514,24 @@ class ScopeContext:
         n, ms = C.c_uint32(), C.c_float()
         self._check(self.L.scope_ctx_kernel_ms(self.h, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
+
+
+class FramePool:
+    """Device memory from scope_frame_pool_alloc; exposes the CUDA array interface so that torch can view it."""
+
+    def __init__(self, ctx: ScopeContext, ptr: int, n_bytes: int):
+        self.ctx, self.ptr, self.n_bytes = ctx, ptr, n_bytes
+        self.__cuda_array_interface__ = {"shape": (n_bytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def tensor(self, torch, shape):
+        """A uint8 torch tensor over the pool (the pool must outlive it: keep this object)."""
+        t = torch.as_tensor(self, device="cuda")
+        return t[: int(np.prod(shape))].view(*shape)
+
+    def free(self):
+        if self.ptr:
+            self.ctx._check(self.ctx.L.scope_frame_pool_free(self.ctx.h, C.c_void_p(self.ptr)))
+            self.ptr = 0
 
 
 class ScopePipe:

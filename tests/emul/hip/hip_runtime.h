@@ -93,6 +93,11 @@ hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st);
 hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v);
 typedef struct emul_event_t *hipEvent_t;
 hipError_t hipEventCreate(hipEvent_t *e);
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned)
+{
+	return hipEventCreate(e);
+}
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);

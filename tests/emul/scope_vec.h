@@ -46,6 +46,11 @@ static inline scope_u2 scope_load_row2_nt(const unsigned char *row, unsigned lan
 	return scope_u2{p[0], p[1]};
 }
 
+static inline scope_u2 scope_load_row2(const unsigned char *row, unsigned lane_off)
+{
+	return scope_load_row2_nt(row, lane_off);
+}
+
 static inline unsigned scope_perm(unsigned hi, unsigned lo, unsigned sel)
 {
 	const unsigned long long src = ((unsigned long long)hi << 32) | lo;
@@ -115,6 +120,11 @@ static inline void scope_lds_add_at(unsigned *tab, unsigned byte, unsigned n)
 }
 static inline void scope_lds_is_at_zero(unsigned *)
 {
+}
+
+static inline int scope_pin_vgpr(int uniform)
+{
+	return uniform;
 }
 
 static inline unsigned scope_wave_sum(unsigned x)

@@ -512,3 +512,32 @@ def check_three_scopes_dev(ctx, oracle, to_dev, to_host, w, h, dists, wc=0x07, h
             assert_same(vss[f], oracle.vectorscope(yuv, w), "dock vectorscope " + tag)
             assert_same(wvs[f], oracle.waveform(rgb, yuv, w, wc), f"dock waveform {wc:#x} " + tag)
             assert_same(his[f], oracle.histogram_counts(rgb, yuv, w, hc), f"dock histogram {hc:#x} " + tag)
+
+
+def check_vectorscope_side_reduce(ctx, oracle, to_dev, to_host, w, h, dists, calls=12, fuse=False):
+    """SCOPE_SIDE_REDUCE: a train of one-frame calls whose reductions run on the context's second stream (two sets of
+    partial tables used in turn), every call into a table of its own; after scope_ctx_fence + sync every table equals the
+    oracle's.  Then a call WITHOUT the flag right behind flagged ones: it fences by itself."""
+    import numpy as np
+
+    pairs = [frames(oracle, w, h, d, seed=900 + d) for d in dists]
+    ls = pairs[0][0].shape[1]
+    planes = []
+    for rgb, yuv in pairs:
+        hnd, addr = to_dev((rgb if fuse else yuv).reshape(-1))
+        planes.append((hnd, addr))
+    batches = [ctx._batch([addr], ls, w, h, fuse, 2) for _, addr in planes]
+    outs = [to_dev(np.full(65536, 0xEE, np.uint8)) for _ in range(calls)]
+    for i in range(calls):
+        ctx.vectorscope_batch_dev(batches[i % len(batches)], outs[i][1], sync=False, side_reduce=True)
+    ctx.fence()
+    ctx.sync()
+    for i in range(calls):
+        assert_same(to_host(outs[i][0]).reshape(256, 256), oracle.vectorscope(pairs[i % len(pairs)][1], w), f"side reduce call {i}")
+    # flagged, flagged, then plain: the plain call fences, and its own table is right as well
+    extra = [to_dev(np.full(65536, 0xEE, np.uint8)) for _ in range(3)]
+    ctx.vectorscope_batch_dev(batches[0], extra[0][1], sync=False, side_reduce=True)
+    ctx.vectorscope_batch_dev(batches[-1], extra[1][1], sync=False, side_reduce=True)
+    ctx.vectorscope_batch_dev(batches[0], extra[2][1], sync=True)
+    for k, which in enumerate((0, -1, 0)):
+        assert_same(to_host(extra[k][0]).reshape(256, 256), oracle.vectorscope(pairs[which][1], w), f"side reduce then plain, table {k}")

@@ -139,10 +139,11 @@ def test_waveform_deep_queue_across_flushes(emul_ctx, oracle):
         pc.check_waveform(emul_ctx, oracle, 512, 265, 5, 0x07)
 
 
-@pytest.mark.parametrize("dock", [1, 0])
+@pytest.mark.parametrize("dock", [1, 2, 0])
 def test_three_scopes_one_read(emul_ctx, oracle, dock):
-    """scope_dock_kernel: one read of the plane for waveform + histogram + vectorscope (the emulated chip has 6 CUs, so
-    up to six 16-column strips qualify); dock=0 is the two-pass form of the same entry point."""
+    """One read of the plane for waveform + histogram + vectorscope.  dock=1: scope_trio_kernel (both tables resident in LDS,
+    any number of frames, slices of strips); dock=2: round 2's scope_dock_kernel (the emulated chip has 6 CUs, so up to six
+    16-column strips qualify, the rest takes two passes); dock=0: always the two-pass form of the same entry point."""
     with pc.options(emul_ctx, dock=dock):
         dev = lambda *a, **k: pc.check_three_scopes_dev(emul_ctx, oracle, _np_dev, lambda hnd: hnd, *a, **k)  # noqa: E731
         dev(72, 19, [5])                                  # 5 strips, the last one 8 columns wide, row ranges of 3 rows
@@ -151,7 +152,12 @@ def test_three_scopes_one_read(emul_ctx, oracle, dock):
         dev(16, 9, [1, 2], 0x02, 0x02, reps=1)            # two frames in one launch
         dev(100, 5, [1], reps=1)                          # 7 strips on 6 CUs: two passes
         dev(80, 2170, [2], reps=1)                        # 17 loads per lane, the last ones partly past the end
-        dev(16, 2300, [1], reps=1)                        # more rows than the registers hold: two passes
+        dev(16, 2300, [1], reps=1)                        # more rows than the dock kernel's registers hold
+        if dock == 1:
+            dev(32, 2100, [3, 1, 2, 5, 1, 3], reps=1)     # six frames on six CUs: one slice of TWO strips per frame, final tables
+                                                          # straight from the kernel, a clamp pass between the strips (flat: saturates)
+            dev(200, 40, [1, 5], 0x06, 0x02, reps=2)      # 13 strips (the last 8 columns wide) in 4 paired slices per frame
+            dev(16, 4090, [1], reps=1)                    # a strip beyond the 16-bit budget: two passes
 
 
 def test_three_scopes_host_planes(emul_ctx, oracle):
@@ -323,3 +329,34 @@ def test_k0_all_colours_fixed_point_path(emul_ctx, oracle, cs):
     v = np.arange(1 << 24, dtype=np.uint32) | np.uint32(0xFF000000)
     rgb = v.view(np.uint8).reshape(4096, 4096 * 4)
     pc.assert_same(emul_ctx.convert_rgb_yuv(rgb, 4096, cs), oracle.rgb_to_yuv(rgb, 4096, cs), f"K0 exhaustive cs{cs}")
+
+
+def test_frame_pool_alloc_and_free(emul_ctx):
+    """scope_frame_pool_alloc: several candidate allocations, each read and timed, the fastest kept and the rest freed;
+    the kept pool is ordinary device memory a scope reads from."""
+    import ctypes as C
+
+    pool, rates = emul_ctx.frame_pool_alloc(64 * 36 * 4, candidates=3)
+    assert pool.ptr and len(rates) == 3 and rates[0] == max(rates)
+    w, h = 64, 36
+    import scope_oracle
+
+    o = scope_oracle.COracle()
+    rgb = o.fill_frame(w, h, 1, 9)
+    yuv = o.rgb_to_yuv(rgb, w, 2)
+    C.memmove(pool.ptr, yuv.ctypes.data, yuv.nbytes)
+    b = emul_ctx._batch([pool.ptr], 4 * w, w, h, False, 2)
+    out = np.zeros(65536, dtype=np.uint8)
+    emul_ctx.vectorscope_batch_dev(b, out.ctypes.data)
+    assert np.array_equal(out.reshape(256, 256), o.vectorscope(yuv, w))
+    pool.free()
+    one, rates = emul_ctx.frame_pool_alloc(4096, candidates=1)  # a plain allocation: nothing to compare
+    assert one.ptr and rates == [0.0]
+    one.free()
+    with pytest.raises(Exception):
+        emul_ctx.frame_pool_alloc(0, 2)
+
+
+def test_vectorscope_side_reduce(emul_ctx, oracle):
+    pc.check_vectorscope_side_reduce(emul_ctx, oracle, _np_dev, lambda hnd: hnd, 96, 40, [1, 5, 2], calls=7)
+    pc.check_vectorscope_side_reduce(emul_ctx, oracle, _np_dev, lambda hnd: hnd, 64, 30, [5, 3], calls=4, fuse=True)

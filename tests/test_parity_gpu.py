@@ -154,10 +154,12 @@ def test_one_and_three_frame_launches_4k(hip_ctx, oracle):
         for rep in range(3):  # accumulators and tickets must come back to zero
             for batch in (by, br):
                 vss.fill_(0xEE)
+                torch.cuda.synchronize()  # torch fills on ITS stream; the context launches on its own (non-blocking) one
                 hip_ctx.vectorscope_batch_dev(batch, vss)
                 for f in range(n):
                     pc.assert_same(vss[f].cpu().numpy().reshape(256, 256), oracle.vectorscope(yuvs[f], w), f"vss n{n} f{f}")
             cnt.fill_(-1)
+            torch.cuda.synchronize()  # torch fills on ITS stream; the context launches on its own (non-blocking) one
             hip_ctx.histogram_counts_batch_dev(br, 0x07, cnt)
             for f in range(n):
                 pc.assert_same(cnt[f].cpu().numpy().view(np.uint32).reshape(256, 4),
@@ -179,11 +181,12 @@ def test_randomised_geometries(hip_ctx, oracle):
     assert fz.run(hip_ctx, oracle, 60, 5, lambda m: None) == 60
 
 
-@pytest.mark.parametrize("dock", [1, 0])
+@pytest.mark.parametrize("dock", [1, 2, 0])
 def test_three_scopes_one_read(hip_ctx, oracle, dock):
-    """scope_three_scopes_batch: the dock's three scopes of a frame.  Small device-resident launches read the plane ONCE
-    (scope_dock_kernel: the strip's texels stay in registers, waveform + histogram first, the vectorscope through the fused
-    K0 second); dock=0 forces the two-pass form.  Both against the oracle: 4K on every content kind, ragged last strips,
+    """scope_three_scopes_batch: the dock's three scopes of a frame from ONE read of the plane.  dock=1: scope_trio_kernel
+    (both tables resident in LDS, any number of frames); dock=2: round 2's scope_dock_kernel for launches of one round of
+    strips (the strip's texels stay in registers, waveform + histogram first, the vectorscope through the fused K0 second;
+    other launches take two passes); dock=0 forces the two-pass form.  All against the oracle: 4K on every content kind, ragged last strips,
     heights that leave row ranges partly empty, padded pitches, BT.601, every RGB mask, two small frames in one launch,
     a frame too tall for the registers (falls back), host planes."""
     to_dev, to_host = _torch_dev()
@@ -203,8 +206,26 @@ def test_three_scopes_one_read(hip_ctx, oracle, dock):
         dev(4, 5, [1])
         dev(64, 2300, [1], reps=1)   # more than 2176 rows: two passes
         dev(330, 77, [5], reps=1)    # width % 4 != 0: two passes
-        dev(3840, 2160, [1, 2, 5], reps=1)  # 720 strips: two passes
+        dev(3840, 2160, [1, 2, 5], reps=1)  # the ring of three: 80 slices of three strips per frame (dock=2: two passes)
         pc.check_three_scopes_host(hip_ctx, oracle, 640, 360, 5)
+
+
+def test_three_scopes_batches_one_read(hip_ctx, oracle):
+    """scope_trio_kernel in its batch shapes: twelve 4K frames of every content kind (20 paired slices of twelve strips per
+    frame, a clamp pass of the vectorscope table before every strip but the first; flat frames saturate bins and columns),
+    64 small frames (four slices per frame, the launch the bench's three_scope workload makes at 4K), seven frames (252
+    workgroups: the last block of the pairing is a partial one), a batch with a padded pitch and a ragged last strip, and
+    more frames than one launch takes."""
+    to_dev, to_host = _torch_dev()
+
+    def dev(*a, **k):
+        pc.check_three_scopes_dev(hip_ctx, oracle, to_dev, to_host, *a, **k)
+
+    dev(3840, 2160, [1, 2, 3, 4, 5, 1, 3, 2, 5, 4, 1, 2], reps=1)
+    dev(320, 180, [(i % 5) + 1 for i in range(64)], reps=2)
+    dev(1280, 720, [1, 2, 3, 4, 5, 1, 2], 0x05, 0x04, reps=1)
+    dev(1000, 300, [5, 1, 2, 3], 0x07, 0x07, 1000 * 4 + 48, colorspace=1, reps=1)
+    dev(256, 144, [(i % 5) + 1 for i in range(70)], reps=1)
 
 
 @pytest.mark.parametrize("strip", [16, 64])
@@ -235,6 +256,7 @@ def test_waveform_strip_widths(hip_ctx, oracle, strip):
             for rep in range(2):
                 wvs.fill_(0xEE)
                 cnt.fill_(-1)
+                torch.cuda.synchronize()  # torch fills on ITS stream; the context launches on its own (non-blocking) one
                 hip_ctx.waveform_histogram_batch_dev(br, 0x07, 0x07, wvs, cnt)
                 for f in range(n):
                     pc.assert_same(wvs[f].cpu().numpy().reshape(256, w, 4), oracle.waveform(rgbs[f], None, w, 0x07), f"wvs strip{strip} n{n} f{f}")
@@ -264,6 +286,7 @@ def test_waveform_histogram_batch_device(hip_ctx, oracle):
     for wc, hc in ((0x07, 0x07), (0x70, 0x20), (0x07, 0x70)):
         for rep in range(3):
             cnt.fill_(-1)
+            torch.cuda.synchronize()  # torch fills on ITS stream; the context launches on its own (non-blocking) one
             hip_ctx.waveform_histogram_batch_dev(b, wc, hc, wv, cnt)
             for f in range(n):
                 yuv = oracle.rgb_to_yuv(rgbs[f], w, 1)
@@ -856,3 +879,39 @@ def test_bench_one_gpu_line_has_config4_and_rccl_rank_count(hip_ctx):
     assert "error" not in c4, c4
     assert c4["parity"] is True and c4["rccl_ranks_in_communicator"] == 1 and c4["rows_of_this_rank"] == [0, 4320]
     assert d["scaling"] == "strong" and d["value"] == c4["value"]
+
+
+def test_frame_pool_alloc_places_a_pool(hip_ctx, oracle):
+    """scope_frame_pool_alloc on the GPU: four candidates of 256 MB each are read and timed, the fastest is kept (its rate
+    comes first and is the maximum), the pool is ordinary device memory that torch can view and a scope can read, and
+    freeing it gives the memory back."""
+    import torch
+
+    n_bytes = 256 << 20
+    free0 = torch.cuda.mem_get_info()[0]
+    pool, rates = hip_ctx.frame_pool_alloc(n_bytes, candidates=4)
+    assert len(rates) == 4 and rates[0] == max(rates) and min(rates) > 500.0, rates  # GB/s of a plain streaming read
+    assert torch.cuda.mem_get_info()[0] <= free0 - n_bytes + (64 << 20)  # one allocation is held, three went back
+    w, h = 1920, 1080
+    t = pool.tensor(torch, (4, h, 4 * w))
+    frames_ = [pc.frames(oracle, w, h, d, seed=40 + d) for d in (1, 2, 5, 3)]
+    for i, (rgb, yuv) in enumerate(frames_):
+        t[i].copy_(torch.from_numpy(yuv))
+    assert int(t.data_ptr()) == pool.ptr
+    b = hip_ctx.make_device_batch(t, 4 * w, w, h, planes_are_rgb=False)
+    out = torch.empty((4, 65536), dtype=torch.uint8, device="cuda")
+    hip_ctx.vectorscope_batch_dev(b, out)
+    for i, (rgb, yuv) in enumerate(frames_):
+        pc.assert_same(out[i].cpu().numpy().reshape(256, 256), oracle.vectorscope(yuv, w), f"vectorscope of pool frame {i}")
+    del t
+    pool.free()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+
+
+def test_vectorscope_side_reduce(hip_ctx, oracle):
+    """SCOPE_SIDE_REDUCE on the GPU: trains of one-frame 4K calls (160 slices each) and of 1080p calls with the fused K0,
+    the reductions on the second stream under the next call's accumulation; 300 calls back to back with no host
+    synchronisation in between."""
+    to_dev, to_host = _torch_dev()
+    pc.check_vectorscope_side_reduce(hip_ctx, oracle, to_dev, to_host, 3840, 2160, [1, 5, 2, 3], calls=40)
+    pc.check_vectorscope_side_reduce(hip_ctx, oracle, to_dev, to_host, 1920, 1080, [5, 1], calls=300, fuse=True)

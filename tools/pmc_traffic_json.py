@@ -34,7 +34,7 @@ def code_only(src):
 
 def fingerprint():
     hsh = hashlib.sha256()
-    for f in ("scope_kernels.hip", "scope_kernels.h", "scope_vec.h", "scope_api.hip"):
+    for f in ("scope_kernels.hip", "scope_trio.hip", "scope_device.h", "scope_kernels.h", "scope_vec.h", "scope_api.hip"):
         with open(os.path.join(ROOT, "obs-color-monitor_amd", "csrc", f), "rb") as fh:
             hsh.update(code_only(fh.read()))
     return hsh.hexdigest()[:16]
@@ -68,8 +68,11 @@ def main():
             continue
         fetch, write = counters(fd, "FETCH_SIZE"), counters(wd, "WRITE_SIZE")
         lead = LEAD[wl]
-        if wl == "three_scope" and "scope_dock_kernel" in fetch:  # small launches: one kernel reads the planes once
-            lead = "scope_dock_kernel"
+        if wl == "three_scope":  # one kernel reads the planes once (round 3: any launch; round 2: one-frame launches)
+            for k in ("scope_trio_kernel", "scope_dock_kernel"):
+                if k in fetch:
+                    lead = k
+                    break
         if lead not in fetch or lead not in write:
             continue
         steps_f, steps_w = fetch[lead][1], write[lead][1]
