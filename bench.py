@@ -690,21 +690,27 @@ def run_rank(args):
             b = ctx.make_device_batch(t[:pn], 4 * w, w, h, planes_are_rgb=False)
             return lambda: ctx.vectorscope_batch_dev(b, ptab, sync=False)
 
-        # the headline kernel on the pool as this process first allocated it, then on the pool the library placed
-        us_first = kernel_us(ctx, probe_yuv(yuv))
+        # the headline kernel on the pool as this process first allocated it and on the pool the library placed, measured
+        # ALTERNATELY (clocks drift over a run: two figures taken a second apart are not comparable to a per cent)
         yuv_first = yuv
         yuv, rates_y = place_pool(torch, dev, ctx, yuv_first, args.placement_candidates, pools)
-        del yuv_first
+        fa, fb = probe_yuv(yuv_first), probe_yuv(yuv)
+        t_first, t_placed = [], []
+        for _ in range(3):
+            t_first.append(kernel_us(ctx, fa, warm=6, reps=16))
+            t_placed.append(kernel_us(ctx, fb, warm=6, reps=16))
+        us_first, us_placed = min(t_first), min(t_placed)
+        del yuv_first, fa
         rgb_first = rgb
         rgb, rates_r = place_pool(torch, dev, ctx, rgb_first, args.placement_candidates, pools)
         del rgb_first
         dev.empty_cache()
-        us_placed = kernel_us(ctx, probe_yuv(yuv))
         probe_bytes = pn * (4 * w * h + 65536)
         placement = {"candidates": args.placement_candidates, "by": "scope_frame_pool_alloc (C-ABI): candidates held at once, each read "
                      "by the vectorscope accumulation kernel timed with its own begin/end stamps, the fastest kept, the rest freed; untimed set-up",
                      "yuv_pool_read_gbps": rates_y, "rgb_pool_read_gbps": rates_r,
                      "vectorscope_kernel_us_first_allocation": us_first, "vectorscope_kernel_us_placed_pool": us_placed,
+                     "how_compared": "three alternating rounds of 16 launches on each pool, the fastest round of each",
                      "first_allocation_frac": round(probe_bytes / (us_first * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                      "placed_frac": round(probe_bytes / (us_placed * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
         del ptab

@@ -35,6 +35,10 @@
  * A strip's row segment is 64 bytes, half a cache line.  Slices come in pairs that split a range of strips even / odd, and
  * the two workgroups of a pair are b and b + 8 (same XCD, same L2, same moment): the other half of every line is wanted by
  * the partner while it is still in the L2.
+ * Tried and dropped: skipping the K0 / vote work of slots that are empty for a whole wave (one of 18 per strip at 4K; the
+ * uniform branch around a slot's work cost hipcc's schedule of the round 8 %: 632 -> 685 us for 64 x 4K), deeper or
+ * shallower load queues (4 / 8 / 12 per lane: 674 / 739 / 738 us against 641 at 6 -- a strip's 17 slots are rounded up to
+ * whole rounds of D, and empty slots still run K0); profiles/round3/trio_variants.txt.
  * Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables), H <= 4080 (a strip's texels fit the
  * vectorscope's 16-bit counters between two clamp passes).
  * ---------------------------------------------------------------------------------------- */
@@ -42,12 +46,11 @@
 #define TRIO_D 6 /* 8-byte loads in flight per lane; a strip's loads per lane are rounded up to a multiple of it */
 #endif
 #ifndef TRIO_NT
-#define TRIO_NT 1
+#define TRIO_NT 0 /* plain loads: the other half of every cache line is wanted by the partner workgroup, so lines should stay in
+		   * the L2 with normal priority (64 x 4K: 637 us against 642 with streaming loads; three frames 45.9 / 46.4) */
 #endif
-#ifndef TRIO_SKIP
-#define TRIO_SKIP 0 /* 1: skip the K0 / vote work of slots that are empty for the whole wave (one of 18 at 4K).  Measured: 8 % SLOWER
-		     * (64 x 4K: 632 -> 685 us) -- the uniform branch around the slot's work costs hipcc's schedule of the whole
-		     * round more than the empty slot's instructions; profiles/round3/trio_variants.txt */
+#ifndef TRIO_BUF
+#define TRIO_BUF 1 /* buffer addressing for the pixel loads (see the issue side of the kernel); 0: global loads + offset select */
 #endif
 #ifndef TRIO_EXP
 #define TRIO_EXP 0 /* measurement only (wrong tables): bit 0 no waveform adds, 1 no vectorscope adds, 2 no K0, 3 no clamp pass */
@@ -123,23 +126,49 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	const u32 dstep = nwaves * fs.linesize;
 	const u32 lane_base = TRIO_WVS_BASE + (pair << 2);
 
-	/* ---- issue side ------------------------------------------------------------------------------------------------ */
+	/* ---- issue side ------------------------------------------------------------------------------------------------
+	 * TRIO_BUF (default): buffer addressing -- the plane is a buffer resource of H * linesize bytes in SGPRs, a lane holds ONE
+	 * 32-bit byte offset that advances by nwaves rows per slot, and a load past the plane's end returns zeros by the
+	 * hardware's range check: issuing a slot is the load and one add.  Which slots of a lane are real is decided where they
+	 * are binned: slot g < nv (a per-lane constant: the lane's rows form a prefix of its slots) and the strip's column
+	 * exists.  TRIO_BUF 0: global loads with a validity test and an offset select per slot (A/B). */
 	u32 px[D][2];
+#if !TRIO_BUF
 	bool ok[D];
-	bool wok[D]; /* wave-uniform: does this slot hold rows for anybody in the wave?  (the rounding of G up to whole rounds, and
-		      * the last waves' last rows, leave slots that are empty for the whole wave: their K0 and votes are skipped) */
+#endif
 	u32 s_i = 0, g_i = 0, off_i = 0;
 	bool live_i = false;
+	const u32 lim = row0 < H ? min(rps, H - row0) : 0u; /* rows of this lane's range that exist */
+	const u32 nv = lim > wave ? (lim - wave + nwaves - 1u) / nwaves : 0u;
+	const scope_buf buf = scope_buf_make(plane, H * fs.linesize);
+	(void)buf;
+	(void)nv;
+	(void)live_i;
 	auto strip_start = [&](u32 s) {
 		const u32 x0 = (first + s * stride) * 16u + 2u * pair;
 		live_i = s < nst && x0 < W; /* W % 4 == 0: both texels of the pair or none */
 		off_i = (row0 + wave) * fs.linesize + x0 * 4u;
+		if (TRIO_BUF && s >= nst)
+			off_i = H * fs.linesize; /* past the last strip: every load out of range */
 	};
 	strip_start(0);
+#if TRIO_BUF
+#define TRIO_ISSUE(d)                                                                                                  \
+	do {                                                                                                           \
+		const scope_u2 t_ = scope_buf_load2<TRIO_NT != 0>(buf, off_i);                                         \
+		px[d][0] = t_.x;                                                                                       \
+		px[d][1] = t_.y;                                                                                       \
+		off_i += dstep;                                                                                        \
+		if (++g_i == Gp) {                                                                                     \
+			g_i = 0;                                                                                       \
+			strip_start(++s_i);                                                                            \
+		}                                                                                                      \
+	} while (0)
+#define TRIO_OK(d, g) (live_b && (g) < nv)
+#else
 #define TRIO_ISSUE(d)                                                                                                  \
 	do {                                                                                                           \
 		const u32 i_ = wave + g_i * nwaves;                                                                    \
-		wok[d] = s_i < nst && i_ < rps;                                                                        \
 		ok[d] = live_i && i_ < rps && row0 + i_ < H;                                                           \
 		scope_u2 t_;                                                                                           \
 		if (TRIO_NT)                                                                                           \
@@ -154,6 +183,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 			strip_start(++s_i);                                                                            \
 		}                                                                                                      \
 	} while (0)
+#define TRIO_OK(d, g) (ok[d])
+#endif
 #pragma unroll
 	for (int d = 0; d < D; d++)
 		TRIO_ISSUE(d);
@@ -174,30 +205,30 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	const u32 value = threadIdx.x >> 2, g4 = threadIdx.x & 3u;
 
 	for (u32 s_b = 0; s_b < nst; s_b++) {
+		const bool live_b = (first + s_b * stride) * 16u + 2u * pair < W; /* this lane's column pair exists in the strip */
+		(void)live_b;
 		for (u32 g_b = 0; g_b < Gp; g_b += (u32)D) {
 #pragma unroll
 			for (int d = 0; d < D; d++) {
-				const bool w = TRIO_SKIP ? wok[d] : true, v = ok[d]; /* w: wave-uniform */
+				const bool v = TRIO_OK(d, g_b + (u32)d);
 				const u32 p0 = px[d][0], p1 = px[d][1];
 				u32 key[2] = {p0, p1};
-				if (w) {
-					if (v && !(TRIO_EXP & 1)) {
-						if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
-							trio_count<CH>(tab, p0, lane_base, 1u);
-						if ((p1 >> 24) != 0)
-							trio_count<CH>(tab, p1, lane_base, 65536u);
-					}
-					if (TRIO_EXP & 4) {
-						key[0] = vss_bin(p0);
-						key[1] = vss_bin(p1);
-					} else {
-						scope_k0_cell<2, true>(key, k0, true, false); /* wave votes inside: every lane goes through, valid or not */
-					}
-					if (((g_b + (u32)d) & 3u) == 0) /* content is coherent: the verdict holds for four loads */
-						absorb = __popcll(__ballot(!v || key[0] == key[1])) >= 48;
+				if (v && !(TRIO_EXP & 1)) {
+					if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
+						trio_count<CH>(tab, p0, lane_base, 1u);
+					if ((p1 >> 24) != 0)
+						trio_count<CH>(tab, p1, lane_base, 65536u);
 				}
+				if (TRIO_EXP & 4) {
+					key[0] = vss_bin(p0);
+					key[1] = vss_bin(p1);
+				} else {
+					scope_k0_cell<2, true>(key, k0, true, false); /* wave votes inside: every lane goes through, valid or not */
+				}
+				if (((g_b + (u32)d) & 3u) == 0) /* content is coherent: the verdict holds for four loads */
+					absorb = __popcll(__ballot(!v || key[0] == key[1])) >= 48;
 				TRIO_ISSUE(d); /* ONE issue point per slot, whatever the slot held: the load queue has the same shape on every path */
-				if (!(w && v) || (TRIO_EXP & 2))
+				if (!v || (TRIO_EXP & 2))
 					continue;
 				if (absorb) {
 					bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
@@ -260,6 +291,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		__syncthreads();
 	}
 #undef TRIO_ISSUE
+#undef TRIO_OK
 
 	/* ---- the slice's vectorscope table: final (one slice per frame) or a sparse partial, as scope_vss_kernel ---------- */
 	{

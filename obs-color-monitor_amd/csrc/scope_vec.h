@@ -76,6 +76,34 @@ __device__ __forceinline__ scope_u2 scope_load_row2(const unsigned char *row, un
 	return *(const __attribute__((address_space(1))) scope_u2 *)(base + lane_off);
 }
 
+/* Buffer addressing: a 128-bit resource descriptor in SGPRs (base, size) and ONE 32-bit byte offset per lane -- no
+ * 64-bit address arithmetic at all, and the hardware's own range check: a load whose offset lies at or beyond `bytes`
+ * returns zeros instead of faulting, so lanes past the end of a plane need no offset select (only their results are
+ * ignored).  gfx9-family descriptor: dword 3 = 0x00020000 (raw buffer, 32-bit data format); stride 0.
+ * scope_buf_load2: 8 bytes (two texels) at base + off; NT = streaming. */
+typedef int scope_i4 __attribute__((ext_vector_type(4)));
+typedef int scope_i2 __attribute__((ext_vector_type(2)));
+typedef scope_i4 scope_buf;
+__device__ scope_i2 scope_llvm_raw_buffer_load_v2i32(scope_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
+__device__ __forceinline__ scope_buf scope_buf_make(const unsigned char *base, unsigned bytes)
+{
+	const unsigned long long a = (unsigned long long)base;
+	scope_i4 r;
+	r.x = (int)__builtin_amdgcn_readfirstlane((unsigned)a);
+	r.y = (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu);
+	r.z = (int)__builtin_amdgcn_readfirstlane(bytes);
+	r.w = 0x00020000;
+	return r;
+}
+template <bool NT> __device__ __forceinline__ scope_u2 scope_buf_load2(scope_buf buf, unsigned off)
+{
+	const scope_i2 t = scope_llvm_raw_buffer_load_v2i32(buf, (int)off, 0, NT ? 2 : 0); /* aux bit 1 = nt */
+	scope_u2 r;
+	r.x = (unsigned)t.x;
+	r.y = (unsigned)t.y;
+	return r;
+}
+
 /* v_perm_b32: byte i of the result is byte sel[i] of the 8 bytes {hi (4..7), lo (0..3)}; 0x0c gives 0x00, 0x0d gives 0xff. */
 __device__ __forceinline__ unsigned scope_perm(unsigned hi, unsigned lo, unsigned sel)
 {

@@ -51,6 +51,22 @@ static inline scope_u2 scope_load_row2(const unsigned char *row, unsigned lane_o
 	return scope_load_row2_nt(row, lane_off);
 }
 
+struct scope_buf {
+	const unsigned char *base;
+	unsigned bytes;
+};
+static inline scope_buf scope_buf_make(const unsigned char *base, unsigned bytes)
+{
+	return scope_buf{base, bytes};
+}
+template <bool NT> static inline scope_u2 scope_buf_load2(scope_buf buf, unsigned off)
+{
+	if ((unsigned long long)off + 8 > buf.bytes) /* the hardware's range check: zeros */
+		return scope_u2{0, 0};
+	const unsigned *p = (const unsigned *)(buf.base + off);
+	return scope_u2{p[0], p[1]};
+}
+
 static inline unsigned scope_perm(unsigned hi, unsigned lo, unsigned sel)
 {
 	const unsigned long long src = ((unsigned long long)hi << 32) | lo;
