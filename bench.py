@@ -1044,11 +1044,15 @@ class Legs:
         torch = self.torch
         out = {}
 
-        def both(rgb, yuv):
+        def both(rgb, yuv, trio=True):
             a = self.variant("vectorscope", rgb, yuv, 0x07, steps=10, seconds=0.5)
             b = self.variant("vectorscope_rgb", rgb, yuv, 0x07, steps=10, seconds=0.5)
-            return {"vectorscope": {"frac": a["roofline"]["frac"], "frac_whole_step": a["roofline"]["frac_whole_step"], "gpix_per_s": a["value"], "parity": a["parity"]},
-                    "vectorscope_rgb": {"frac": b["roofline"]["frac"], "frac_whole_step": b["roofline"]["frac_whole_step"], "gpix_per_s": b["value"], "parity": b["parity"]}}
+            res = {"vectorscope": {"frac": a["roofline"]["frac"], "frac_whole_step": a["roofline"]["frac_whole_step"], "gpix_per_s": a["value"], "parity": a["parity"]},
+                   "vectorscope_rgb": {"frac": b["roofline"]["frac"], "frac_whole_step": b["roofline"]["frac_whole_step"], "gpix_per_s": b["value"], "parity": b["parity"]}}
+            if trio:  # the one-read three-scope kernel is LDS / VALU bound: same-address LDS atomics make it content dependent
+                c = self.variant("three_scope", rgb, yuv, 0x07, steps=6, seconds=0.4)
+                res["three_scope"] = {"gpix_per_s": c["value"], "frac_whole_step": c["roofline"]["frac_whole_step"], "parity": c["parity"]}
+            return res
 
         for kind in ("natural", "concentrated", "flat", "screen", "ramp"):
             rgb, yuv = make_frames(torch, self.ctx, self.n, self.w, self.h, kind, 0xD157 + len(out), device=self.dev.device)

@@ -142,7 +142,7 @@ hipError_t scope_launch_dock(const ScopeFrameSet &fs, uint32_t chmask, int color
  * one-replica waveform table of a 16-column strip are resident in LDS, a workgroup streams the strips of one slice of one
  * frame.  slices = scope_trio_slices(fs, num_cu) workgroups per frame; slices == 1: vss_dst = the final uint8[n][65536]
  * tables, vss_mask unused; else vss_dst / vss_mask = sparse partials as scope_launch_vss writes them with 1024 mask bytes
- * per slice, for scope_launch_sat_reduce_sparse.  Where scope_trio_fits says so (vector shape, height <= 4080). */
+ * per slice, for scope_launch_sat_reduce_sparse.  Where scope_trio_fits says so (vector shape, height <= 65535). */
 bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const ScopeTuning &tn);
 uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu);
 hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int colorspace, uint8_t *wvs_dst,

@@ -21,8 +21,8 @@
  * other kernel here: every texel is loaded once, counted in the waveform table (alpha test, src/waveform.c:247-248), sent
  * through the fixed-point K0 and counted in the vectorscope table, with TRIO_D loads per lane in flight and no register-held
  * strip.  Per strip: barrier, the waveform's 256 x 16 output texels leave (the thread that reads a counter zeroes it, the
- * histogram's totals accumulate in three registers per thread over all strips of the slice), the vectorscope's clamp
- * pass when the next strip could overflow 16 bits, barrier; the loads of the next strip are in flight across it.  Per
+ * histogram's totals accumulate in three registers per thread over all strips of the slice), barrier; the loads of the next
+ * strip are in flight across it.  The vectorscope's clamp pass runs before the round of loads that could overflow 16 bits.  Per
  * slice: ONE vectorscope partial (sparse, as scope_vss_kernel writes them; the final table when the frame has one slice)
  * and <= 768 device atomics for the histogram.  64 frames: 4 slices of 60 strips per frame; three frames: 80 slices of
  * three strips; one frame: 240 slices of one -- the dock kernel's shape.
@@ -39,8 +39,8 @@
  * uniform branch around a slot's work cost hipcc's schedule of the round 8 %: 632 -> 685 us for 64 x 4K), deeper or
  * shallower load queues (4 / 8 / 12 per lane: 674 / 739 / 738 us against 641 at 6 -- a strip's 17 slots are rounded up to
  * whole rounds of D, and empty slots still run K0); profiles/round3/trio_variants.txt.
- * Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables), H <= 4080 (a strip's texels fit the
- * vectorscope's 16-bit counters between two clamp passes).
+ * Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables), H <= 65535 (a column's rows fit the waveform's
+ * 16-bit counters).
  * ---------------------------------------------------------------------------------------- */
 #ifndef TRIO_D
 #define TRIO_D 6 /* 8-byte loads in flight per lane; a strip's loads per lane are rounded up to a multiple of it */
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	VssLane st = {0xffffffffu, 0};
 	bool absorb = false; /* wave-uniform */
 	u32 since = 0;       /* texels the vectorscope table may have taken since its last clamp pass (uniform) */
-	const u32 strip_px = 16u * H;
+	const u32 round_px = (u32)D * blockDim.x * 2u; /* texels a round of D slots can add (upper bound: every lane valid) */
 	u32 hs[3] = {0, 0, 0}; /* HIS: this thread's (value, column group) totals over the slice's strips */
 	const u32 value = threadIdx.x >> 2, g4 = threadIdx.x & 3u;
 
@@ -208,6 +208,18 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		const bool live_b = (first + s_b * stride) * 16u + 2u * pair < W; /* this lane's column pair exists in the strip */
 		(void)live_b;
 		for (u32 g_b = 0; g_b < Gp; g_b += (u32)D) {
+			/* the vectorscope's 16-bit counters: a clamp pass (every counter min(c, 255): exact, the reference saturates
+			 * at 255) before the round that could carry one past 65535 -- at round granularity, not per strip: a 4K strip is
+			 * 34 560 texels, two strips would overflow, but five rounds of 12 288 fit, so 60 strips need 36 passes and
+			 * not 59 (a pass reads the whole 128 KiB table: 5 % of the kernel when taken once per strip) */
+			if (since + round_px > VSS_EPOCH_PIXELS && !(TRIO_EXP & 8)) { /* uniform across the workgroup */
+				vss_flush_lane<0>(tab, st); /* pending texels belong to the epoch that ends here */
+				__syncthreads();
+				vss_clamp_pass(tab);
+				__syncthreads();
+				since = 0;
+			}
+			since += round_px;
 #pragma unroll
 			for (int d = 0; d < D; d++) {
 				const bool v = TRIO_OK(d, g_b + (u32)d);
@@ -251,11 +263,9 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 				}
 			}
 		}
-		since += strip_px;
 		const bool last_strip = s_b + 1u == nst;
-		const bool clamp = !last_strip && since + strip_px > VSS_EPOCH_PIXELS;
-		if (last_strip || clamp)
-			vss_flush_lane<0>(tab, st); /* pending texels belong to the epoch that ends here */
+		if (last_strip)
+			vss_flush_lane<0>(tab, st); /* the lanes' pending texels, before the table is read out */
 		__syncthreads();
 		{
 			/* the strip's 256 x 16 waveform texels: thread -> (value, group of four columns); the reader of a counter zeroes it */
@@ -284,10 +294,6 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		}
 		if (last_strip)
 			break;
-		if (clamp && !(TRIO_EXP & 8)) {
-			vss_clamp_pass(tab);
-			since = 0;
-		}
 		__syncthreads();
 	}
 #undef TRIO_ISSUE
@@ -406,8 +412,8 @@ hipError_t scope_trio_init(void)
 
 bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const ScopeTuning &tn)
 {
-	/* the vector shape, a strip (16 x H texels) within the 16-bit counters' budget between two clamp passes, 32-bit offsets */
-	return scope_wvs_vector_shape(fs, wvs_dst, tn) && fs.height >= 1 && 16u * fs.height <= VSS_EPOCH_PIXELS &&
+	/* the vector shape, a column's rows within the waveform's 16-bit counters, 32-bit offsets */
+	return scope_wvs_vector_shape(fs, wvs_dst, tn) && fs.height >= 1 && fs.height <= 65535u &&
 	       (u64)fs.height * fs.linesize < (1ull << 31);
 }
 

@@ -157,7 +157,7 @@ def test_three_scopes_one_read(emul_ctx, oracle, dock):
             dev(32, 2100, [3, 1, 2, 5, 1, 3], reps=1)     # six frames on six CUs: one slice of TWO strips per frame, final tables
                                                           # straight from the kernel, a clamp pass between the strips (flat: saturates)
             dev(200, 40, [1, 5], 0x06, 0x02, reps=2)      # 13 strips (the last 8 columns wide) in 4 paired slices per frame
-            dev(16, 4090, [1], reps=1)                    # a strip beyond the 16-bit budget: two passes
+            dev(16, 4090, [3], reps=1)                    # a tall flat strip: clamp passes inside the strip
 
 
 def test_three_scopes_host_planes(emul_ctx, oracle):

@@ -226,6 +226,7 @@ def test_three_scopes_batches_one_read(hip_ctx, oracle):
     dev(1280, 720, [1, 2, 3, 4, 5, 1, 2], 0x05, 0x04, reps=1)
     dev(1000, 300, [5, 1, 2, 3], 0x07, 0x07, 1000 * 4 + 48, colorspace=1, reps=1)
     dev(256, 144, [(i % 5) + 1 for i in range(70)], reps=1)
+    dev(7680, 4320, [1], reps=1)  # BASELINE config 4's frame: 480 strips, 240 slices of two, clamp passes inside a strip
 
 
 @pytest.mark.parametrize("strip", [16, 64])
