@@ -163,15 +163,97 @@ def launch_once(argv, n, timeout_s):
     return line, outcome
 
 
-def launcher(args, argv):
-    """Attempts in order: what was asked for; the torch.distributed table sum; replicas with no table sum at all.  The
-    first attempt whose ranks all exit 0 and whose rank 0 printed a line wins; its line goes out with `launcher` added.
-    If nothing works a line still goes out (value 0, the attempts' failures inside) and the exit code is 5."""
+def reduce_ladder(args):
+    """Rungs of extra arguments: what was asked for; the torch.distributed table sum; replicas with no table sum at all."""
     ladder = [[]]
     if not args.torch_reduce and not args.no_collective:
         ladder.append(["--torch-reduce"])
     if not args.no_collective:
         ladder.append(["--no-collective"])
+    return ladder
+
+
+def failure_line(args, attempts, mode):
+    return json.dumps({
+        "metric": METRIC, "value": 0.0, "unit": "Gpix/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "error": "no attempt of the N-rank run completed; see launcher.attempts (rank logs are on stderr)",
+        "config": {"workload": "none completed"},
+        "launcher": {"mode": mode, "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout},
+    })
+
+
+def supervisor(args, argv):
+    """Under `python -m torch.distributed.run ... bench.py --gpus N` every process torchrun starts is a SUPERVISOR: it runs
+    the rank's work in a child process (same RANK / LOCAL_RANK / WORLD_SIZE, a rendezvous port of the attempt's own) against
+    a deadline, and the supervisors -- a gloo group of their own on the rendezvous torchrun gave them, CPU only -- agree
+    after every attempt whether it worked on ALL ranks.  So the fallback ladder of the self-launched form (C-ABI RCCL ->
+    torch.distributed -> replicas) exists here too, and a hung collective still ends in rank 0's one JSON line."""
+    import datetime
+    import tempfile
+
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.launch_timeout * 3 + 600))
+    attempts, deadline = [], args.launch_timeout
+    mode = "torch.distributed.run started supervisors; each runs its rank in a child process per attempt"
+    for extra in reduce_ladder(args):
+        port = [free_port() if rank == 0 else None]
+        dist.broadcast_object_list(port, src=0)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), BENCH_SELF_LAUNCHED="1", BENCH_WORKER="1")
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            env.pop(k)  # the children rendezvous among themselves on the attempt's port: rank 0's child hosts the store, not the agent
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out_file = tempfile.TemporaryFile()
+        t0 = time.time()
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv, *extra, "--launch-timeout", str(deadline)], env=env,
+                                 start_new_session=True, stdout=out_file if rank == 0 else subprocess.DEVNULL)
+        why = None
+        while child.poll() is None:
+            if time.time() - t0 > deadline:
+                why = f"deadline of {deadline:.0f} s passed"
+                kill_ranks([child])
+                break
+            time.sleep(0.05)
+        rc = child.returncode
+        out_file.seek(0)
+        line = None
+        for ln in out_file.read().decode(errors="replace").splitlines():
+            if ln.startswith("{"):
+                line = ln
+        out_file.close()
+        ok_here = why is None and rc in (0, 3) and (rank != 0 or line is not None)
+        flags = torch.tensor([1 if ok_here else 0, 1 if rc == 3 else 0], dtype=torch.int32)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)  # [every rank fine, every rank reports a parity mismatch]
+        codes = [None] * world
+        dist.all_gather_object(codes, rc)
+        attempts.append({"extra_args": extra, "exit_codes": codes, "seconds": round(time.time() - t0, 1),
+                         "failure": None if int(flags[0]) else (why or f"exit codes {codes}"), "rendezvous": f"127.0.0.1:{port[0]}"})
+        if int(flags[0]):
+            if rank == 0:
+                res = json.loads(line)
+                res["launcher"] = {"mode": mode, "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout}
+                print(json.dumps(res), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            return 3 if 3 in codes else 0
+        log(f"bench.py supervisor (rank {rank}): attempt {extra or ['as asked']} failed ({attempts[-1]['failure']}); next rung")
+        deadline = max(120.0, args.launch_timeout / 2)
+    if rank == 0:
+        print(failure_line(args, attempts, mode), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 5
+
+
+def launcher(args, argv):
+    """Attempts in order: what was asked for; the torch.distributed table sum; replicas with no table sum at all.  The
+    first attempt whose ranks all exit 0 and whose rank 0 printed a line wins; its line goes out with `launcher` added.
+    If nothing works a line still goes out (value 0, the attempts' failures inside) and the exit code is 5."""
+    ladder = reduce_ladder(args)
     attempts, deadline = [], args.launch_timeout
     for extra in ladder:
         line, outcome = launch_once(argv + extra, args.gpus, deadline)
@@ -190,13 +272,7 @@ def launcher(args, argv):
             print(json.dumps(res), flush=True)
             return 3 if parity_exit else 0
         deadline = max(120.0, args.launch_timeout / 2)  # the later rungs get less: the whole ladder stays bounded
-    print(json.dumps({
-        "metric": METRIC, "value": 0.0, "unit": "Gpix/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "error": "no attempt of the N-rank run completed; see launcher.attempts (rank logs are on stderr)",
-        "config": {"workload": "none completed"},
-        "launcher": {"mode": "bench.py started its own ranks", "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout},
-    }), flush=True)
+    print(failure_line(args, attempts, "bench.py started its own ranks"), flush=True)
     return 5
 
 
@@ -592,6 +668,8 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launcher(args, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("BENCH_WORKER") and not os.environ.get("BENCH_SELF_LAUNCHED"):
+        sys.exit(supervisor(args, sys.argv[1:]))  # a rank torch.distributed.run (or anybody else) started
     run_rank(args)
 
 
@@ -861,7 +939,8 @@ def run_rank(args):
                 "ranks_in_communicator": rccl_info["ranks"], "rank": rccl_info["rank"], "version": rccl_info["version"],
                 "library": os.environ.get("SCOPE_RCCL_LIBRARY") or "librccl (dlopen by libscope_hip.so)",
                 "what": "ncclCommCount / ncclCommUserRank / ncclGetVersion of the data path's communicator (scope_rccl_comm_info)"},
-            "launch": "self-launched rank" if os.environ.get("BENCH_SELF_LAUNCHED") else ("torch.distributed.run rank" if multi else "single process"),
+            "launch": ("supervised rank under torch.distributed.run" if os.environ.get("BENCH_WORKER") else
+                       "self-launched rank" if os.environ.get("BENCH_SELF_LAUNCHED") else ("rank of a foreign launcher" if multi else "single process")),
             "backend": "libscope_hip.so on " + info["name"] if not dev.emul else "EMULATION (tests/emul, CPU): numbers are meaningless",
             "gpu_shared_by_ranks": bool(dev.shared),
             "device": info["name"],

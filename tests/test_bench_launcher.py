@@ -71,8 +71,21 @@ def test_under_torch_distributed_run(shm_rccl):
     prefix = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29519"]
     rc, d, err = run_bench(["--gpus", "2", *SMALL, "--no-extras"], env, prefix=prefix)
     assert rc == 0, err[-3000:]
-    assert d["n_gpus"] == 2 and "launcher" not in d and d["config"]["launch"] == "torch.distributed.run rank"
+    assert d["n_gpus"] == 2 and d["config"]["launch"] == "supervised rank under torch.distributed.run"
+    assert len(d["launcher"]["attempts"]) == 1 and d["launcher"]["attempts"][0]["exit_codes"] == [0, 0]
     assert d["config"]["rccl"]["ranks_in_communicator"] == 2 and d["parity"].startswith("bit-exact")
+
+
+def test_hung_collective_under_torch_distributed_run(shm_rccl):
+    # the driver's N > 1 command line: the processes torchrun starts supervise their ranks, agree that the first attempt
+    # failed (rank 1 never entered its collective) and run the next rung together
+    env = clean_env(MASTER_ADDR="127.0.0.1", SHM_RCCL_HANG_RANK="1", SHM_RCCL_TIMEOUT_S="1000")
+    prefix = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29521"]
+    rc, d, err = run_bench(["--gpus", "2", *SMALL, "--no-extras", "--launch-timeout", "20"], env, prefix=prefix)
+    assert rc == 0, err[-3000:]
+    attempts = d["launcher"]["attempts"]
+    assert len(attempts) == 2 and attempts[0]["failure"] and attempts[1]["failure"] is None and attempts[1]["extra_args"] == ["--torch-reduce"]
+    assert d["config"]["reduce"].startswith("torch.distributed") and d["parity"].startswith("bit-exact")
 
 
 def test_hung_collective_still_prints_a_line(shm_rccl):
