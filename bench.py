@@ -192,6 +192,12 @@ def supervisor(args, argv):
     import datetime
     import tempfile
 
+    # ONE JSON line on stdout: gloo announces its connections through C stdio on file descriptor 1, so that descriptor points
+    # at stderr while this process lives and the line goes to the saved, real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -236,14 +242,14 @@ def supervisor(args, argv):
             if rank == 0:
                 res = json.loads(line)
                 res["launcher"] = {"mode": mode, "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout}
-                print(json.dumps(res), flush=True)
+                os.write(real_stdout, (json.dumps(res) + "\n").encode())
             dist.barrier()
             dist.destroy_process_group()
             return 3 if 3 in codes else 0
         log(f"bench.py supervisor (rank {rank}): attempt {extra or ['as asked']} failed ({attempts[-1]['failure']}); next rung")
         deadline = max(120.0, args.launch_timeout / 2)
     if rank == 0:
-        print(failure_line(args, attempts, mode), flush=True)
+        os.write(real_stdout, (failure_line(args, attempts, mode) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
     return 5

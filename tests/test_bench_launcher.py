@@ -35,8 +35,9 @@ def clean_env(**extra):
 def run_bench(args, env, prefix=(), timeout=600):
     out = subprocess.run([sys.executable, *prefix, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True,
                          timeout=timeout, cwd=ROOT)
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, f"exactly one JSON line expected, rc={out.returncode}\n{out.stdout[-2000:]}\n{out.stderr[-4000:]}"
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), \
+        f"exactly one line on stdout, the JSON line, expected; rc={out.returncode}\n{out.stdout[-2000:]}\n{out.stderr[-4000:]}"
     return out.returncode, json.loads(lines[0]), out.stderr
 
 
