@@ -52,6 +52,13 @@
 #ifndef TRIO_BUF
 #define TRIO_BUF 1 /* buffer addressing for the pixel loads (see the issue side of the kernel); 0: global loads + offset select */
 #endif
+#ifndef TRIO_WABSORB
+#define TRIO_WABSORB 0 /* 1: the waveform's counters in absorb mode where a whole wave sits on flat content (see the kernel).
+			* Measured, 64 x 4K (profiles/round3/trio_variants.txt, visits f3): a flat frame 628 -> 890 Gpix/s, but
+			* its mere presence costs the kernel 3.5 % on noise and natural content (850 -> 817, 836 -> 808) and 5 % on
+			* screen content (721 -> 685; with the vectorscope's looser vote 9 %): entirely flat frames are not worth
+			* that, so it is compiled out */
+#endif
 #ifndef TRIO_EXP
 #define TRIO_EXP 0 /* measurement only (wrong tables): bit 0 no waveform adds, 1 no vectorscope adds, 2 no K0, 3 no clamp pass */
 #endif
@@ -198,7 +205,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	__syncthreads();
 
 	VssLane st = {0xffffffffu, 0};
-	bool absorb = false; /* wave-uniform */
+	bool absorb = false, wflat = false; /* wave-uniform */
+	u32 wp0 = 0, wp1 = 0, wn = 0; /* the waveform's pending texel pair and how often it came (absorb mode) */
 	u32 since = 0;       /* texels the vectorscope table may have taken since its last clamp pass (uniform) */
 	const u32 round_px = (u32)D * blockDim.x * 2u; /* texels a round of D slots can add (upper bound: every lane valid) */
 	u32 hs[3] = {0, 0, 0}; /* HIS: this thread's (value, column group) totals over the slice's strips */
@@ -226,10 +234,34 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 				const u32 p0 = px[d][0], p1 = px[d][1];
 				u32 key[2] = {p0, p1};
 				if (v && !(TRIO_EXP & 1)) {
-					if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
-						trio_count<CH>(tab, p0, lane_base, 1u);
-					if ((p1 >> 24) != 0)
-						trio_count<CH>(tab, p1, lane_base, 65536u);
+					if (TRIO_WABSORB && wflat) {
+						/* Flat content -- EVERY lane of the wave held a horizontally equal texel pair at the last vote
+						 * (stricter than the vectorscope's three quarters: screen content with a few per cent of detail
+						 * flushed its pending pairs so often that this mode lost 9 % there): a lane's consecutive
+						 * slots then hold the same pair too, and with ONE
+						 * replica four rows of a half wave would meet on one counter at 4 clk per lane (a flat
+						 * frame ran at 628 Gpix/s, noise at 859).  The lane counts repeats of its pending pair in a
+						 * register and adds them in one go when the pair changes, at the strip's end at the latest.
+						 * Either mode is exact; `wflat` is wave-uniform. */
+						if (p0 == wp0 && p1 == wp1) {
+							wn++;
+						} else {
+							if (wn) {
+								if ((wp0 >> 24) != 0)
+									trio_count<CH>(tab, wp0, lane_base, wn);
+								if ((wp1 >> 24) != 0)
+									trio_count<CH>(tab, wp1, lane_base, wn << 16);
+							}
+							wp0 = p0;
+							wp1 = p1;
+							wn = 1;
+						}
+					} else {
+						if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
+							trio_count<CH>(tab, p0, lane_base, 1u);
+						if ((p1 >> 24) != 0)
+							trio_count<CH>(tab, p1, lane_base, 65536u);
+					}
 				}
 				if (TRIO_EXP & 4) {
 					key[0] = vss_bin(p0);
@@ -237,8 +269,11 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 				} else {
 					scope_k0_cell<2, true>(key, k0, true, false); /* wave votes inside: every lane goes through, valid or not */
 				}
-				if (((g_b + (u32)d) & 3u) == 0) /* content is coherent: the verdict holds for four loads */
-					absorb = __popcll(__ballot(!v || key[0] == key[1])) >= 48;
+				if (((g_b + (u32)d) & 3u) == 0) { /* content is coherent: the verdict holds for four loads */
+					const u32 flat_lanes = (u32)__popcll(__ballot(!v || key[0] == key[1]));
+					absorb = flat_lanes >= 48;
+					wflat = flat_lanes >= 64;
+				}
 				TRIO_ISSUE(d); /* ONE issue point per slot, whatever the slot held: the load queue has the same shape on every path */
 				if (!v || (TRIO_EXP & 2))
 					continue;
@@ -262,6 +297,13 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 					vss_add<0>(tab, key[1], 1);
 				}
 			}
+		}
+		if (TRIO_WABSORB && wn) { /* the waveform's pending pair belongs to this strip's table */
+			if ((wp0 >> 24) != 0)
+				trio_count<CH>(tab, wp0, lane_base, wn);
+			if ((wp1 >> 24) != 0)
+				trio_count<CH>(tab, wp1, lane_base, wn << 16);
+			wn = 0;
 		}
 		const bool last_strip = s_b + 1u == nst;
 		if (last_strip)
