@@ -157,10 +157,6 @@ hipError_t scope_launch_sat_reduce(const uint8_t *part, uint8_t *out, uint32_t n
 hipError_t scope_launch_sat_reduce_sparse(const uint8_t *part, const uint8_t *pmask, uint8_t *out, uint32_t n_frames,
 					  uint32_t slices, uint32_t mask_block, int packed16, hipStream_t st);
 
-/* A plain streaming read of `bytes` (a multiple of 16) at p: what scope_frame_pool_alloc times a candidate with. */
-hipError_t scope_launch_read_probe(const void *p, uint64_t bytes, uint32_t num_cu, uint32_t *sink, hipStream_t st,
-				   const ScopeTiming *tm);
-
 hipError_t scope_launch_sum_reduce(const uint32_t *part, uint32_t *out, uint32_t n_frames, uint32_t slices,
 				   uint32_t len, hipStream_t st);
 

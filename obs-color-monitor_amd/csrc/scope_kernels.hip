@@ -1325,25 +1325,6 @@ __global__ __launch_bounds__(256) void scope_sat_reduce_sparse_kernel(const uint
 	wire[1] = make_uint4(b[8] | b[9] << 16, b[10] | b[11] << 16, b[12] | b[13] << 16, b[14] | b[15] << 16);
 }
 
-/* Plain streaming read of n 16-byte cells -- the yardstick scope_frame_pool_alloc times a candidate allocation with: 256
- * threads per workgroup, four loads per lane in flight (the depth at which this chip reads fastest).
- * The result goes nowhere; the comparison only keeps the loads alive. */
-__global__ __launch_bounds__(256) void scope_read_probe_kernel(const scope_v4 *p, u64 n, u32 *sink)
-{
-	const u64 stride = (u64)gridDim.x * blockDim.x;
-	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	scope_v4 acc = {0, 0, 0, 0};
-	for (; i + 3 * stride < n; i += 4 * stride) {
-		const scope_v4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
-		const scope_v4 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
-		acc ^= a ^ b ^ c ^ d;
-	}
-	for (; i < n; i += stride)
-		acc ^= __builtin_nontemporal_load(p + i);
-	if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink)
-		*sink = 1u;
-}
-
 __global__ __launch_bounds__(256) void scope_sum_reduce_kernel(const u32 *part, u32 *out, u32 slices, u32 len)
 {
 	const u32 frame = blockIdx.y;
@@ -1812,13 +1793,6 @@ hipError_t scope_launch_sat_reduce_sparse(const uint8_t *part, const uint8_t *pm
 	const u32 lds = sl_log2 ? 8192u + 32u * gpw : 0u;
 	hipLaunchKernelGGL(scope_sat_reduce_sparse_kernel, dim3(SCOPE_VSS_BINS / 16 / gpw, n_frames), dim3(256), lds, st, part,
 			   pmask, out, slices, mask_block, sl_log2, packed16 ? 1u : 0u);
-	return hipGetLastError();
-}
-
-hipError_t scope_launch_read_probe(const void *p, uint64_t bytes, uint32_t num_cu, uint32_t *sink, hipStream_t st, const ScopeTiming *tm)
-{
-	const u32 grid = max(1u, num_cu) * 8u; /* eight 256-thread workgroups per CU: 32 KiB of loads in flight per CU */
-	SCOPE_LAUNCH(scope_read_probe_kernel, dim3(grid), dim3(256), 0, st, tm, (const scope_v4 *)p, (u64)(bytes / 16), sink);
 	return hipGetLastError();
 }
 
