@@ -73,10 +73,10 @@ WORKLOAD_TEXT = {
     "vectorscope_rgb": "vectorscope with fused K0 over RGB planes",
     "waveform": "waveform per-column 256-bin (K2)",
     "histogram": "histogram 3x256 u32 (K3)",
-    "three_scope": "vectorscope (fused K0) + waveform + histogram of every frame (scope_three_scopes_batch)",
+    "three_scope": "vectorscope (fused K0) + waveform + histogram of every frame from ONE read of its plane (scope_three_scopes_batch)",
 }
 KERNEL = {"vectorscope": "scope_vss_kernel", "vectorscope_rgb": "scope_vss_kernel", "waveform": "scope_wvs_kernel",
-          "histogram": "scope_his_kernel", "three_scope": "scope_dock_kernel / scope_vss_kernel + scope_wvs_kernel"}
+          "histogram": "scope_his_kernel", "three_scope": "scope_trio_kernel (one read; two passes = scope_vss_kernel + scope_wvs_kernel with dock=0)"}
 
 
 def log(*a):
@@ -1115,8 +1115,10 @@ class Legs:
             vr["achieved"] = round(vw.algo_bytes / (sus["ms_per_step"] * 1e-3) / 1e9, 1)
             vr["frac"] = vr["frac_whole_step"]
             vr["bound"] = "lds/valu issue (4 LDS atomics + K0 per pixel); hbm is the yardstick, not the ceiling"
-            vr["ceiling_estimate"] = {"gpix_per_s": 1300, "frac_of_hbm_peak": 0.64,
-                                      "from": "ds_add_u32 at 4.5 clk per wave instruction, 4 per pixel, 256 CUs at 2.4 GHz"}
+            vr["ceiling_estimate"] = {"gpix_per_s": 1100, "frac_of_hbm_peak": 0.62,
+                                      "from": "the larger of LDS issue (3 waveform adds at 2.1 x the conflict-free 4.5 clk per wave instruction "
+                                              "-- one table replica -- + 1 vectorscope add at 7.5: 0.56 clk per pixel and CU) and VALU issue "
+                                              "(31.3 instructions per pixel / 64 lanes per clk = 0.49), 256 CUs at 2.4 GHz; DESIGN.md 3.8"}
             vr["note"] = "achieved = SURVEY 8(d) config-5 bytes (one read of the frames + the three tables) / whole step"
         out = {"value": round(self.n * self.w * self.h / (sus["ms_per_step"] * 1e-3) / 1e9, 3), "unit": "Gpix/s", "components": f"{comp:#04x}",
                "ms_per_step": sus["ms_per_step"], "steps": sus["steps"], "parity": ok, "roofline": vr}
