@@ -1237,6 +1237,10 @@ __global__ __launch_bounds__(256) void scope_sat_reduce_kernel(const uint8_t *pa
  * slices = 256 workgroups x 16 groups x 16 slice lanes.
  * mask_block = blockDim.x of the producing launch: group g is bit g / mask_block of byte g % mask_block of a mask.
  * grid = (4096 / gpw, n_frames); dynamic LDS = 8 KiB + 32 * gpw bytes. */
+/* K = slices a slice lane takes (1 ... 16; >= slices / 2^sl_log2): the loads are unconditional, so a launch of 4
+ * slices per frame (the 64-frame batches) issued 16 mask and 16 group loads per thread for ONE useful pair until round 3 --
+ * 18.5 us per 64-frame step, 5.6 % of it; with K = 1: see profiles/round3. */
+template <int K>
 __global__ __launch_bounds__(256) void scope_sat_reduce_sparse_kernel(const uint8_t *part, const uint8_t *pmask, uint8_t *out,
 									     u32 slices, u32 mask_block, u32 sl_log2, u32 packed16)
 {
@@ -1255,26 +1259,26 @@ __global__ __launch_bounds__(256) void scope_sat_reduce_sparse_kernel(const uint
 	/* Every load is unconditional (a lane without a slice, or with an unflagged group, re-reads cell 0 of its own
 	 * column, which is always mapped, and drops the value): predicated loads made hipcc wait for each one inside
 	 * its branch -- 32 serial round trips, 10 us for one frame. */
-	u32 mb[16];
-	bool on[16];
-	uint4 q[16];
+	u32 mb[K];
+	bool on[K];
+	uint4 q[K];
 #pragma unroll
-	for (u32 k = 0; k < 16; k++) {
+	for (u32 k = 0; k < (u32)K; k++) {
 		const u32 s = sl + k * nsl;
 		mb[k] = m[(s < slices ? s : 0u) * 16u];
 	}
 #pragma unroll
-	for (u32 k = 0; k < 16; k++) {
+	for (u32 k = 0; k < (u32)K; k++) {
 		const u32 s = sl + k * nsl;
 		on[k] = (s < slices) & (((mb[k] >> mbit) & 1u) != 0);
 		q[k] = p[(on[k] ? s : 0u) * 16u];
 	}
 #pragma unroll
-	for (u32 k = 0; k < 16; k++)
+	for (u32 k = 0; k < (u32)K; k++)
 		if (!on[k])
 			q[k] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-	for (u32 k = 0; k < 16; k++) {
+	for (u32 k = 0; k < (u32)K; k++) {
 		acc[0] += q[k].x & 0x00ff00ffu;
 		acc[4] += (q[k].x >> 8) & 0x00ff00ffu;
 		acc[1] += q[k].y & 0x00ff00ffu;
@@ -1791,8 +1795,28 @@ hipError_t scope_launch_sat_reduce_sparse(const uint8_t *part, const uint8_t *pm
 		sl_log2++;
 	const u32 gpw = 256u >> sl_log2;
 	const u32 lds = sl_log2 ? 8192u + 32u * gpw : 0u;
-	hipLaunchKernelGGL(scope_sat_reduce_sparse_kernel, dim3(SCOPE_VSS_BINS / 16 / gpw, n_frames), dim3(256), lds, st, part,
-			   pmask, out, slices, mask_block, sl_log2, packed16 ? 1u : 0u);
+	const dim3 grid(SCOPE_VSS_BINS / 16 / gpw, n_frames);
+	const u32 per_lane = (slices + (1u << sl_log2) - 1u) >> sl_log2; /* slices a slice lane takes: <= 16 for <= 256 slices */
+#define SCOPE_REDUCE_K(K)                                                                                               \
+	hipLaunchKernelGGL(scope_sat_reduce_sparse_kernel<K>, grid, dim3(256), lds, st, part, pmask, out, slices, mask_block, \
+			   sl_log2, packed16 ? 1u : 0u)
+	if (per_lane <= 1)
+		SCOPE_REDUCE_K(1); /* the 64-frame batches: 4 slices per frame */
+	else if (per_lane <= 2)
+		SCOPE_REDUCE_K(2);
+	else if (per_lane <= 4)
+		SCOPE_REDUCE_K(4);
+	else if (per_lane <= 6)
+		SCOPE_REDUCE_K(6); /* the ring of three: 80 / 85 slices per frame */
+	else if (per_lane <= 8)
+		SCOPE_REDUCE_K(8);
+	else if (per_lane <= 10)
+		SCOPE_REDUCE_K(10); /* one frame over staged planes: 160 slices */
+	else if (per_lane <= 12)
+		SCOPE_REDUCE_K(12);
+	else
+		SCOPE_REDUCE_K(16); /* one frame, 240 / 256 slices */
+#undef SCOPE_REDUCE_K
 	return hipGetLastError();
 }
 
