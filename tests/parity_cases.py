@@ -541,3 +541,23 @@ def check_vectorscope_side_reduce(ctx, oracle, to_dev, to_host, w, h, dists, cal
     ctx.vectorscope_batch_dev(batches[0], extra[2][1], sync=True)
     for k, which in enumerate((0, -1, 0)):
         assert_same(to_host(extra[k][0]).reshape(256, 256), oracle.vectorscope(pairs[which][1], w), f"side reduce then plain, table {k}")
+
+
+def check_pipeline_without_histogram(ctx, oracle, w, h, depth=2):
+    """scope_pipe_* with vectorscope + waveform only: the one-read kernel in its form WITHOUT the histogram hand-off
+    (scope_trio_kernel<CH, false>); the histogram pointer comes back NULL."""
+    import obs_color_monitor_amd as ocm
+
+    frames_ = [oracle.fill_frame(w, h, d, 40 + d) for d in (1, 5, 2)]
+    pipe = ocm.ScopePipe(ctx, w, h, depth=depth, colorspace=2, wvs_components=0x05, his_components=0)
+    try:
+        for f in frames_:
+            while not pipe.submit(f.ctypes.data, 4 * w):
+                pipe.collect()
+            vss, wvs, his = pipe.collect()
+            yuv = oracle.rgb_to_yuv(f, w, 2)
+            assert his is None
+            assert_same(vss, oracle.vectorscope(yuv, w), "pipe without histogram: vectorscope")
+            assert_same(wvs, oracle.waveform(f, yuv, w, 0x05), "pipe without histogram: waveform 0x05")
+    finally:
+        pipe.close()

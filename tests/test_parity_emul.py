@@ -360,3 +360,7 @@ def test_frame_pool_alloc_and_free(emul_ctx):
 def test_vectorscope_side_reduce(emul_ctx, oracle):
     pc.check_vectorscope_side_reduce(emul_ctx, oracle, _np_dev, lambda hnd: hnd, 96, 40, [1, 5, 2], calls=7)
     pc.check_vectorscope_side_reduce(emul_ctx, oracle, _np_dev, lambda hnd: hnd, 64, 30, [5, 3], calls=4, fuse=True)
+
+
+def test_pipeline_without_histogram(emul_ctx, oracle):
+    pc.check_pipeline_without_histogram(emul_ctx, oracle, 72, 20)

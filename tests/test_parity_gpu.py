@@ -916,3 +916,7 @@ def test_vectorscope_side_reduce(hip_ctx, oracle):
     to_dev, to_host = _torch_dev()
     pc.check_vectorscope_side_reduce(hip_ctx, oracle, to_dev, to_host, 3840, 2160, [1, 5, 2, 3], calls=40)
     pc.check_vectorscope_side_reduce(hip_ctx, oracle, to_dev, to_host, 1920, 1080, [5, 1], calls=300, fuse=True)
+
+
+def test_pipeline_without_histogram(hip_ctx, oracle):
+    pc.check_pipeline_without_histogram(hip_ctx, oracle, 1920, 1080, depth=3)
