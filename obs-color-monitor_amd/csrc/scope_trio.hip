@@ -1,8 +1,8 @@
 /*
  * scope_trio.hip -- scope_trio_kernel: the dock's three scopes (vectorscope through the fused K0, waveform, histogram) of
  * every frame of a launch from ONE read of its RGB plane, both LDS tables resident (src/roi.c:329-341 hands one staged
- * surface to every registered scope; the reference walks it three times).  A translation unit of its own: it is the
- * kernel under development this round and compiles in a fraction of scope_kernels.hip's time.
+ * surface to every registered scope; the reference walks it three times).  A translation unit of its own (it compiles in
+ * seconds where scope_kernels.hip takes minutes: `make trio_variant` builds A/B variants of it alone).
  *
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (K0 must not be FMA-contracted).
  */
@@ -11,7 +11,7 @@
 /* ------------------------------------------------------------------------------------------
  * The dock's three scopes from ONE read, for ANY number of frames: scope_trio_kernel (round 3).
  *
- * scope_dock_kernel above reads a frame once but only where one round of strips covers the launch (one 4K frame), because it
+ * scope_dock_kernel (scope_kernels.hip, round 2) reads a frame once but only where one round of strips covers the launch (one 4K frame), because it
  * time-shares the LDS between the waveform's and the vectorscope's table and has to hold a strip's texels in registers in
  * between; the ring of three and every batch fell back to two reads of the planes (1.91 x the algorithmic traffic).
  *
