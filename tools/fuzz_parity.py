@@ -54,10 +54,12 @@ def run(ctx, o, cases, seed, log=print, to_dev=None, to_host=None):
         if rnd.random() < 0.6:
             hc = wc & hc or wc  # mostly a subset: the one-pass forms
         n = rnd.choice([1, 1, 1, 2, 3])
+        if w * h <= 64 * 1024 and rnd.random() < 0.3:
+            n = rnd.choice([5, 8, 17, 66])  # batches of small frames: several strips per slice, more frames than a launch takes
         tag = f"case {case}: {w}x{h} pitch {ls} dist {dist} cs {cs} wc {wc:#x} hc {hc:#x} n {n}"
         try:
             pc.check_three_scopes_dev(ctx, o, to_dev, to_host, w, h, [dist] * n if n > 1 else [dist], wc, hc, ls, cs, reps=1)
-            with pc.options(ctx, dock=0):
+            with pc.options(ctx, dock=rnd.choice([0, 2])):  # the two-pass form / round 2's one-frame kernel
                 pc.check_three_scopes_dev(ctx, o, to_dev, to_host, w, h, [dist], wc, hc, ls, cs, reps=1)
             comp = rnd.choice(pc.COMPONENTS)
             pc.check_waveform(ctx, o, w, h, dist, comp, ls, fuse=bool(comp & 0x70) and rnd.random() < 0.5, colorspace=cs)
