@@ -32,6 +32,15 @@ for n in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("8"
         t0 = t[:, 0].min()
         us = (t - t0) / 100.0   # 100 MHz
         res.append((us[:, 0].max(), np.median(us[:, 1]), us[:, 1].min(), us[:, 1].max(), us[:, 2].max(), np.percentile(us[:, 1], 10), np.percentile(us[:, 1], 90)))
+        durs = globals().setdefault("_durs", [])
+        durs.append((us[:, 1] - us[:, 0]).copy())
+    # is a workgroup that is slow in one launch slow in the next one too (same frames, same slices)?  correlation of the
+    # per-workgroup loop durations between consecutive traced launches, and what is left after taking the mean pattern out
+    d = np.array(globals()["_durs"][-5:])
+    cc = [float(np.corrcoef(d[i], d[i + 1])[0, 1]) for i in range(len(d) - 1)]
+    print("   loop duration per workgroup: correlation between consecutive launches", " ".join(f"{x:.2f}" for x in cc),
+          f"; spread of the mean pattern {d.mean(axis=0).std():.2f} us, of the residual {(d - d.mean(axis=0)).std():.2f} us; slowest workgroups (mean): ",
+          " ".join(f"{i}:{v:.0f}" for i, v in sorted(enumerate(d.mean(axis=0)), key=lambda t: -t[1])[:8]))
     ends = us[:, 1]  # last launch: when each workgroup left its pixel loop
     starts = us[:, 0]
     print("   by XCD (workgroup id mod 8), mean START [us]:", " ".join(f"{starts[x::8].mean():.1f}" for x in range(8)),
