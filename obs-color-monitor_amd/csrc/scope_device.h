@@ -76,7 +76,7 @@ __device__ __forceinline__ u32 scope_k0_texel(u32 px, const ScopeK0 &k, bool nee
  * number, below 4 -- is "near a step": its cell is recomputed with the fp32 chain (a wave votes per cell;
  * 6e-5 .. 1e-3 of all colours).  Two rows' fractions travel as the halves of one register (v_perm_b32) and the
  * running minimum over a cell is a v_pk_min_u16.  Black is an exact tie (V = 128.0) on which both paths agree,
- * and common (letterbox bars): cells that are black throughout are exempt.
+ * and common (letterbox bars): black texels are exempt.
  * tests/test_parity_gpu.py runs all 2^24 colours through this code against the oracle. */
 __device__ __forceinline__ int scope_mad24(int a, int b, int c)
 {
@@ -128,10 +128,9 @@ __device__ __forceinline__ u32 scope_k0_fixed(u32 px, const ScopeK0 &k, bool nee
 	return out;
 }
 
-/* N texels of one lane, in place.  The votes are wave-wide: a cell is redone in fp32 by the whole wave when any
- * lane holds a texel near a step (identical results for the other lanes, that is what the exhaustive test says).
- * Cells that are black throughout are exempt (black is an exact tie both paths agree on); a black texel next to
- * other colours just sends its cell to the fp32 path, which is as right as the fast one. */
+/* N texels of one lane, in place.  The votes are wave-wide: a texel is redone in fp32 by the whole wave when any
+ * lane holds one near a step in that position (identical results for the other lanes, that is what the exhaustive test
+ * says).  Black is exempt: an exact tie both paths agree on. */
 template <int N, bool VSSKEY = false>
 __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, bool need_uv, bool need_y)
 {
@@ -140,24 +139,65 @@ __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, boo
 	for (int j = 0; j < N; j++)
 		t[j] = scope_k0_fixed<VSSKEY>(p[j], k, need_uv, need_y, worst);
 	const bool near_step = min(worst & 0xffffu, worst >> 16) < SCOPE_K0_NEAR;
-	if (__ballot(near_step) != 0) { /* rare, except on black */
+	if (__ballot(near_step) != 0) { /* 3 % of the cells of a wave on noise (64 lanes x 4 texels x 1.2e-4), and black */
 		u32 any = 0;
 #pragma unroll
 		for (int j = 0; j < N; j++)
 			any |= p[j];
 		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
+			/* which of the N texels: the wave redoes only those (one of four, as a rule) */
 #pragma unroll
 			for (int j = 0; j < N; j++) {
-				p[j] = scope_k0_texel(p[j], k, need_uv, need_y);
-				if (VSSKEY)
-					p[j] = vss_bin(p[j]);
+				u32 wj = 0xffffffffu;
+				(void)scope_k0_fixed<VSSKEY>(p[j], k, need_uv, need_y, wj);
+				const bool nj = min(wj & 0xffffu, wj >> 16) < SCOPE_K0_NEAR && (p[j] & 0x00ffffffu) != 0;
+				if (N == 1 || __ballot(nj) != 0) {
+					t[j] = scope_k0_texel(p[j], k, need_uv, need_y);
+					if (VSSKEY)
+						t[j] = vss_bin(t[j]);
+				}
 			}
-			return;
 		}
 	}
 #pragma unroll
 	for (int j = 0; j < N; j++)
 		p[j] = t[j];
+}
+
+/* The vectorscope's pair form (HASH 2, vss_add_pair): four texels in, the chroma of texels (0, 1) and (2, 3) out as
+ * pu[i] = U_even | U_odd << 16 and pv[i] likewise -- the top bytes of the fixed-point sums picked up two texels at a time
+ * by one v_perm_b32 per row, instead of a key per texel.  Same votes, same fp32 redo as scope_k0_cell. */
+__device__ __forceinline__ void scope_k0_cell_uv(const u32 (&p)[4], const ScopeK0 &k, u32 (&pu)[2], u32 (&pv)[2])
+{
+	u32 eu[4], ev[4], worst = 0xffffffffu;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const u32 b = p[j] & 0xffu;
+		eu[j] = scope_k0_row(p[j], (int)b, k.fu);
+		ev[j] = scope_k0_row(p[j], (int)b, k.fv);
+		worst = scope_pk_min_u16(worst, scope_perm(ev[j], eu[j], 0x06050201u));
+	}
+	const bool near_step = min(worst & 0xffffu, worst >> 16) < SCOPE_K0_NEAR;
+	if (__ballot(near_step) != 0) {
+		const u32 any = p[0] | p[1] | p[2] | p[3];
+		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const u32 f = scope_perm(ev[j], eu[j], 0x06050201u);
+				const bool nj = min(f & 0xffffu, f >> 16) < SCOPE_K0_NEAR && (p[j] & 0x00ffffffu) != 0;
+				if (__ballot(nj) != 0) { /* the wave redoes the texels that need it: one of the four, as a rule */
+					const u32 t = scope_k0_texel(p[j], k, true, false); /* U, 0, V, 255 */
+					eu[j] = t << 24;
+					ev[j] = t << 8;
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		pu[i] = scope_perm(eu[2 * i + 1], eu[2 * i], 0x0c070c03u);
+		pv[i] = scope_perm(ev[2 * i + 1], ev[2 * i], 0x0c070c03u);
+	}
 }
 
 /* The matrix with the rows' constant terms pinned into vector registers (scope_pin_vgpr): what a fused kernel hands to
@@ -235,17 +275,44 @@ __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
 
 #define VSS_WORDS 32768u
 #define VSS_EPOCH_PIXELS 65280u
+/* HASH 2 (the fused-K0 kernel, which is short of VALU issue slots): rows of 136 words, word v*136 + (u >> 1), no
+ * exclusive-or -- 16 consecutive rows start on 16 different multiples of eight words as well (136 = 2 * 64 + 8) -- and
+ * 34 816 words = 136 KiB of the CU's 160.  Every word index fits 16 bits, so TWO pixels' indices are worked out in the
+ * halves of one register (vss_add_pair): 4.5 VALU instructions per pixel from the fixed-point sums to the two LDS
+ * operands instead of 7. */
+#define VSS_PITCH2 136u
+template <int HASH> struct VssTable {
+	static constexpr u32 words = HASH == 2 ? 256u * VSS_PITCH2 : VSS_WORDS;
+};
 
 template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u32 n)
 {
 	const u32 t = key >> 7; /* v << 9 | u << 1 */
 	u32 byte;
-	if (HASH == 1)
+	if (HASH == 2)
+		byte = (key >> 16) * (VSS_PITCH2 * 4u) + (t & 0x1fcu); /* the slow door of the pair layout: see vss_add_pair */
+	else if (HASH == 1)
 		byte = t & 0x1fffcu;
 	else
 		byte = scope_bitop3<0x78>(t, key >> 11, 0x1e0u) & 0x1fffcu; /* t ^ (v << 5 & 0x1e0); key >> 11 = v << 5 | u >> 3 */
 	/* half u & 1 = bit 8 of the key; bits 4..7 are zero, so the shift count is 0 or 16 */
 	scope_lds_add_at(tab, byte, n << ((key >> 4) & 31u));
+}
+
+/* HASH 2, two pixels at once: pu = U0 | U1 << 16, pv = V0 | V1 << 16 (scope_k0_cell_uv).  Word indices in 16-bit halves
+ * (v_pk_lshrrev_b16, v_pk_mad_u16), then per pixel one SDWA shift for the byte address and one for the increment
+ * 1 << 16 (u & 1), whose count is the byte (u & 15) << 4 of pu << 4 (the shifter reads five bits). */
+__device__ __forceinline__ void vss_add_pair(u32 *tab, u32 pu, u32 pv)
+{
+	const u32 w = scope_pk_mad_u16(pv, VSS_PITCH2 | (VSS_PITCH2 << 16), scope_pk_lshr_u16(pu, 1));
+	const u32 q = pu << 4;
+	scope_lds_add_at(tab, scope_shl_word0(2u, w), scope_shl_by_byte0(q, 1u));
+	scope_lds_add_at(tab, scope_shl_word1(2u, w), scope_shl_by_byte2(q, 1u));
+}
+/* the key (0, U, V, 0) of either pixel of a pair: what the absorb mode and the votes compare */
+__device__ __forceinline__ u32 vss_pair_key(u32 pu, u32 pv, int odd)
+{
+	return scope_perm(pv, pu, odd ? 0x0c06020cu : 0x0c04000cu);
 }
 
 /* Flat content (screen capture, graphics, letterbox, a paused scene): almost every pixel of a lane's
@@ -285,6 +352,47 @@ template <int HASH> __device__ __forceinline__ void vss_absorb4(u32 *tab, VssLan
 	}
 }
 
+/* The same in pair form (HASH 2): lane_u / lane_v are the lane's colour as U | U << 16, V | V << 16 (0xffffffff while it
+ * has none: no pair looks like that), x = 0 in the half whose pixel has that colour.  A cell of the lane's colour
+ * throughout -- nearly all of them, in this mode -- costs five instructions. */
+__device__ __forceinline__ void vss_absorb_pairs(u32 *tab, VssLane &st, u32 &lane_u, u32 &lane_v, u32 pu0, u32 pv0, u32 pu1, u32 pv1)
+{
+	u32 x0 = scope_bitop3<0xf6>(pu0 ^ lane_u, pv0, lane_v); /* (pu ^ lane_u) | (pv ^ lane_v) */
+	u32 x1 = scope_bitop3<0xf6>(pu1 ^ lane_u, pv1, lane_v);
+	if ((x0 | x1) == 0u) {
+		st.count += 4;
+		return;
+	}
+	bool e0 = (x0 & 0xffffu) == 0u, e1 = (x0 >> 16) == 0u, e2 = (x1 & 0xffffu) == 0u, e3 = (x1 >> 16) == 0u;
+	if (!(e0 | e1 | e2 | e3)) { /* the colour changed: hand in the old one, start counting the first pixel's */
+		if (st.count)
+			vss_add<2>(tab, st.colour, st.count);
+		st.colour = vss_pair_key(pu0, pv0, 0);
+		st.count = 0;
+		lane_u = scope_perm(0u, pu0, 0x0c000c00u);
+		lane_v = scope_perm(0u, pv0, 0x0c000c00u);
+		x0 = scope_bitop3<0xf6>(pu0 ^ lane_u, pv0, lane_v);
+		x1 = scope_bitop3<0xf6>(pu1 ^ lane_u, pv1, lane_v);
+		e0 = true;
+		e1 = (x0 >> 16) == 0u;
+		e2 = (x1 & 0xffffu) == 0u;
+		e3 = (x1 >> 16) == 0u;
+	}
+	st.count += (u32)e0 + (u32)e1 + (u32)e2 + (u32)e3;
+	if (!(e0 & e1 & e2 & e3)) {
+		const u32 w0 = scope_pk_mad_u16(pv0, VSS_PITCH2 | (VSS_PITCH2 << 16), scope_pk_lshr_u16(pu0, 1)), q0 = pu0 << 4;
+		const u32 w1 = scope_pk_mad_u16(pv1, VSS_PITCH2 | (VSS_PITCH2 << 16), scope_pk_lshr_u16(pu1, 1)), q1 = pu1 << 4;
+		if (!e0)
+			scope_lds_add_at(tab, scope_shl_word0(2u, w0), scope_shl_by_byte0(q0, 1u));
+		if (!e1)
+			scope_lds_add_at(tab, scope_shl_word1(2u, w0), scope_shl_by_byte2(q0, 1u));
+		if (!e2)
+			scope_lds_add_at(tab, scope_shl_word0(2u, w1), scope_shl_by_byte0(q1, 1u));
+		if (!e3)
+			scope_lds_add_at(tab, scope_shl_word1(2u, w1), scope_shl_by_byte2(q1, 1u));
+	}
+}
+
 /* Add what the lanes still hold.  Called by whole waves (uniform control flow).  When every pending
  * lane of the wave holds the same colour -- the flat-frame case -- one lane adds the wave's total. */
 template <int HASH> __device__ __forceinline__ void vss_flush_lane(u32 *tab, VssLane &st)
@@ -317,9 +425,9 @@ __device__ __forceinline__ u32 vss_clamp_pair(u32 w0, u32 w1)
 	return min(w0 & 0xffffu, 255u) | (min(w0 >> 16, 255u) << 8) | (min(w1 & 0xffffu, 255u) << 16) | (min(w1 >> 16, 255u) << 24);
 }
 
-__device__ __forceinline__ void vss_clamp_pass(u32 *tab)
+__device__ __forceinline__ void vss_clamp_pass(u32 *tab, u32 words = VSS_WORDS)
 {
-	for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4) {
+	for (u32 i = threadIdx.x * 4; i < words; i += blockDim.x * 4) {
 		uint4 x = *(uint4 *)&tab[i];
 		if ((x.x | x.y | x.z | x.w) & 0xff00ff00u) {
 			x.x = vss_clamp_word(x.x);

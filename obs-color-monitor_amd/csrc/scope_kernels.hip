@@ -140,7 +140,10 @@ __device__ __forceinline__ u32 scope_slice_begin_cells(u32 total, u32 s, u32 S)
 	return c & ~((u32)SCOPE_SLICE_ALIGN - 1u);
 }
 
-template <int VECW, int U, bool NT, bool CONTIG, typename Pro, typename Hook, typename F>
+#ifndef SCOPE_STREAM_MAIN
+#define SCOPE_STREAM_MAIN 1 /* 0: every batch through the checked form (A/B) */
+#endif
+template <int VECW, int U, bool NT, bool CONTIG, bool MAIN = CONTIG, typename Pro, typename Hook, typename F>
 __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 c0, u32 c1,
 					     u32 glog2, Pro &&after_first_issue, Hook &&before_batch, F &&fn)
 {
@@ -218,7 +221,40 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	 * compiler can wait with vmcnt(U) instead of draining the queue. */
 	SCOPE_ISSUE(va, oka);
 	after_first_issue();
-	for (u32 b = 0; b < batches; b += 2) {
+	u32 b = 0;
+	if (CONTIG && MAIN && SCOPE_STREAM_MAIN) {
+		/* The first `full` batches are inside the stream for every lane of every group (the shortest group has
+		 * len >> glog2 cells): no range test, no address select and no predication there -- two VALU instructions per
+		 * load and an exec-mask branch per load less (what the fused-K0 kernels are short of); the rest of the stream,
+		 * one or two iterations, runs the checked form below.  oka stays all true across this loop: it was set by the
+		 * checked ISSUE of batch 0, and the loop only runs when that batch is full.
+		 * Same-process A/B on 64 x 4K: fused-K0 vectorscope +1.9 %, fused Y'CbCr histogram +4 %, plain vectorscope
+		 * +0.3 %; the plain RGB histogram -2 .. -5 % (its callers pass MAIN = false).  (A form in which the vectorscope's
+		 * main loop knew only the plain adds and left for the general loop when the vote said absorb -- to get the vote's
+		 * 1.4 % back -- gained nothing on noise and lost 6 % on flat and 13 % on screen content: both bodies in one loop.) */
+		const u32 full = (len >> glog2) / step;
+		bool yes[U];
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			yes[k] = true;
+#define SCOPE_ISSUE_FULL(v)                                                                        \
+	do {                                                                                       \
+		_Pragma("unroll") for (int k = 0; k < U; k++)                                      \
+		{                                                                                  \
+			v[k] = scope_load_base<NT, vec_t>(base, off);                              \
+			off += tg * cell_bytes;                                                    \
+		}                                                                                  \
+		c += step;                                                                         \
+	} while (0)
+		for (; b + 2 < full; b += 2) {
+			SCOPE_ISSUE_FULL(vb);
+			SCOPE_BIN(va, yes);
+			SCOPE_ISSUE_FULL(va);
+			SCOPE_BIN(vb, yes);
+		}
+#undef SCOPE_ISSUE_FULL
+	}
+	for (; b < batches; b += 2) {
 		SCOPE_ISSUE(vb, okb);
 		SCOPE_BIN(va, oka);
 		SCOPE_ISSUE(va, oka);
@@ -244,15 +280,59 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		if (since_clamp + px > VSS_EPOCH_PIXELS) {
 			vss_flush_lane<HASH>(tab, st); /* pending pixels belong to the epoch that ends here */
 			__syncthreads();
-			vss_clamp_pass(tab);
+			vss_clamp_pass(tab, VssTable<HASH>::words);
 			__syncthreads();
 			since_clamp = 0;
 		}
 		since_clamp += px;
 	};
 	u32 vote_clock = 0;          /* wave-uniform: every lane runs the same batches */
-	bool absorb_verdict = false; /* wave-uniform: comes out of a ballot */
-	if (VECW == 4) {
+	u32 absorb_verdict = 0;      /* wave-uniform and kept in a scalar register (readfirstlane): a bool carried round the
+				      * loop becomes a lane mask and every `if (absorb)` an exec-mask dance */
+	if (VECW == 4 && FUSE && HASH == 2) {
+		/* the pair form: chroma travels two pixels to a register from the matrix rows to the LDS operands */
+		/* the lane's colour as U | U << 16 and V | V << 16; 0xffffffff (no pair looks like that) while it has none */
+		u32 lane_u = st.colour == 0xffffffffu ? 0xffffffffu : scope_perm(0u, st.colour, 0x0c010c01u);
+		u32 lane_v = st.colour == 0xffffffffu ? 0xffffffffu : scope_perm(0u, st.colour, 0x0c020c02u);
+		auto bin_pairs = [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
+			u32 pu[U][2], pv[U][2];
+#pragma unroll
+			for (int k = 0; k < U; k++) {
+				const u32 p[4] = {q[k][0], q[k][1], q[k][2], q[k][3]};
+				scope_k0_cell_uv(p, k0, pu[k], pv[k]);
+			}
+			bool absorb = MERGE == 1 || MERGE == 2;
+			if (MERGE == 3) { /* the same vote as below */
+				if ((vote_clock++ & (16u / U - 1u)) == 0) {
+					bool flat = true;
+#pragma unroll
+					for (int k = 0; k < U; k++)
+						flat &= !ok[k] || ((pu[k][0] == pu[k][1]) & (pv[k][0] == pv[k][1]) &
+								   (pu[k][0] == scope_perm(0u, pu[k][0], 0x01000302u)) &
+								   (pv[k][0] == scope_perm(0u, pv[k][0], 0x01000302u)));
+					absorb_verdict = (u32)__builtin_amdgcn_readfirstlane((int)(__popcll(__ballot(flat)) >= 16));
+				}
+				absorb = __builtin_amdgcn_readfirstlane(absorb_verdict) != 0;
+			}
+			if (__builtin_expect(absorb, false)) {
+#pragma unroll
+				for (int k = 0; k < U; k++)
+					if (ok[k])
+						vss_absorb_pairs(tab, st, lane_u, lane_v, pu[k][0], pv[k][0], pu[k][1], pv[k][1]);
+			} else {
+#pragma unroll
+				for (int k = 0; k < U; k++)
+					if (ok[k]) {
+						vss_add_pair(tab, pu[k][0], pv[k][0]);
+						vss_add_pair(tab, pu[k][1], pv[k][1]);
+					}
+			}
+		};
+		if (linesize == ncols * 16u)
+			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_pairs);
+		else
+			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_pairs);
+	} else if (VECW == 4) {
 		auto bin_cells = [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
 					       u32 idx[U][4];
 #pragma unroll
@@ -278,11 +358,11 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 							       for (int k = 0; k < U; k++)
 								       flat &= !ok[k] || ((idx[k][0] == idx[k][1]) & (idx[k][1] == idx[k][2]) &
 											  (idx[k][2] == idx[k][3]));
-							       absorb_verdict = __popcll(__ballot(flat)) >= 16;
+							       absorb_verdict = (u32)__builtin_amdgcn_readfirstlane((int)(__popcll(__ballot(flat)) >= 16));
 						       }
-						       absorb = absorb_verdict;
+						       absorb = __builtin_amdgcn_readfirstlane(absorb_verdict) != 0;
 					       }
-					       if (absorb) {
+					       if (__builtin_expect(absorb, false)) {
 #pragma unroll
 						       for (int k = 0; k < U; k++)
 							       if (ok[k])
@@ -348,7 +428,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 			return;
 		zeroed = true;
 		const uint4 zero = make_uint4(0, 0, 0, 0);
-		for (u32 i = threadIdx.x * 4; i < VSS_WORDS; i += blockDim.x * 4)
+		for (u32 i = threadIdx.x * 4; i < VssTable<HASH>::words; i += blockDim.x * 4)
 			*(uint4 *)&tab[i] = zero;
 		__syncthreads();
 	};
@@ -375,7 +455,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	u32 wrote = 0, k = 0;
 	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
 		const u32 row = 255u - (g >> 4); /* table row v of output row g >> 4 */
-		const u32 w0 = (row << 7) + (((g & 15u) << 3) ^ (HASH == 1 ? 0u : ((row & 15u) << 3)));
+		const u32 w0 = HASH == 2 ? row * VSS_PITCH2 + ((g & 15u) << 3)
+					 : (row << 7) + (((g & 15u) << 3) ^ (HASH == 1 ? 0u : ((row & 15u) << 3)));
 		const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
 		if (!pmask) {
 			out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
@@ -444,7 +525,7 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 					       }
 		};
 		if (linesize == ncols * 16u) /* uniform: rows without padding */
-			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
+			scope_stream<4, U, NT, true, FUSE>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
 		else
 			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
 	} else {
@@ -1088,7 +1169,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_dock_kernel(ScopeFrameSet f
 			absorb = __popcll(__ballot(!ok || key[0] == key[1])) >= 48;
 		if (!ok)
 			continue;
-		if (absorb) {
+		if (__builtin_expect(absorb, false)) {
 			bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
 			if (!(e0 | e1)) {
 				if (st.count)
@@ -1422,18 +1503,21 @@ struct VssArgs {
 
 template <int U, bool NT, int MERGE, bool FUSE, int HASH> hipError_t vss_variant(const VssArgs *a)
 {
+	constexpr u32 lds = VssTable<HASH>::words * 4u;
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_vss_kernel<U, NT, MERGE, FUSE, HASH>,
-					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)VSS_LDS_BYTES);
+					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	SCOPE_LAUNCH((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(a->block),
-		     VSS_LDS_BYTES, a->st, a->tm, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->k0,
+		     lds, a->st, a->tm, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->k0,
 		     a->dst, a->pmask);
 	return hipGetLastError();
 }
 
 template <int U, bool NT, int MERGE, bool FUSE> hipError_t vss_pick_hash(int hash, const VssArgs *a)
 {
-	return hash ? vss_variant<U, NT, MERGE, FUSE, 1>(a) : vss_variant<U, NT, MERGE, FUSE, 0>(a);
+	if (hash == 2 && FUSE) /* the pair layout exists for the fused-K0 form only */
+		return vss_variant<U, NT, MERGE, FUSE, FUSE ? 2 : 0>(a);
+	return hash == 1 ? vss_variant<U, NT, MERGE, FUSE, 1>(a) : vss_variant<U, NT, MERGE, FUSE, 0>(a);
 }
 template <int U, bool NT, int MERGE> hipError_t vss_pick_fuse(int fuse, int hash, const VssArgs *a)
 {
@@ -1600,7 +1684,7 @@ hipError_t scope_kernels_init(void)
 		for (int nt = 0; nt < 2; nt++)
 			for (int fuse = 0; fuse < 2; fuse++) {
 				for (int merge = 0; merge < 4; merge++)
-					for (int hash = 0; hash < 2; hash++)
+					for (int hash = 0; hash < 3; hash++)
 						if (e == hipSuccess)
 							e = vss_pick(unroll, nt, merge, fuse, hash, NULL);
 				if (e == hipSuccess)
@@ -1685,7 +1769,7 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 	if (pmask && !scope_vss_mask_block(tn))
 		return hipErrorInvalidValue;
 	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), split_regions(fs), scope_k0_matrix(colorspace), dst, pmask, st, tm};
-	return vss_pick(unroll, tn.nt_loads, tn.vss_merge, fuse_k0, tn.vss_hash, &a);
+	return vss_pick(unroll, tn.nt_loads, tn.vss_merge, fuse_k0, fuse_k0 ? tn.vss_fused_hash : tn.vss_hash, &a);
 }
 
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,

@@ -159,6 +159,36 @@ SCOPE_MUL24_BYTE(scope_umul24_byte1, "v_mul_u32_u24_sdwa", unsigned, "BYTE_1")
 SCOPE_MUL24_BYTE(scope_umul24_byte2, "v_mul_u32_u24_sdwa", unsigned, "BYTE_2")
 #undef SCOPE_MUL24_BYTE
 
+/* Two 16-bit lanes per register (VOP3P): what the vectorscope's pair addressing (vss_add_pair) is made of. */
+typedef unsigned short scope_us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned scope_pk_lshr_u16(unsigned a, unsigned n)
+{
+	const scope_us2v r = __builtin_bit_cast(scope_us2v, a) >> (unsigned short)n; /* v_pk_lshrrev_b16 */
+	return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ unsigned scope_pk_mad_u16(unsigned a, unsigned b, unsigned c)
+{
+	unsigned r;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c)); /* a * b + c in each half, mod 2^16 */
+	return r;
+}
+/* (half H of x) << n and value << (byte B of count, its low five bits): the SDWA forms pick the half / the byte out of
+ * the register, one instruction each (as a shift and a mask they are two). */
+#define SCOPE_SHL_SEL(name, sel0, sel1)                                                                                 \
+	__device__ __forceinline__ unsigned name(unsigned count, unsigned value)                                         \
+	{                                                                                                                \
+		unsigned r;                                                                                              \
+		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel0 " src1_sel:" sel1  \
+		    : "=v"(r)                                                                                            \
+		    : "v"(count), "v"(value));                                                                           \
+		return r;                                                                                                \
+	}
+SCOPE_SHL_SEL(scope_shl_word0, "DWORD", "WORD_0") /* (value & 0xffff) << count */
+SCOPE_SHL_SEL(scope_shl_word1, "DWORD", "WORD_1") /* (value >> 16) << count */
+SCOPE_SHL_SEL(scope_shl_by_byte0, "BYTE_0", "DWORD") /* value << (count & 31) */
+SCOPE_SHL_SEL(scope_shl_by_byte2, "BYTE_2", "DWORD") /* value << (count >> 16 & 31) */
+#undef SCOPE_SHL_SEL
+
 /* A wave-uniform value pinned into a VECTOR register for the rest of the kernel.  v_mad_i32_i24 takes one scalar operand
  * (gfx9 constant bus): with coefficient AND constant term in SGPRs hipcc moves the constant into a VGPR again before every
  * multiply-add -- one VALU instruction per matrix row and cell in the fused kernels.  The asm is opaque, so the copy is

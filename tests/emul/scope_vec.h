@@ -138,6 +138,33 @@ static inline void scope_lds_is_at_zero(unsigned *)
 {
 }
 
+static inline unsigned scope_pk_lshr_u16(unsigned a, unsigned n)
+{
+	return ((a & 0xffffu) >> n) | ((a >> 16) >> n << 16);
+}
+static inline unsigned scope_pk_mad_u16(unsigned a, unsigned b, unsigned c)
+{
+	const unsigned lo = ((a & 0xffffu) * (b & 0xffffu) + (c & 0xffffu)) & 0xffffu;
+	const unsigned hi = ((a >> 16) * (b >> 16) + (c >> 16)) & 0xffffu;
+	return lo | (hi << 16);
+}
+static inline unsigned scope_shl_word0(unsigned count, unsigned value)
+{
+	return (value & 0xffffu) << (count & 31u);
+}
+static inline unsigned scope_shl_word1(unsigned count, unsigned value)
+{
+	return (value >> 16) << (count & 31u);
+}
+static inline unsigned scope_shl_by_byte0(unsigned count, unsigned value)
+{
+	return value << (count & 31u);
+}
+static inline unsigned scope_shl_by_byte2(unsigned count, unsigned value)
+{
+	return value << ((count >> 16) & 31u);
+}
+
 static inline int scope_pin_vgpr(int uniform)
 {
 	return uniform;

@@ -48,11 +48,27 @@ def test_vectorscope_saturation_and_epochs(emul_ctx, oracle):
 
 
 @pytest.mark.parametrize("cs", [1, 2])
-@pytest.mark.parametrize("hash_", [0, 1])
+@pytest.mark.parametrize("hash_", [0, 1, 2])
 def test_vectorscope_fused_k0(emul_ctx, oracle, cs, hash_):
-    with pc.options(emul_ctx, **{"vss.hash": hash_}):
+    """vss.fused_hash 2 (the default): rows of 136 words, two pixels' addresses per register (vss_add_pair)."""
+    with pc.options(emul_ctx, **{"vss.fused_hash": hash_}):
         pc.check_vectorscope(emul_ctx, oracle, 70, 9, 1, None, fuse=True, colorspace=cs)
         pc.check_vectorscope(emul_ctx, oracle, 64, 8, 4, None, fuse=True, colorspace=cs)
+        pc.check_vectorscope(emul_ctx, oracle, 33, 5, 2, 140, fuse=True, colorspace=cs)
+
+
+@pytest.mark.parametrize("merge", [0, 2, 3])
+@pytest.mark.parametrize("hash_", [0, 2])
+def test_vectorscope_fused_k0_long_streams(emul_ctx, oracle, merge, hash_):
+    """One workgroup walks 131072 pixels: scope_stream's unchecked main loop and its checked tail, two clamp passes, the
+    absorb mode on flat and banded content (dist 3, 4) and the plain adds on noise, in both table layouts."""
+    for groups, unroll in ((3, 2), (0, 4), (2, 1)):
+        with pc.options(emul_ctx, **{"slices": 1, "vss.merge": merge, "vss.fused_hash": hash_, "vss.groups": groups,
+                                     "vss.fused_unroll": unroll}):
+            for dist in (1, 3, 4):
+                pc.check_vectorscope(emul_ctx, oracle, 512, 256, dist, None, fuse=True, colorspace=2)
+    with pc.options(emul_ctx, **{"slices": 1, "vss.merge": merge, "vss.fused_hash": hash_}):
+        pc.check_vectorscope(emul_ctx, oracle, 509, 130, 2, 2048, fuse=True, colorspace=1)  # tails + pitch
 
 
 @pytest.mark.parametrize("comp", pc.COMPONENTS)

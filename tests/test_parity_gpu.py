@@ -365,14 +365,28 @@ def test_fused_k0(hip_ctx, oracle, cs):
     pc.check_histogram_counts(hip_ctx, oracle, 640, 360, 1, 0x70, None, fuse=True, colorspace=cs)
 
 
+@pytest.mark.parametrize("merge", [0, 2, 3])
+@pytest.mark.parametrize("hash_", [0, 2])
+def test_fused_vectorscope_layouts_and_modes(hip_ctx, oracle, merge, hash_):
+    """vss.fused_hash 2 (the default: rows of 136 words, two pixels' addresses per register) and 0 (the plain kernel's
+    layout), with the absorb mode off, forced and voted, on noise, flat and banded content, one workgroup per frame (clamp
+    passes, scope_stream's unchecked main loop and its tail) and the default slicing, tails and a padded pitch."""
+    for slices, groups, unroll in ((1, 3, 2), (1, 0, 4), (0, -1, 2), (3, 2, 1)):
+        with pc.options(hip_ctx, **{"slices": slices, "vss.merge": merge, "vss.fused_hash": hash_, "vss.groups": groups,
+                                    "vss.fused_unroll": unroll}):
+            for dist in (1, 3, 4):
+                pc.check_vectorscope(hip_ctx, oracle, 1280, 720, dist, None, fuse=True, colorspace=2)
+            pc.check_vectorscope(hip_ctx, oracle, 509, 130, 2, 2048, fuse=True, colorspace=1)
+
+
 @pytest.mark.parametrize("cs", [1, 2])
-@pytest.mark.parametrize("hash_", [0, 1])
+@pytest.mark.parametrize("hash_", [0, 1, 2])
 def test_fused_vectorscope_all_colours(hip_ctx, oracle, cs, hash_):
     """All 2^24 colours through the vectorscope's own fused K0 (fixed point with its fp32 fallback): 64 slices see 262144 colours each, so no bin of a partial saturates early."""
     v = np.arange(1 << 24, dtype=np.uint32) | np.uint32(0xFF000000)
     rgb = v.view(np.uint8).reshape(4096, 4096 * 4)
     want = oracle.vectorscope(oracle.rgb_to_yuv(rgb, 4096, cs), 4096)
-    with pc.options(hip_ctx, **{"vss.hash": hash_}):
+    with pc.options(hip_ctx, **{"vss.fused_hash": hash_}):
         got, st = hip_ctx.vectorscope(rgb=rgb, width=4096, colorspace=cs, fuse_k0=True)
     assert st == 0
     pc.assert_same(got, want, f"fused vectorscope, all colours, cs{cs} hash{hash_}")
