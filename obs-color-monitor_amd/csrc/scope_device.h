@@ -164,14 +164,15 @@ __device__ __forceinline__ void scope_k0_cell(u32 (&p)[N], const ScopeK0 &k, boo
 		p[j] = t[j];
 }
 
-/* The vectorscope's pair form (HASH 2, vss_add_pair): four texels in, the chroma of texels (0, 1) and (2, 3) out as
+/* The vectorscope's pair form (HASH 2, vss_add_pair): 2 NP texels in, the chroma of texels (0, 1), (2, 3) out as
  * pu[i] = U_even | U_odd << 16 and pv[i] likewise -- the top bytes of the fixed-point sums picked up two texels at a time
  * by one v_perm_b32 per row, instead of a key per texel.  Same votes, same fp32 redo as scope_k0_cell. */
-__device__ __forceinline__ void scope_k0_cell_uv(const u32 (&p)[4], const ScopeK0 &k, u32 (&pu)[2], u32 (&pv)[2])
+template <int NP>
+__device__ __forceinline__ void scope_k0_cell_uv(const u32 (&p)[2 * NP], const ScopeK0 &k, u32 (&pu)[NP], u32 (&pv)[NP])
 {
-	u32 eu[4], ev[4], worst = 0xffffffffu;
+	u32 eu[2 * NP], ev[2 * NP], worst = 0xffffffffu, any = 0;
 #pragma unroll
-	for (int j = 0; j < 4; j++) {
+	for (int j = 0; j < 2 * NP; j++) {
 		const u32 b = p[j] & 0xffu;
 		eu[j] = scope_k0_row(p[j], (int)b, k.fu);
 		ev[j] = scope_k0_row(p[j], (int)b, k.fv);
@@ -179,13 +180,15 @@ __device__ __forceinline__ void scope_k0_cell_uv(const u32 (&p)[4], const ScopeK
 	}
 	const bool near_step = min(worst & 0xffffu, worst >> 16) < SCOPE_K0_NEAR;
 	if (__ballot(near_step) != 0) {
-		const u32 any = p[0] | p[1] | p[2] | p[3];
+#pragma unroll
+		for (int j = 0; j < 2 * NP; j++)
+			any |= p[j];
 		if (__ballot(near_step && (any & 0x00ffffffu) != 0) != 0) {
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
+			for (int j = 0; j < 2 * NP; j++) {
 				const u32 f = scope_perm(ev[j], eu[j], 0x06050201u);
 				const bool nj = min(f & 0xffffu, f >> 16) < SCOPE_K0_NEAR && (p[j] & 0x00ffffffu) != 0;
-				if (__ballot(nj) != 0) { /* the wave redoes the texels that need it: one of the four, as a rule */
+				if (__ballot(nj) != 0) { /* the wave redoes the texels that need it: one of them, as a rule */
 					const u32 t = scope_k0_texel(p[j], k, true, false); /* U, 0, V, 255 */
 					eu[j] = t << 24;
 					ev[j] = t << 8;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void scope_k0_cell_uv(const u32 (&p)[4], const ScopeK
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < NP; i++) {
 		pu[i] = scope_perm(eu[2 * i + 1], eu[2 * i], 0x0c070c03u);
 		pv[i] = scope_perm(ev[2 * i + 1], ev[2 * i], 0x0c070c03u);
 	}
@@ -390,6 +393,36 @@ __device__ __forceinline__ void vss_absorb_pairs(u32 *tab, VssLane &st, u32 &lan
 			scope_lds_add_at(tab, scope_shl_word0(2u, w1), scope_shl_by_byte0(q1, 1u));
 		if (!e3)
 			scope_lds_add_at(tab, scope_shl_word1(2u, w1), scope_shl_by_byte2(q1, 1u));
+	}
+}
+
+/* one pair (scope_trio_kernel's slot) */
+__device__ __forceinline__ void vss_absorb_pair(u32 *tab, VssLane &st, u32 &lane_u, u32 &lane_v, u32 pu, u32 pv)
+{
+	u32 x = scope_bitop3<0xf6>(pu ^ lane_u, pv, lane_v);
+	if (x == 0u) {
+		st.count += 2;
+		return;
+	}
+	bool e0 = (x & 0xffffu) == 0u, e1 = (x >> 16) == 0u;
+	if (!(e0 | e1)) {
+		if (st.count)
+			vss_add<2>(tab, st.colour, st.count);
+		st.colour = vss_pair_key(pu, pv, 0);
+		st.count = 0;
+		lane_u = scope_perm(0u, pu, 0x0c000c00u);
+		lane_v = scope_perm(0u, pv, 0x0c000c00u);
+		x = scope_bitop3<0xf6>(pu ^ lane_u, pv, lane_v);
+		e0 = true;
+		e1 = (x >> 16) == 0u;
+	}
+	st.count += (u32)e0 + (u32)e1;
+	if (!(e0 & e1)) {
+		const u32 w = scope_pk_mad_u16(pv, VSS_PITCH2 | (VSS_PITCH2 << 16), scope_pk_lshr_u16(pu, 1)), q = pu << 4;
+		if (!e0)
+			scope_lds_add_at(tab, scope_shl_word0(2u, w), scope_shl_by_byte0(q, 1u));
+		if (!e1)
+			scope_lds_add_at(tab, scope_shl_word1(2u, w), scope_shl_by_byte2(q, 1u));
 	}
 }
 

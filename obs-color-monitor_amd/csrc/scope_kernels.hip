@@ -299,7 +299,7 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 #pragma unroll
 			for (int k = 0; k < U; k++) {
 				const u32 p[4] = {q[k][0], q[k][1], q[k][2], q[k][3]};
-				scope_k0_cell_uv(p, k0, pu[k], pv[k]);
+				scope_k0_cell_uv<2>(p, k0, pu[k], pv[k]);
 			}
 			bool absorb = MERGE == 1 || MERGE == 2;
 			if (MERGE == 3) { /* the same vote as below */

@@ -62,8 +62,16 @@
 #ifndef TRIO_EXP
 #define TRIO_EXP 0 /* measurement only (wrong tables): bit 0 no waveform adds, 1 no vectorscope adds, 2 no K0, 3 no clamp pass */
 #endif
+#ifndef TRIO_HASH
+#define TRIO_HASH 0 /* the vectorscope table's layout.  0: as scope_vss_kernel's plain form.  2: rows of 136 words, a slot's two
+		     * texels addressed as a pair (vss_add_pair: 4.5 VALU instructions per texel instead of 7, what gave the fused-K0
+		     * vectorscope 4 %); with the waveform's 24 KiB that is all 160 KiB of the CU.  Measured here (visit p10, same
+		     * process, 64 x 4K): noise 3779 -> 3758 GB/s, natural 3724 -> 3746, flat 2890 -> 2938, screen 3074 -> 2847 --
+		     * this kernel waits for the LDS (the waveform's single replica), not for VALU issue slots: left at 0 */
+#endif
 #define TRIO_CH_BYTES 8192u
-#define TRIO_WVS_BASE (VSS_WORDS * 4u)
+#define TRIO_VSS_WORDS (VssTable<TRIO_HASH>::words)
+#define TRIO_WVS_BASE (TRIO_VSS_WORDS * 4u)
 
 template <int CH> __device__ __forceinline__ void trio_count(u32 *tab, u32 px, u32 lane_base, u32 inc)
 {
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	constexpr int D = TRIO_D;
 	u32 *tab = scope_lds;
 	scope_lds_is_at_zero(tab);
-	u32 *wt = tab + VSS_WORDS; /* [nch][256 values][8 column pairs] */
+	u32 *wt = tab + TRIO_VSS_WORDS; /* [nch][256 values][8 column pairs] */
 	const u32 W = fs.width, H = fs.height;
 	const u32 lane = threadIdx.x & 63u;
 	const u32 pair = lane & 7u, rsub = lane >> 3;
@@ -199,12 +207,15 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	/* both tables zeroed under the first loads */
 	{
 		const uint4 zero = make_uint4(0, 0, 0, 0);
-		for (u32 i = threadIdx.x * 4; i < VSS_WORDS + nch * (TRIO_CH_BYTES / 4u); i += blockDim.x * 4)
+		for (u32 i = threadIdx.x * 4; i < TRIO_VSS_WORDS + nch * (TRIO_CH_BYTES / 4u); i += blockDim.x * 4)
 			*(uint4 *)&tab[i] = zero;
 	}
 	__syncthreads();
 
 	VssLane st = {0xffffffffu, 0};
+	u32 lane_u = 0xffffffffu, lane_v = 0xffffffffu; /* TRIO_HASH 2: the lane's colour in pair form (vss_absorb_pair) */
+	(void)lane_u;
+	(void)lane_v;
 	bool absorb = false, wflat = false; /* wave-uniform */
 	u32 wp0 = 0, wp1 = 0, wn = 0; /* the waveform's pending texel pair and how often it came (absorb mode) */
 	u32 since = 0;       /* texels the vectorscope table may have taken since its last clamp pass (uniform) */
@@ -221,9 +232,9 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 			 * 34 560 texels, two strips would overflow, but five rounds of 12 288 fit, so 60 strips need 36 passes and
 			 * not 59 (a pass reads the whole 128 KiB table: 5 % of the kernel when taken once per strip) */
 			if (since + round_px > VSS_EPOCH_PIXELS && !(TRIO_EXP & 8)) { /* uniform across the workgroup */
-				vss_flush_lane<0>(tab, st); /* pending texels belong to the epoch that ends here */
+				vss_flush_lane<TRIO_HASH>(tab, st); /* pending texels belong to the epoch that ends here */
 				__syncthreads();
-				vss_clamp_pass(tab);
+				vss_clamp_pass(tab, TRIO_VSS_WORDS);
 				__syncthreads();
 				since = 0;
 			}
@@ -233,6 +244,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 				const bool v = TRIO_OK(d, g_b + (u32)d);
 				const u32 p0 = px[d][0], p1 = px[d][1];
 				u32 key[2] = {p0, p1};
+				u32 pu[1] = {0}, pv[1] = {0}; /* TRIO_HASH 2: the slot's chroma in pair form */
 				if (v && !(TRIO_EXP & 1)) {
 					if (TRIO_WABSORB && wflat) {
 						/* Flat content -- EVERY lane of the wave held a horizontally equal texel pair at the last vote
@@ -266,22 +278,31 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 				if (TRIO_EXP & 4) {
 					key[0] = vss_bin(p0);
 					key[1] = vss_bin(p1);
+				} else if (TRIO_HASH == 2) {
+					scope_k0_cell_uv<1>(key, k0, pu, pv);
 				} else {
 					scope_k0_cell<2, true>(key, k0, true, false); /* wave votes inside: every lane goes through, valid or not */
 				}
 				if (((g_b + (u32)d) & 3u) == 0) { /* content is coherent: the verdict holds for four loads */
-					const u32 flat_lanes = (u32)__popcll(__ballot(!v || key[0] == key[1]));
+					const bool same = TRIO_HASH == 2 ? ((pu[0] == scope_perm(0u, pu[0], 0x01000302u)) & (pv[0] == scope_perm(0u, pv[0], 0x01000302u)))
+									 : key[0] == key[1];
+					const u32 flat_lanes = (u32)__popcll(__ballot(!v || same));
 					absorb = flat_lanes >= 48;
 					wflat = flat_lanes >= 64;
 				}
 				TRIO_ISSUE(d); /* ONE issue point per slot, whatever the slot held: the load queue has the same shape on every path */
 				if (!v || (TRIO_EXP & 2))
 					continue;
-				if (absorb) {
+				if (TRIO_HASH == 2) {
+					if (absorb)
+						vss_absorb_pair(tab, st, lane_u, lane_v, pu[0], pv[0]);
+					else
+						vss_add_pair(tab, pu[0], pv[0]);
+				} else if (absorb) {
 					bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
 					if (!(e0 | e1)) {
 						if (st.count)
-							vss_add<0>(tab, st.colour, st.count);
+							vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, st.colour, st.count);
 						st.colour = key[0];
 						st.count = 0;
 						e0 = true;
@@ -289,12 +310,12 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 					}
 					st.count += (u32)e0 + (u32)e1;
 					if (!e0)
-						vss_add<0>(tab, key[0], 1);
+						vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, key[0], 1);
 					if (!e1)
-						vss_add<0>(tab, key[1], 1);
+						vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, key[1], 1);
 				} else {
-					vss_add<0>(tab, key[0], 1);
-					vss_add<0>(tab, key[1], 1);
+					vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, key[0], 1);
+					vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, key[1], 1);
 				}
 			}
 		}
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		}
 		const bool last_strip = s_b + 1u == nst;
 		if (last_strip)
-			vss_flush_lane<0>(tab, st); /* the lanes' pending texels, before the table is read out */
+			vss_flush_lane<TRIO_HASH>(tab, st); /* the lanes' pending texels, before the table is read out */
 		__syncthreads();
 		{
 			/* the strip's 256 x 16 waveform texels: thread -> (value, group of four columns); the reader of a counter zeroes it */
@@ -349,7 +370,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		u32 wrote = 0, k = 0;
 		for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
 			const u32 row = 255u - (g >> 4);
-			const u32 w0 = (row << 7) + (((g & 15u) << 3) ^ ((row & 15u) << 3));
+			const u32 w0 = TRIO_HASH == 2 ? row * VSS_PITCH2 + ((g & 15u) << 3) : (row << 7) + (((g & 15u) << 3) ^ ((row & 15u) << 3));
 			const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
 			if (!vss_mask) {
 				out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
@@ -411,7 +432,7 @@ struct TrioArgs {
 template <int CH, bool HIS> hipError_t trio_variant(const TrioArgs *a)
 {
 	constexpr u32 nch = (CH & 1) + ((CH >> 1) & 1) + ((CH >> 2) & 1);
-	constexpr u32 lds = VSS_WORDS * 4u + nch * TRIO_CH_BYTES;
+	constexpr u32 lds = TRIO_VSS_WORDS * 4u + nch * TRIO_CH_BYTES;
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_trio_kernel<CH, HIS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	SCOPE_LAUNCH((scope_trio_kernel<CH, HIS>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), lds, a->st, a->tm, *a->fs,

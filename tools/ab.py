@@ -4,7 +4,7 @@
 Between processes the streaming kernels land in one of two placement modes 3 % apart, which
 drowns the 1-2 % effects kernel tuning is about; here both libraries read the very same buffers, alternately.
 
-    python tools/ab.py /path/to/libA.so /path/to/libB.so [--workload vectorscope|vectorscope_rgb|histogram|histogram_yuv|waveform|waveform_yuv]
+    python tools/ab.py /path/to/libA.so /path/to/libB.so [--workload vectorscope|vectorscope_rgb|histogram|histogram_yuv|waveform|waveform_yuv|three_scope]
 (the *_rgb / *_yuv forms read RGB planes and convert in the kernel: the fused-K0 path)
 """
 import argparse
@@ -47,9 +47,13 @@ def main():
 
     wl = args.workload
     table = {"vectorscope": 65536, "vectorscope_rgb": 65536, "histogram": 4096, "histogram_yuv": 4096,
-             "waveform": 256 * W * 4, "waveform_yuv": 256 * W * 4}[wl]
+             "waveform": 256 * W * 4, "waveform_yuv": 256 * W * 4, "three_scope": 65536 + 4096 + 256 * W * 4}[wl]
     comp = 0x70 if wl.endswith("_yuv") else 0x07
     out = torch.empty((n, table), dtype=torch.uint8, device="cuda")
+    if wl == "three_scope":
+        o_vss = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
+        o_wvs = torch.empty((n, 256 * W * 4), dtype=torch.uint8, device="cuda")
+        o_his = torch.empty((n, 1024), dtype=torch.int32, device="cuda")
     for d in args.dists.split(","):
         rgb, yuv = make_frames(torch, ctxs[0], n, W, H, d, 7)
         res = [[], []]
@@ -61,6 +65,9 @@ def main():
                 elif wl == "vectorscope_rgb":
                     b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
                     fn = lambda: c.vectorscope_batch_dev(b, out, sync=False)  # noqa: E731
+                elif wl == "three_scope":
+                    b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
+                    fn = lambda: c.three_scopes_batch_dev(b, 0x07, 0x07, o_vss, o_wvs, o_his, sync=False)  # noqa: E731
                 elif wl.startswith("histogram"):
                     b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
                     fn = lambda: c.histogram_counts_batch_dev(b, comp, out, sync=False)  # noqa: E731
