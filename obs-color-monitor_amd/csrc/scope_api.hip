@@ -759,9 +759,9 @@ int scope_ctx_create(int device, scope_ctx **out)
 	}
 	ctx->tn.vss_merge = 3;
 	ctx->tn.vss_unroll = 0;       /* auto: 4 loads per lane per batch for batches, 2 for launches of a few frames */
-	ctx->tn.vss_fused_unroll = 4;
+	ctx->tn.vss_fused_unroll = 0;
 	ctx->tn.vss_hash = 0;
-	ctx->tn.vss_fused_hash = 2;
+	ctx->tn.vss_fused_hash = -1;
 	ctx->tn.vss_groups_log2 = -1; /* auto: 8 lane-group streams for batches, one stream for launches of a few frames */
 	ctx->tn.his_unroll = 0; /* auto: 1 load per lane per batch, 2 for one-frame launches */
 	ctx->tn.wvs_wide = 1;

@@ -1765,11 +1765,16 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 	u32 glog2 = tn.vss_groups_log2 < 0 ? (small ? 0u : 3u) : (u32)tn.vss_groups_log2;
 	if (glog2 > 3)
 		glog2 = 3; /* lane groups of >= 8 lanes: every request still covers a whole 128-byte line */
-	const int unroll = fuse_k0 ? tn.vss_fused_unroll : (tn.vss_unroll > 0 ? tn.vss_unroll : (small ? 2 : 4));
+	/* the fused-K0 form: four loads per lane and the pair-addressed table (HASH 2) where the frames are many and VALU issue
+	 * is the limit; a small launch is not short of issue slots, and the larger table costs it in zero-fill and flush
+	 * (one 4K frame 18.4 -> 19.3 us per call with the batch settings) */
+	const int fused_unroll = tn.vss_fused_unroll > 0 ? tn.vss_fused_unroll : (small ? 2 : 4);
+	const int fused_hash = tn.vss_fused_hash >= 0 ? tn.vss_fused_hash : (small ? 0 : 2);
+	const int unroll = fuse_k0 ? fused_unroll : (tn.vss_unroll > 0 ? tn.vss_unroll : (small ? 2 : 4));
 	if (pmask && !scope_vss_mask_block(tn))
 		return hipErrorInvalidValue;
 	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), split_regions(fs), scope_k0_matrix(colorspace), dst, pmask, st, tm};
-	return vss_pick(unroll, tn.nt_loads, tn.vss_merge, fuse_k0, fuse_k0 ? tn.vss_fused_hash : tn.vss_hash, &a);
+	return vss_pick(unroll, tn.nt_loads, tn.vss_merge, fuse_k0, fuse_k0 ? fused_hash : tn.vss_hash, &a);
 }
 
 hipError_t scope_launch_his(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int fuse_k0, int colorspace,

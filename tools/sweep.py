@@ -279,7 +279,7 @@ def main():
                     k, wall, l = timed(ctx, lambda: ctx.histogram_counts_batch_dev(batch_rgb, comp, cnt_h, sync=False))
                     report("his_inflight", k, wall, l, n, 4096, dist=d, unroll=unroll, comp=hex(comp))
         ctx.set_option("vss.unroll", 4)
-        ctx.set_option("vss.fused_unroll", 4)
+        ctx.set_option("vss.fused_unroll", 0)
         ctx.set_option("his.unroll", 1)
 
     out.close()
