@@ -64,7 +64,13 @@ def run(ctx, o, cases, seed, log=print, to_dev=None, to_host=None):
             comp = rnd.choice(pc.COMPONENTS)
             pc.check_waveform(ctx, o, w, h, dist, comp, ls, fuse=bool(comp & 0x70) and rnd.random() < 0.5, colorspace=cs)
             pc.check_histogram_counts(ctx, o, w, h, dist, comp, ls, colorspace=cs)
-            pc.check_vectorscope(ctx, o, w, h, dist, ls, fuse=rnd.random() < 0.5, colorspace=cs)
+            fuse = rnd.random() < 0.5
+            opts = {}
+            if fuse and rnd.random() < 0.7:  # the batch form of the fused kernel (pair-addressed table) on any geometry
+                opts = {"vss.fused_hash": rnd.choice([0, 2, 2]), "vss.fused_unroll": rnd.choice([1, 2, 4]),
+                        "slices": rnd.choice([0, 1, 3]), "vss.merge": rnd.choice([0, 2, 3, 3]), "vss.groups": rnd.choice([-1, 0, 2, 3])}
+            with pc.options(ctx, **opts):
+                pc.check_vectorscope(ctx, o, w, h, dist, ls, fuse=fuse, colorspace=cs)
         except Exception as e:  # noqa: BLE001
             log("FAIL " + tag + " -- " + repr(e)[:300])
             raise
