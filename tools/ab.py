@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dists", default="uniform,natural,screen")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--frames", type=int, default=32, help="frames per launch (bench.py's default is 64)")
+    ap.add_argument("--comp", type=lambda x: int(x, 0), default=None, help="component mask of the waveform / histogram workloads (default 0x07, 0x70 for *_yuv)")
     ap.add_argument("--opt-a", action="append", default=[], help="key=value for the first library's context")
     ap.add_argument("--opt-b", action="append", default=[], help="key=value for the second (the same .so twice compares options)")
     args = ap.parse_args()
@@ -48,7 +49,7 @@ def main():
     wl = args.workload
     table = {"vectorscope": 65536, "vectorscope_rgb": 65536, "histogram": 4096, "histogram_yuv": 4096,
              "waveform": 256 * W * 4, "waveform_yuv": 256 * W * 4, "three_scope": 65536 + 4096 + 256 * W * 4}[wl]
-    comp = 0x70 if wl.endswith("_yuv") else 0x07
+    comp = args.comp if args.comp is not None else (0x70 if wl.endswith("_yuv") else 0x07)
     out = torch.empty((n, table), dtype=torch.uint8, device="cuda")
     if wl == "three_scope":
         o_vss = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
