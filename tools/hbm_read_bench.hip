@@ -364,6 +364,91 @@ static int small_main()
 	return 0;
 }
 
+// "mix": what does the memory system deliver when a stream of reads carries a share of writes?  The waveform moves 33.2 MB
+// of frame in and 3.9 MB of table out per 4K frame (10.6 % of its bytes are writes); this is the bare form of that mix:
+// every workgroup streams its contiguous share with 16-byte nt loads, four per lane in flight, and after every K-th batch
+// stores one batch worth of 16-byte nt words (the running XOR: real data) to a contiguous share of a second buffer.
+// SPREAD: one store per lane after every `every / U` batches instead of U stores after every `every` batches (same share).
+template <int U, bool SPREAD> __global__ __launch_bounds__(1024) void mix_kernel(const v4 *src, uint64_t n16, v4 *dst, uint32_t every)
+{
+	const uint32_t spread_every = every / U ? every / U : 1;
+	const uint64_t per = (n16 + gridDim.x - 1) / gridDim.x;
+	const uint64_t b0 = (uint64_t)blockIdx.x * per, b1 = (b0 + per < n16) ? b0 + per : n16;
+	v4 acc = {0, 0, 0, 0};
+	uint64_t i = b0 + threadIdx.x, o = b0 / (every ? every : 1) + threadIdx.x;
+	uint32_t phase = 0;
+	for (; i + (uint64_t)(U - 1) * blockDim.x < b1; i += (uint64_t)U * blockDim.x) {
+		v4 t[U];
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			t[k] = __builtin_nontemporal_load(src + i + (uint64_t)k * blockDim.x);
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			acc ^= t[k];
+		if (every && ++phase == (SPREAD ? spread_every : every)) { /* uniform */
+			phase = 0;
+#pragma unroll
+			for (int k = 0; k < (SPREAD ? 1 : U); k++) {
+				acc[0] += k;
+				__builtin_nontemporal_store(acc, dst + o + (uint64_t)k * blockDim.x);
+			}
+			o += (uint64_t)(SPREAD ? 1 : U) * blockDim.x;
+		}
+	}
+	if (!every && (acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u)
+		dst[0] = acc;
+}
+
+static int mix_main()
+{
+	const uint64_t bytes = 64ull * 3840 * 2160 * 4;
+	const uint64_t n16 = bytes / 16;
+	uint32_t *buf;
+	v4 *dst;
+	if (hipMalloc((void **)&buf, bytes) != hipSuccess || hipMalloc((void **)&dst, bytes + (1u << 20)) != hipSuccess) {
+		fprintf(stderr, "hipMalloc failed\n");
+		return 1;
+	}
+	hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf, bytes / 4);
+	hipDeviceSynchronize();
+	for (int i = 0; i < 100; i++)
+		hipLaunchKernelGGL((mix_kernel<4, false>), dim3(256), dim3(1024), 0, 0, (const v4 *)buf, n16, dst, 0u);
+	hipDeviceSynchronize();
+	printf("# 64 x 4K frames (%llu bytes) read per launch, 256 workgroups x 1024 threads, four 16-byte nt loads per lane in flight;\n"
+	       "# after every K-th batch one batch of 16-byte nt stores.  GB/s over 30 back-to-back launches (HIP events).\n",
+	       (unsigned long long)bytes);
+	printf("# %8s %10s %12s %12s %12s\n", "K", "writes", "ms", "read GB/s", "total GB/s");
+	const uint32_t ks[] = {0, 64, 32, 16, 9, 8, 4, 2, 1};
+	for (int rep = 0; rep < 3; rep++)
+		for (uint32_t k : ks) {
+			const bool spread = rep == 2;
+			if (spread && (k % 4 || !k))
+				continue;
+			hipEvent_t e0, e1;
+			hipEventCreate(&e0);
+			hipEventCreate(&e1);
+			hipEventRecord(e0, 0);
+			for (int i = 0; i < 30; i++)
+				if (spread)
+					hipLaunchKernelGGL((mix_kernel<4, true>), dim3(256), dim3(1024), 0, 0, (const v4 *)buf, n16, dst, k);
+				else
+					hipLaunchKernelGGL((mix_kernel<4, false>), dim3(256), dim3(1024), 0, 0, (const v4 *)buf, n16, dst, k);
+			hipEventRecord(e1, 0);
+			hipEventSynchronize(e1);
+			float ms;
+			hipEventElapsedTime(&ms, e0, e1);
+			ms /= 30;
+			const double w = k ? (double)bytes / k : 0.0;
+			printf("  %8u %9.1f%% %12.4f %12.1f %12.1f%s\n", k, 100.0 * w / (bytes + w), ms, bytes / (ms * 1e-3) / 1e9,
+			       (bytes + w) / (ms * 1e-3) / 1e9, spread ? "  (one store per lane every K/4 batches)" : "");
+			hipEventDestroy(e0);
+			hipEventDestroy(e1);
+		}
+	hipFree(buf);
+	hipFree(dst);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc > 1 && !strcmp(argv[1], "placement"))
@@ -372,6 +457,8 @@ int main(int argc, char **argv)
 		return placement2_main();
 	if (argc > 1 && !strcmp(argv[1], "small"))
 		return small_main();
+	if (argc > 1 && !strcmp(argv[1], "mix"))
+		return mix_main();
 	const uint64_t bytes = 32ull * 3840 * 2160 * 4;
 	const uint64_t n16 = bytes / 16;
 	uint32_t *buf, *sink;
