@@ -329,9 +329,30 @@ struct VssLane {
 	u32 count;
 };
 
+#ifndef VSS_ABSORB_WHOLE
+#define VSS_ABSORB_WHOLE 1 /* 0: the first form -- matching pixels of a mixed cell counted, the others sent one by one (A/B) */
+#endif
 template <int HASH> __device__ __forceinline__ void vss_absorb4(u32 *tab, VssLane &st, u32 k0, u32 k1, u32 k2, u32 k3)
 {
 	bool e0 = k0 == st.colour, e1 = k1 == st.colour, e2 = k2 == st.colour, e3 = k3 == st.colour;
+	if (VSS_ABSORB_WHOLE) {
+		/* whole cells only (see vss_absorb_pairs): the lane's colour throughout -> the register; one other colour
+		 * throughout -> that becomes the lane's colour; anything else -> the table, as it is */
+		if (e0 & e1 & e2 & e3) {
+			st.count += 4;
+		} else if ((k0 == k1) & (k1 == k2) & (k2 == k3)) {
+			if (st.count)
+				vss_add<HASH>(tab, st.colour, st.count);
+			st.colour = k0;
+			st.count = 4;
+		} else {
+			vss_add<HASH>(tab, k0, 1);
+			vss_add<HASH>(tab, k1, 1);
+			vss_add<HASH>(tab, k2, 1);
+			vss_add<HASH>(tab, k3, 1);
+		}
+		return;
+	}
 	if (!(e0 | e1 | e2 | e3)) { /* none of the four is the lane's colour: it changed (rare; divergent) */
 		if (st.count)
 			vss_add<HASH>(tab, st.colour, st.count); /* hand in the old one ... */
@@ -356,44 +377,33 @@ template <int HASH> __device__ __forceinline__ void vss_absorb4(u32 *tab, VssLan
 }
 
 /* The same in pair form (HASH 2): lane_u / lane_v are the lane's colour as U | U << 16, V | V << 16 (0xffffffff while it
- * has none: no pair looks like that), x = 0 in the half whose pixel has that colour.  A cell of the lane's colour
- * throughout -- nearly all of them, in this mode -- costs five instructions. */
+ * has none: no pair looks like that), x = 0 in the half whose pixel has that colour.  Whole cells only: a cell of the
+ * lane's colour throughout -- nearly all of them, in this mode -- is counted in the register (six instructions); a cell of
+ * ONE other colour makes that the lane's colour (the old count goes to the table); any other cell goes to the table as it
+ * is, pair by pair.  (The first form counted the matching pixels of a mixed cell and sent only the others to the table, as
+ * vss_absorb4 does: on screen content -- flat areas with a few per cent of single-pixel detail, where every cell of a wave
+ * runs the fast and the slow path -- that cost 28.3 VALU instructions per pixel against 26.2 with keys.) */
 __device__ __forceinline__ void vss_absorb_pairs(u32 *tab, VssLane &st, u32 &lane_u, u32 &lane_v, u32 pu0, u32 pv0, u32 pu1, u32 pv1)
 {
-	u32 x0 = scope_bitop3<0xf6>(pu0 ^ lane_u, pv0, lane_v); /* (pu ^ lane_u) | (pv ^ lane_v) */
-	u32 x1 = scope_bitop3<0xf6>(pu1 ^ lane_u, pv1, lane_v);
+	const u32 x0 = scope_bitop3<0xf6>(pu0 ^ lane_u, pv0, lane_v); /* (pu ^ lane_u) | (pv ^ lane_v) */
+	const u32 x1 = scope_bitop3<0xf6>(pu1 ^ lane_u, pv1, lane_v);
 	if ((x0 | x1) == 0u) {
 		st.count += 4;
 		return;
 	}
-	bool e0 = (x0 & 0xffffu) == 0u, e1 = (x0 >> 16) == 0u, e2 = (x1 & 0xffffu) == 0u, e3 = (x1 >> 16) == 0u;
-	if (!(e0 | e1 | e2 | e3)) { /* the colour changed: hand in the old one, start counting the first pixel's */
+	/* one colour throughout?  Then the four differences are equal (necessary; the exact test only where that holds) */
+	if (x0 == x1 && x0 == scope_perm(0u, x0, 0x01000302u) && pu0 == pu1 && pv0 == pv1 && pu0 == scope_perm(0u, pu0, 0x01000302u) &&
+	    pv0 == scope_perm(0u, pv0, 0x01000302u)) {
 		if (st.count)
 			vss_add<2>(tab, st.colour, st.count);
 		st.colour = vss_pair_key(pu0, pv0, 0);
-		st.count = 0;
-		lane_u = scope_perm(0u, pu0, 0x0c000c00u);
-		lane_v = scope_perm(0u, pv0, 0x0c000c00u);
-		x0 = scope_bitop3<0xf6>(pu0 ^ lane_u, pv0, lane_v);
-		x1 = scope_bitop3<0xf6>(pu1 ^ lane_u, pv1, lane_v);
-		e0 = true;
-		e1 = (x0 >> 16) == 0u;
-		e2 = (x1 & 0xffffu) == 0u;
-		e3 = (x1 >> 16) == 0u;
+		st.count = 4;
+		lane_u = pu0;
+		lane_v = pv0;
+		return;
 	}
-	st.count += (u32)e0 + (u32)e1 + (u32)e2 + (u32)e3;
-	if (!(e0 & e1 & e2 & e3)) {
-		const u32 w0 = scope_pk_mad_u16(pv0, VSS_PITCH2 | (VSS_PITCH2 << 16), scope_pk_lshr_u16(pu0, 1)), q0 = pu0 << 4;
-		const u32 w1 = scope_pk_mad_u16(pv1, VSS_PITCH2 | (VSS_PITCH2 << 16), scope_pk_lshr_u16(pu1, 1)), q1 = pu1 << 4;
-		if (!e0)
-			scope_lds_add_at(tab, scope_shl_word0(2u, w0), scope_shl_by_byte0(q0, 1u));
-		if (!e1)
-			scope_lds_add_at(tab, scope_shl_word1(2u, w0), scope_shl_by_byte2(q0, 1u));
-		if (!e2)
-			scope_lds_add_at(tab, scope_shl_word0(2u, w1), scope_shl_by_byte0(q1, 1u));
-		if (!e3)
-			scope_lds_add_at(tab, scope_shl_word1(2u, w1), scope_shl_by_byte2(q1, 1u));
-	}
+	vss_add_pair(tab, pu0, pv0);
+	vss_add_pair(tab, pu1, pv1);
 }
 
 /* one pair (scope_trio_kernel's slot) */
