@@ -118,7 +118,7 @@ int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
  *   "vss.merge" 0|2|3        plain adds | absorb mode always | absorb mode by wave vote
  *   "vss.unroll" 0|1|2|4, "vss.fused_unroll" 0|1|2|4, "his.unroll" 0|1|2|4   16-byte loads per lane per batch (0: by launch size)
  *   "vss.fused_hash" -1|0|1|2   the fused-K0 vectorscope's LDS table: as "vss.hash" (0, 1) or rows of 136 words with the LDS
- *                              operands of two pixels worked out in one register (2); -1: 2 in batches, 0 in small launches
+ *                              operands of two pixels worked out in one register (2); -1: the default, 2
  *   "vss.hash" 0|1, "vss.groups" -1|0..3   table rows XOR-swizzled across the LDS banks (0) or not (1); log2 of lane groups per
  *                wave (-1: 8 groups for batches, 1 for launches of a few frames)
  *   "vss.block" / "his.block" 0|64..1024   threads per workgroup (0 = 1024)

@@ -52,7 +52,7 @@ struct ScopeTuning {
 	int vss_unroll;      /* 16-byte loads per lane per batch (two batches in flight): 1, 2 or 4; 0 = by launch size */
 	int vss_fused_unroll; /* the same for the fused-K0 form; 0 = by launch size (4 in batches, 2 in small launches) */
 	int vss_hash;        /* bin -> LDS word placement, see scope_kernels.hip */
-	int vss_fused_hash;  /* the same for the fused-K0 form: 2 = rows of 136 words, two pixels' addresses per register; -1 = by launch size */
+	int vss_fused_hash;  /* the same for the fused-K0 form: 2 = rows of 136 words, two pixels' addresses per register; -1 = the default (2) */
 	int vss_groups_log2; /* lane groups per wave walking separate image regions: 0..3; -1 = by launch size */
 	int his_unroll;      /* 1, 2 or 4; 0 = by launch size.  More bytes in flight than ~32 KiB per CU LOWER the achieved bandwidth of a batch */
 	int vss_block, his_block; /* threads per workgroup (0 = SCOPE_BLOCK) */

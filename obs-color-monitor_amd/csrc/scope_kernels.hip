@@ -1765,11 +1765,12 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 	u32 glog2 = tn.vss_groups_log2 < 0 ? (small ? 0u : 3u) : (u32)tn.vss_groups_log2;
 	if (glog2 > 3)
 		glog2 = 3; /* lane groups of >= 8 lanes: every request still covers a whole 128-byte line */
-	/* the fused-K0 form: four loads per lane and the pair-addressed table (HASH 2) where the frames are many and VALU issue
-	 * is the limit; a small launch is not short of issue slots, and the larger table costs it in zero-fill and flush
-	 * (one 4K frame 18.4 -> 19.3 us per call with the batch settings) */
+	/* the fused-K0 form: the pair-addressed table (HASH 2) everywhere, four loads per lane where the frames are many; small
+	 * launches keep two (bench.py --frames 1 / 3 --workload vectorscope_rgb, us per call on distinct HBM-resident frames,
+	 * visit s3: table as the plain kernel's + two loads 18.5 / 30.0, pair table + two loads 18.2 / 29.3, pair table +
+	 * four loads 19.4 / 30.8) */
 	const int fused_unroll = tn.vss_fused_unroll > 0 ? tn.vss_fused_unroll : (small ? 2 : 4);
-	const int fused_hash = tn.vss_fused_hash >= 0 ? tn.vss_fused_hash : (small ? 0 : 2);
+	const int fused_hash = tn.vss_fused_hash >= 0 ? tn.vss_fused_hash : 2;
 	const int unroll = fuse_k0 ? fused_unroll : (tn.vss_unroll > 0 ? tn.vss_unroll : (small ? 2 : 4));
 	if (pmask && !scope_vss_mask_block(tn))
 		return hipErrorInvalidValue;
