@@ -449,6 +449,74 @@ static int mix_main()
 	return 0;
 }
 
+// "vmm": does memory mapped through the virtual-memory API (hipMemCreate in chunks of the allocation granularity, one
+// contiguous virtual range) read at another rate than what hipMalloc hands out?  Six buffers of 64 x 4K frames each way,
+// alternately, each read by the persistent two-batch stream (the scope kernels' shape).
+static int vmm_main()
+{
+	setvbuf(stdout, NULL, _IONBF, 0);
+	const uint64_t bytes = 64ull * 3840 * 2160 * 4;
+	const uint64_t n16 = bytes / 16;
+	uint32_t *sink;
+	hipMalloc((void **)&sink, 64);
+	hipMemAllocationProp prop = {};
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = 0;
+	size_t gran = 0, gran_rec = 0;
+	hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+	hipMemGetAllocationGranularity(&gran_rec, &prop, hipMemAllocationGranularityRecommended);
+	printf("# allocation granularity: minimum %zu, recommended %zu bytes\n", gran, gran_rec);
+	hipMemAccessDesc acc = {};
+	acc.location = prop.location;
+	acc.flags = hipMemAccessFlagsProtReadWrite;
+	for (int round = 0; round < 3; round++) {
+		uint32_t *m;
+		if (hipMalloc((void **)&m, bytes) != hipSuccess) {
+			fprintf(stderr, "hipMalloc failed\n");
+			return 1;
+		}
+		hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, m, bytes / 4);
+		hipDeviceSynchronize();
+		const float t_malloc = placement_read(m, n16, sink);
+		for (int chunked = 0; chunked < 1; chunked++) { /* (granularity is 4 KiB here: mapping half a million chunks takes minutes) */
+			const size_t chunk = chunked ? (gran_rec ? gran_rec : gran) : ((bytes + gran - 1) / gran) * gran;
+			const size_t total = ((bytes + chunk - 1) / chunk) * chunk;
+			void *va = NULL;
+			printf("  reserving %zu bytes, %zu chunk(s) of %zu ...\n", total, total / chunk, chunk);
+			if (hipMemAddressReserve(&va, total, 0, NULL, 0) != hipSuccess) {
+				fprintf(stderr, "hipMemAddressReserve failed\n");
+				return 1;
+			}
+			const size_t nchunks = total / chunk;
+			hipMemGenericAllocationHandle_t *h = (hipMemGenericAllocationHandle_t *)calloc(nchunks, sizeof(*h));
+			bool ok = true;
+			for (size_t i = 0; i < nchunks && ok; i++)
+				ok = hipMemCreate(&h[i], chunk, &prop, 0) == hipSuccess && hipMemMap((char *)va + i * chunk, chunk, 0, h[i], 0) == hipSuccess;
+			printf("  mapped: %d\n", (int)ok);
+			ok = ok && hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+			printf("  access set: %d\n", (int)ok);
+			if (!ok) {
+				fprintf(stderr, "virtual-memory API failed (%s)\n", hipGetErrorString(hipGetLastError()));
+				return 1;
+			}
+			hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (uint32_t *)va, bytes / 4);
+			hipDeviceSynchronize();
+			const float t = placement_read((const uint32_t *)va, n16, sink);
+			printf("round %d  hipMalloc at %p %7.1f GB/s   hipMemCreate x %zu chunk(s) of %zu MiB at %p %7.1f GB/s\n", round, (void *)m,
+			       bytes / (t_malloc * 1e-3) / 1e9, nchunks, chunk >> 20, va, bytes / (t * 1e-3) / 1e9);
+			hipMemUnmap(va, total);
+			for (size_t i = 0; i < nchunks; i++)
+				hipMemRelease(h[i]);
+			hipMemAddressFree(va, total);
+			free(h);
+		}
+		if (round & 1)
+			hipFree(m); /* every other hipMalloc buffer stays: later rounds see a fuller device */
+	}
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc > 1 && !strcmp(argv[1], "placement"))
@@ -459,6 +527,8 @@ int main(int argc, char **argv)
 		return small_main();
 	if (argc > 1 && !strcmp(argv[1], "mix"))
 		return mix_main();
+	if (argc > 1 && !strcmp(argv[1], "vmm"))
+		return vmm_main();
 	const uint64_t bytes = 32ull * 3840 * 2160 * 4;
 	const uint64_t n16 = bytes / 16;
 	uint32_t *buf, *sink;
