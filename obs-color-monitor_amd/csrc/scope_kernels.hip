@@ -1605,6 +1605,10 @@ template <int CH, bool HIS> hipError_t wvs_pick_shape(int fuse, int wide, const 
 {
 	if (wide == 3 && !fuse) /* the fused-K0 forms are short of VALU issue slots, not of loads: they lose 3 % with it */
 		return wvs_variant<CH, false, true, HIS, 64, true>(a);
+	if (wide == 3 && CH == 2) /* ... except the one-row form (luma, BASELINE config 3's Y mode): +2.3 ... 2.7 %, visit d1 */
+		return wvs_variant<CH == 2 ? CH : 2, true, true, HIS, 64, true>(a);
+	if (wide == 3)
+		wide = 1;
 	if (wide == 2)
 		return fuse ? wvs_variant<CH, true, true, HIS, WVS_NARROW, false>(a)
 			    : wvs_variant<CH, false, true, HIS, WVS_NARROW, false>(a);
@@ -1835,7 +1839,7 @@ hipError_t scope_launch_wvs(const ScopeFrameSet &fs, uint32_t bands, uint32_t ch
 		grid = min(resident, (((total + rounds - 1u) / rounds) + 15u) & ~15u);
 	}
 	/* the deep queue across flushes: batches only -- every unit the same, with enough slots, several units per workgroup */
-	if (wide == 1 && !fuse_k0 && tn.wvs_deep && bands == 1 && total > grid) {
+	if (wide == 1 && (!fuse_k0 || chmask == 2u) && tn.wvs_deep && bands == 1 && total > grid) {
 		const u32 nbatch = ((fs.height >> 1) + WVS_U - 1) / WVS_U, nwaves = SCOPE_BLOCK / 64;
 		const u32 slots = max(2u, ((nbatch + nwaves - 1) / nwaves + 1u) & ~1u);
 		if (slots >= (u32)WVS_DEEP_SETS + 2u)

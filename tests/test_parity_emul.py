@@ -151,8 +151,11 @@ def test_waveform_deep_queue_across_flushes(emul_ctx, oracle):
     pc.check_waveform(emul_ctx, oracle, 512, 265, 5, 0x07)  # 8 units on 6 workgroups, an odd last row
     pc.check_waveform(emul_ctx, oracle, 448, 300, 1, 0x20, 448 * 4 + 64)  # 7 units: one workgroup walks two
     pc.check_waveform_histogram(emul_ctx, oracle, 512, 264, 2)
+    for cs in (1, 2):  # the fused one-row (luma) form takes the deep queue as well
+        pc.check_waveform(emul_ctx, oracle, 512, 265, 1, 0x20, None, fuse=True, colorspace=cs)
     with pc.options(emul_ctx, **{"wvs.deep": 0}):
         pc.check_waveform(emul_ctx, oracle, 512, 265, 5, 0x07)
+        pc.check_waveform(emul_ctx, oracle, 512, 265, 1, 0x20, None, fuse=True, colorspace=2)
 
 
 @pytest.mark.parametrize("dock", [1, 2, 0])

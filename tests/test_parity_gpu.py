@@ -357,6 +357,14 @@ def test_waveform_load_shapes(hip_ctx, oracle, wide):
         pc.check_waveform(hip_ctx, oracle, 1, 3, 1, 0x07)
 
 
+def test_waveform_deep_queue_batches(hip_ctx, oracle):
+    """32 frames of 640x360 = 320 units on 256 persistent workgroups, six slots per wave: the deep queue across flushes, for
+    the plain RGB form and for the fused one-row (luma) form; the same with it switched off."""
+    pc.check_batches(hip_ctx, oracle, 640, 360, 32)
+    with pc.options(hip_ctx, **{"wvs.deep": 0}):
+        pc.check_batches(hip_ctx, oracle, 640, 360, 32)
+
+
 @pytest.mark.parametrize("cs", [1, 2])
 def test_fused_k0(hip_ctx, oracle, cs):
     pc.check_vectorscope(hip_ctx, oracle, 640, 360, 1, None, fuse=True, colorspace=cs)
