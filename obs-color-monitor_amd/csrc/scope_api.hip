@@ -623,17 +623,24 @@ int zero_result(scope_ctx *ctx, void *out, size_t bytes, uint32_t flags)
 	return SCOPE_OK;
 }
 
-#define SCOPE_ENTER(ctx)                                                      \
+/* Every entry point but one fences the side stream first (include/scope_hip.h, SCOPE_SIDE_REDUCE: "the next call on the
+ * context without this flag fences first"): whatever it enqueues on the context's stream -- another scope, a table
+ * pack / all-reduce, a display pass, a download -- then sees the tables of earlier SCOPE_SIDE_REDUCE calls complete.
+ * Only scope_vectorscope_batch carrying the flag itself enters without the fence (SCOPE_ENTER_FLAGS). */
+#define SCOPE_ENTER_FLAGS(ctx, flags)                                         \
 	if (!(ctx))                                                           \
 		return SCOPE_EINVAL;                                          \
 	std::lock_guard<std::recursive_mutex> scope_lock_((ctx)->mu);         \
-	int st = enter(ctx)
+	int st = enter(ctx, flags)
+#define SCOPE_ENTER(ctx) SCOPE_ENTER_FLAGS(ctx, 0u)
 
-int enter(scope_ctx *ctx)
+int enter(scope_ctx *ctx, uint32_t flags = 0u)
 {
 	if (!ctx)
 		return SCOPE_EINVAL;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (!(flags & SCOPE_SIDE_REDUCE))
+		return side_fence(ctx);
 	return SCOPE_OK;
 }
 
@@ -1089,7 +1096,7 @@ int scope_vectorscope(scope_ctx *ctx, const struct scope_surface_data *sd, uint3
 
 int scope_vectorscope_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t flags, uint8_t *out)
 {
-	SCOPE_ENTER(ctx);
+	SCOPE_ENTER_FLAGS(ctx, flags);
 	if (st)
 		return st;
 	if (!b || !out || !b->planes || b->n_frames == 0)
@@ -1453,6 +1460,7 @@ int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, 
 		const hipError_t e = hipMalloc(&cand[n], (size_t)bytes);
 		if (e != hipSuccess) {
 			cand[n] = NULL;
+			(void)hipGetLastError(); /* the launchers end with hipGetLastError(): a stale out-of-memory must not fail the next one */
 			if (n == 0)
 				rc = fail(ctx, SCOPE_ENOMEM, "hipMalloc (frame pool)", e);
 			break; /* fewer candidates than asked for: the best of those there are */
@@ -2048,19 +2056,21 @@ int scope_rccl_comm_destroy(void *comm)
 
 int scope_rccl_comm_info(void *rccl_comm, int *n_ranks, int *rank, int *version)
 {
-	const rccl_api *r = rccl();
-	if (!r)
-		return SCOPE_ENODEV;
 	if (n_ranks)
 		*n_ranks = -1;
 	if (rank)
 		*rank = -1;
 	if (version)
 		*version = -1;
+	if (!rccl_comm && (n_ranks || rank))
+		return SCOPE_EINVAL; /* before anything is filled in */
+	const rccl_api *r = rccl();
+	if (!r)
+		return SCOPE_ENODEV;
 	if (version && r->get_version && r->get_version(version) != 0)
 		return SCOPE_EIO;
 	if (!rccl_comm)
-		return (n_ranks || rank) ? SCOPE_EINVAL : SCOPE_OK;
+		return SCOPE_OK;
 	if (n_ranks && r->comm_count && r->comm_count(rccl_comm, n_ranks) != 0)
 		return SCOPE_EIO;
 	if (rank && r->comm_user_rank && r->comm_user_rank(rccl_comm, rank) != 0)

@@ -155,7 +155,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	bool live_i = false;
 	const u32 lim = row0 < H ? min(rps, H - row0) : 0u; /* rows of this lane's range that exist */
 	const u32 nv = lim > wave ? (lim - wave + nwaves - 1u) / nwaves : 0u;
-	const scope_buf buf = scope_buf_make(plane, H * fs.linesize);
+	/* the resource ends with the last row's last texel, not with its pitch padding: the API does not ask for the padding
+	 * behind the last row to be allocated, and lanes of a ragged last strip (x0 >= W) must not touch it */
+	const u32 plane_bytes = (H - 1u) * fs.linesize + W * 4u;
+	const scope_buf buf = scope_buf_make(plane, plane_bytes);
 	(void)buf;
 	(void)nv;
 	(void)live_i;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		live_i = s < nst && x0 < W; /* W % 4 == 0: both texels of the pair or none */
 		off_i = (row0 + wave) * fs.linesize + x0 * 4u;
 		if (TRIO_BUF && s >= nst)
-			off_i = H * fs.linesize; /* past the last strip: every load out of range */
+			off_i = plane_bytes; /* past the last strip: every load out of range */
 	};
 	strip_start(0);
 #if TRIO_BUF

@@ -39,6 +39,18 @@ const float *scope_host_his_table(void *data, uint32_t *hi_max)
 	return (const float *)src->tex_buf[r];
 }
 
+/* The level settings his_update left behind (src/histogram.c:131-156): what the next K3b pass and the graticule use. */
+void scope_host_his_levels(void *data, int *level_fixed_value, int *level_ratio_value, float *graticule_horizontal_step)
+{
+	const struct his_source *src = data;
+	if (level_fixed_value)
+		*level_fixed_value = src->level_fixed_value;
+	if (level_ratio_value)
+		*level_ratio_value = src->level_ratio_value;
+	if (graticule_horizontal_step)
+		*graticule_horizontal_step = src->graticule_horizontal_step;
+}
+
 uint64_t scope_host_frames_processed(void *source)
 {
 	return scope_host_cm(source)->frames_processed;

@@ -458,17 +458,21 @@ static void his_update(void *data, obs_data_t *settings)
 	 * reference's, so a settings blob saved by the real plugin reads the same here: the ratio is a double PERCENTAGE kept in
 	 * tenths ((int)(v * 10 + 0.5), :146-147), the graticule steps are doubles (:140-141, :149-150). */
 	const int level_mode = (int)obs_data_get_int(settings, "level_mode");
-	src->level_fixed_value = 0;
-	src->level_ratio_value = 0;
-	src->graticule_horizontal_step = 0.0f;
-	if (level_mode == 1) {
+	if (level_mode == 0) {
+		/* the two level values only: the step of the mode before stays (:132-135) */
+		src->level_ratio_value = 0;
+		src->level_fixed_value = 0;
+	} else if (level_mode == 1) {
 		src->level_fixed_value = (int)obs_data_get_int(settings, "level_fixed_value");
 		src->graticule_horizontal_step = (float)obs_data_get_double(settings, "graticule_horizontal_step_fixed");
+		src->level_ratio_value = 0;
 	} else if (level_mode == 2) {
 		src->level_ratio_value = (int)(obs_data_get_double(settings, "level_ratio_value") * 10.0 + 0.5);
 		src->graticule_horizontal_step = (float)obs_data_get_double(settings, "graticule_horizontal_step_ratio");
-	} else if (level_mode != 0) {
-		blog(LOG_ERROR, "histogram: Invalid level_mode %d", level_mode); /* :153-155 */
+		src->level_fixed_value = 0;
+	} else {
+		/* a bad blob changes nothing and is only reported (:153-155) */
+		blog(LOG_ERROR, "histogram: Invalid level_mode %d", level_mode);
 	}
 	src->display = (int)obs_data_get_int(settings, "display");
 	src->level_height = (int)obs_data_get_int(settings, "level_height"); /* src/histogram.c:123 */

@@ -168,6 +168,38 @@ def check_source_surface(host):
     assert seen == []
 
 
+def check_histogram_level_modes(host):
+    """his_update's level_mode switch as the reference writes it (src/histogram.c:131-156): mode 0 zeroes the two level values and
+    leaves the graticule step of the mode before; 1 / 2 set their own value and step and zero the other value; a bad mode only logs."""
+    L = host.L
+    L.scope_host_his_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+
+    def levels(obj):
+        f, r, s = C.c_int(), C.c_int(), C.c_float()
+        L.scope_host_his_levels(obj, C.byref(f), C.byref(r), C.byref(s))
+        return f.value, r.value, s.value
+
+    def update(info, obj, **settings):
+        d = L.fake_obs_data_create()
+        info.get_defaults(d)
+        for k, v in settings.items():
+            (L.fake_obs_data_set_double if isinstance(v, float) else L.fake_obs_data_set_int)(d, k.encode(), v)
+        info.update(obj, d)
+        L.fake_obs_data_release(d)
+
+    info, his = host.create("histogram_source", level_mode=1, level_fixed_value=777, graticule_horizontal_step_fixed=50.0)
+    assert levels(his) == (777, 0, 50.0)
+    update(info, his, level_mode=0)
+    assert levels(his) == (0, 0, 50.0)  # the step stays
+    update(info, his, level_mode=2, level_ratio_value=12.5, graticule_horizontal_step_ratio=2.5)
+    assert levels(his) == (0, 125, 2.5)
+    update(info, his, level_mode=9, level_fixed_value=5, level_ratio_value=1.0)
+    assert levels(his) == (0, 125, 2.5)  # an invalid blob changes nothing
+    update(info, his, level_mode=1, level_fixed_value=31, graticule_horizontal_step_fixed=4.0)
+    assert levels(his) == (31, 0, 4.0)
+    info.destroy(his)
+
+
 def check_profile_zones(host, expect_at_least):
     """The GPU calls sit in the reference's profiler zones (ENABLE_PROFILE builds): every start has its end."""
     L = host.L
@@ -186,6 +218,7 @@ def run_host_checks(host, oracle, w=96, h=40):
         assert host.L.fake_obs_find_source(i).contents.id == i
     assert host.L.fake_obs_find_source(b"vectorscope_source").contents.version == 2
     check_source_surface(host)
+    check_histogram_level_modes(host)
 
     frames = []
     for k, dist in enumerate((1, 2, 5)):

@@ -541,6 +541,24 @@ def check_vectorscope_side_reduce(ctx, oracle, to_dev, to_host, w, h, dists, cal
     ctx.vectorscope_batch_dev(batches[0], extra[2][1], sync=True)
     for k, which in enumerate((0, -1, 0)):
         assert_same(to_host(extra[k][0]).reshape(256, 256), oracle.vectorscope(pairs[which][1], w), f"side reduce then plain, table {k}")
+    # every OTHER entry point fences as well (include/scope_hip.h: "the next call on the context without this flag"): a flagged
+    # call into a packed table with the table's unpack enqueued right behind it, and -- for RGB planes -- the one-read
+    # three-scope call of the same frame into the same vectorscope table behind a flagged call
+    for rep in range(4):
+        hp, ap = to_dev(np.full(32768 * 4, 0xEE, np.uint8))
+        ho, ao = to_dev(np.full(65536, 0xEE, np.uint8))
+        ctx.vectorscope_batch_dev(batches[rep % len(batches)], ap, sync=False, packed16=True, side_reduce=True)
+        ctx.unpack16_clamp_dev(ap, ao, 32768)
+        ctx.sync()
+        assert_same(to_host(ho).reshape(256, 256), oracle.vectorscope(pairs[rep % len(pairs)][1], w), f"side reduce then unpack, rep {rep}")
+    if fuse:
+        hv, av = to_dev(np.full(65536, 0xEE, np.uint8))
+        hw, aw = to_dev(np.full(256 * w * 4, 0xEE, np.uint8))
+        hh, ah = to_dev(np.full(4096, 0xEE, np.uint8))
+        ctx.vectorscope_batch_dev(batches[0], av, sync=False, side_reduce=True)
+        ctx.three_scopes_batch_dev(batches[-1], 0x07, 0x07, av, aw, ah)
+        assert_same(to_host(hv).reshape(256, 256), oracle.vectorscope(pairs[-1][1], w), "side reduce then three scopes: vectorscope")
+        assert_same(to_host(hw).reshape(256, w, 4), oracle.waveform(pairs[-1][0], pairs[-1][1], w, 0x07), "side reduce then three scopes: waveform")
 
 
 def check_pipeline_without_histogram(ctx, oracle, w, h, depth=2):
