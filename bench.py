@@ -18,9 +18,12 @@ vss_draw_vectorscope reads.  Every step goes through the C-ABI of libscope_hip.s
 
 The timed region is EXACTLY K steps between barrier + synchronize (-> `value`).  Because K steps of 0.3 ms are over
 before a clock or a utilisation sampler notices, the same steps then run on for at least `--min-seconds` (1 s) more
-(-> `sustained`).  The accumulation kernel's average duration (-> `roofline`) comes from a third leg of the same steps
-in which every launch carries its own begin/end HIP events on its stream (hipExtLaunchKernelGGL: the figure rocprofv3
---kernel-trace --stats reports for the same command).
+(-> `sustained`).  The accumulation kernel's average duration (-> `roofline.avg_launch_ms`, `frac_kernel`) comes from a third
+leg of the same steps in which every launch carries its own begin/end HIP events on its stream (hipExtLaunchKernelGGL: the
+figure rocprofv3 --kernel-trace --stats reports for the same command).  `roofline.frac` itself is the WHOLE STEP's, from the K
+timed steps, on the frame pool as this process first allocated it; the same launch on a pool the library placed
+(scope_frame_pool_alloc) is a leg of its own (`config.frame_pool_placement`, `roofline.frac_placed` / `frac_kernel_placed`).
+Every leg's headline number is repeated as a flat scalar at the top level and inside `roofline` (flat_summary()).
 
 Besides the headline the default one-GPU run measures, briefly and in the same process (`--no-extras` skips them):
   variants       the other workloads of BASELINE.json at the same batch: vectorscope with K0 fused (config 2, variant ii),
@@ -64,7 +67,7 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 W4K, H4K = 3840, 2160
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", r) for r in ("round4", "round3", "round2")]
 METRIC = "Gpix/s scope accumulation @3840×2160; achieved HBM GB/s vs peak"
 UNPINNED = " (parity unpinned: the oracle is this build's restatement of the reference loops, DESIGN.md section 4)"
 
@@ -379,6 +382,11 @@ class Ctl:
         return box[0]
 
 
+def spread(n, k):
+    """k frame indices spread over a launch of n frames, first and last included."""
+    return sorted({round(i * (n - 1) / max(k - 1, 1)) for i in range(min(k, n))})
+
+
 class Workload:
     """One scope workload over a pool of HBM-resident frames, `n` frames per step, rotating through the pool."""
 
@@ -426,7 +434,7 @@ class Workload:
         g, buf = self.last
         torch = self.torch
         ok = True
-        for f in (frames if frames is not None else sorted({0, self.n - 1})):
+        for f in (frames if frames is not None else spread(self.n, 8)):
             pr, py = rgb[g * self.n + f].cpu().numpy(), yuv[g * self.n + f].cpu().numpy()
             if self.wl in ("vectorscope", "vectorscope_rgb", "three_scope"):
                 got = (self.vss if self.wl == "three_scope" else self.tables)[buf][f].cpu().numpy().reshape(256, 256)
@@ -559,22 +567,72 @@ class Overlap:
 
 
 def roofline(wl, algo_bytes, launches, kernel_ms, ms_per_step, traffic):
+    """`achieved` / `frac` are the WHOLE STEP's: algorithmic bytes over everything the call enqueues (the accumulation kernel, the
+    partial-table reduction, the gaps between launches) as the K timed steps saw it -- the conservative figure, and the one an
+    outside clock around the run reproduces.  The accumulation kernel alone (HIP events on its stream around each launch, the
+    figure rocprofv3's average duration for that kernel agrees with) is `achieved_kernel` / `frac_kernel`."""
     kern_avg_ms = kernel_ms / launches if launches else float("nan")
-    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches and kern_avg_ms > 0 else float("nan")
+    kern = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches and kern_avg_ms > 0 else float("nan")
+    whole = algo_bytes / (ms_per_step * 1e-3) / 1e9 if ms_per_step > 0 else float("nan")
     return {
         "bound": "hbm",
         "kernel": KERNEL[wl],
-        "achieved": round(achieved, 1),
+        "achieved": round(whole, 1),
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4),
-        # the whole step (every kernel of the call + launch gaps) on the same scale: what the host sees
-        "frac_whole_step": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_per_step > 0 else None,
+        "frac": round(whole / HBM_PEAK_GBPS, 4),
+        "frac_is": "whole step (every kernel of the call + launch gaps) over the K timed steps",
+        "achieved_kernel": round(kern, 1),
+        "frac_kernel": round(kern / HBM_PEAK_GBPS, 4),
+        "frac_whole_step": round(whole / HBM_PEAK_GBPS, 4),
         "traffic": traffic,
         "algorithmic_bytes_per_launch": algo_bytes,
         "avg_launch_ms": round(kern_avg_ms, 5),
         "launches_timed": launches,
     }
+
+
+def flat_summary(result):
+    """{name: scalar} of the other legs: <variant>_gpix / _frac (whole step) / _frac_kernel, <workload>_x1_us / _x3_us (the
+    reference's call shape), <content>_<workload>_frac_kernel, stream / config 1 / config 4 figures, and all_parity."""
+    flat, ok = {}, result["parity"].startswith("bit-exact")
+    for name, v in (result.get("variants") or {}).items():
+        flat[f"{name}_gpix"] = v["value"]
+        flat[f"{name}_frac"] = v["roofline"]["frac"]
+        flat[f"{name}_frac_kernel"] = v["roofline"]["frac_kernel"]
+        ok = ok and v["parity"] is not False
+    for name, v in (result.get("latency") or {}).items():
+        if isinstance(v, dict):
+            flat[f"{name}_us"] = v["us_per_call"]
+            ok = ok and bool(v["parity"])
+    for kind, v in (result.get("distributions") or {}).items():
+        if not isinstance(v, dict):
+            continue
+        for wl, r in v.items():
+            if isinstance(r, dict):
+                if "frac_kernel" in r:
+                    flat[f"{kind}_{wl}_frac_kernel"] = r["frac_kernel"]
+                flat[f"{kind}_{wl}_gpix"] = r.get("gpix_per_s")
+                ok = ok and r.get("parity") is not False
+    st = result.get("stream") or {}
+    if "flat_out" in st:
+        flat["stream_fps"] = st["flat_out"].get("fps")
+        flat["stream_paced_240fps_latency_ms"] = (st.get("paced_240fps") or {}).get("latency_ms_mean")
+        ok = ok and str(st.get("parity", "")).startswith("bit-exact")
+    c1 = result.get("config1") or {}
+    if "ms_per_frame" in c1:
+        flat["config1_cpu_ms_per_frame"] = c1["ms_per_frame"]
+        ok = ok and bool(c1.get("gpu_tables_bit_exact"))
+    c4 = result.get("config4") or {}
+    if "value" in c4:
+        flat["config4_gpix"] = c4["value"]
+        flat["config4_ranks_in_communicator"] = c4.get("rccl_ranks_in_communicator")
+        ok = ok and bool(c4.get("parity"))
+    pl = (result.get("config") or {}).get("frame_pool_placement") or {}
+    if "value" in pl:
+        flat["placed_pool_gpix"] = pl["value"]
+    flat["all_parity"] = bool(ok)
+    return flat
 
 
 def code_only(src):
@@ -766,38 +824,6 @@ def run_rank(args):
     rgb, yuv = make_frames(torch, ctx, pool, w, h, args.dist, 0x9E3779B9 + rank, device=dev.device)
     dev.sync()
     placement, pools = None, []
-    if args.placement_candidates > 1 and not dev.emul:
-        pn = min(pool, 64)  # the probe reads the whole pool (one launch takes at most 64 frames)
-        ptab = torch.empty((pn, 65536), dtype=torch.uint8, device=dev.device)
-
-        def probe_yuv(t):
-            b = ctx.make_device_batch(t[:pn], 4 * w, w, h, planes_are_rgb=False)
-            return lambda: ctx.vectorscope_batch_dev(b, ptab, sync=False)
-
-        # the headline kernel on the pool as this process first allocated it and on the pool the library placed, measured
-        # ALTERNATELY (clocks drift over a run: two figures taken a second apart are not comparable to a per cent)
-        yuv_first = yuv
-        yuv, rates_y = place_pool(torch, dev, ctx, yuv_first, args.placement_candidates, pools)
-        fa, fb = probe_yuv(yuv_first), probe_yuv(yuv)
-        t_first, t_placed = [], []
-        for _ in range(3):
-            t_first.append(kernel_us(ctx, fa, warm=6, reps=16))
-            t_placed.append(kernel_us(ctx, fb, warm=6, reps=16))
-        us_first, us_placed = min(t_first), min(t_placed)
-        del yuv_first, fa
-        rgb_first = rgb
-        rgb, rates_r = place_pool(torch, dev, ctx, rgb_first, args.placement_candidates, pools)
-        del rgb_first
-        dev.empty_cache()
-        probe_bytes = pn * (4 * w * h + 65536)
-        placement = {"candidates": args.placement_candidates, "by": "scope_frame_pool_alloc (C-ABI): candidates held at once, each read "
-                     "by the vectorscope accumulation kernel timed with its own begin/end stamps, the fastest kept, the rest freed; untimed set-up",
-                     "yuv_pool_read_gbps": rates_y, "rgb_pool_read_gbps": rates_r,
-                     "vectorscope_kernel_us_first_allocation": us_first, "vectorscope_kernel_us_placed_pool": us_placed,
-                     "how_compared": "three alternating rounds of 16 launches on each pool, the fastest round of each",
-                     "first_allocation_frac": round(probe_bytes / (us_first * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-                     "placed_frac": round(probe_bytes / (us_placed * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
-        del ptab
     work = Workload(torch, ctx, wl, rgb, yuv, w, h, n, args.components)
     table_bytes = work.tbytes
     frame0 = (rgb[0].cpu().numpy(), yuv[0].cpu().numpy())  # the CPU baseline's sample
@@ -906,9 +932,30 @@ def run_rank(args):
     traffic, traffic_src = pmc_traffic(wl, n, w, h, plain and world == 1)
     rf = roofline(wl, work.algo_bytes, launches, kernel_ms, ms_per_step, traffic)
     rf["traffic_source"] = traffic_src
-    if placement:
-        # beside the placed pool's figure: the same kernel on the pool as the process first allocated it
-        rf["frac_first_allocation"] = placement["first_allocation_frac"]
+    rf["pool"] = "as this process first allocated it (no placement search): see frame_pool_placement for scope_frame_pool_alloc's pool"
+    if args.placement_candidates > 1 and not dev.emul and world == 1 and not use_dist:
+        # The same launch on a pool the LIBRARY placed (scope_frame_pool_alloc: candidates held at once, each read by the
+        # accumulation kernel, the fastest kept): what a host that keeps a long-lived pool can have.  A leg of its own, after
+        # the headline; the headline above never saw it.
+        src_name = "yuv" if wl == "vectorscope" else "rgb"
+        src = yuv if wl == "vectorscope" else rgb
+        placed, rates = place_pool(torch, dev, ctx, src, args.placement_candidates, pools)
+        pw = Workload(torch, ctx, wl, placed if src_name == "rgb" else rgb, placed if src_name == "yuv" else yuv, w, h, n, args.components)
+        p_el, p_sus, p_ln, p_kms = timed_run(dev, ctl, ctx, stream, pw.step, args.steps, args.warmup, 0.2, 0.5)
+        p_ok = pw.check(o, placed if src_name == "rgb" else rgb, placed if src_name == "yuv" else yuv, np, frames=spread(n, 3))
+        p_ms = p_el / args.steps * 1e3
+        p_rf = roofline(wl, pw.algo_bytes, p_ln, p_kms, p_ms, None)
+        placement = {"candidates": args.placement_candidates, "pool": src_name,
+                     "by": "scope_frame_pool_alloc (C-ABI): candidates held at once, each read by the vectorscope accumulation kernel "
+                           "timed with its own begin/end stamps, the fastest kept, the rest freed; untimed set-up",
+                     "pool_read_gbps": rates, "value": round(n * w * h * args.steps / p_el / 1e9, 3), "ms_per_step": round(p_ms, 4),
+                     "frac": p_rf["frac"], "frac_kernel": p_rf["frac_kernel"], "avg_launch_ms": p_rf["avg_launch_ms"], "parity": bool(p_ok)}
+        rf["frac_placed"] = p_rf["frac"]
+        rf["frac_kernel_placed"] = p_rf["frac_kernel"]
+        parity = parity and bool(p_ok)
+        del pw, placed
+        dev.sync()
+        pools.pop().free()
     sustained["value"] = round(pix_per_step / (sustained["ms_per_step"] * 1e-3) / 1e9, 3) if sustained["ms_per_step"] > 0 else None
     if world == 1:
         partition = "one frame batch per GPU"
@@ -1052,6 +1099,12 @@ def run_rank(args):
         result["cpu_baseline"] = cpu_baseline(np, o, "vectorscope" if wl == "three_scope" else wl, frame0[0], frame0[1],
                                               w, h, args.components, args.cpu_seconds)
 
+    # ---- the legs' headline numbers once more as FLAT scalars, at the top level and inside `roofline`: a reader (the driver's
+    # record keeps scalar fields of the objects it knows and only the NAMES of the others) then has every README row in one place
+    flat = flat_summary(result)
+    result.update(flat)
+    result["roofline"].update(flat)
+
     faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
@@ -1105,21 +1158,19 @@ class Legs:
         torch, np = self.torch, self.np
         vw = Workload(torch, self.ctx, wl, rgb, yuv, self.w, self.h, self.n, comp)
         el, sus, ln, kms = timed_run(self.dev, self.ctl, self.ctx, self.stream, vw.step, steps, 3, 0.2, seconds)
-        ok = vw.check(self.o, rgb, yuv, np, frames=[0]) if check else None
+        ok = vw.check(self.o, rgb, yuv, np, frames=spread(self.n, 3)) if check else None
         tr, _ = pmc_traffic(wl, self.n, self.w, self.h, comp == 0x07 and vw.linesize == 4 * self.w)
         vr = roofline(wl, vw.algo_bytes, ln, kms, sus["ms_per_step"], tr)
         if wl == "three_scope":
             # SURVEY 8(d)'s config-5 bytes (ONE read of the frames + the three tables) over the whole step.  The label
             # "hbm" would flatter this workload: with four LDS atomics and K0 per pixel its own ceiling is LDS / VALU
             # issue, which profiles/round1/lds_atomic_microbench.txt prices at about 1.3 Tpix/s = 0.64 of the HBM peak.
-            vr["achieved"] = round(vw.algo_bytes / (sus["ms_per_step"] * 1e-3) / 1e9, 1)
-            vr["frac"] = vr["frac_whole_step"]
             vr["bound"] = "lds/valu issue (4 LDS atomics + K0 per pixel); hbm is the yardstick, not the ceiling"
             vr["ceiling_estimate"] = {"gpix_per_s": 1100, "frac_of_hbm_peak": 0.62,
                                       "from": "the larger of LDS issue (3 waveform adds at 2.1 x the conflict-free 4.5 clk per wave instruction "
                                               "-- one table replica -- + 1 vectorscope add at 7.5: 0.56 clk per pixel and CU) and VALU issue "
                                               "(31.3 instructions per pixel / 64 lanes per clk = 0.49), 256 CUs at 2.4 GHz; DESIGN.md 3.8"}
-            vr["note"] = "achieved = SURVEY 8(d) config-5 bytes (one read of the frames + the three tables) / whole step"
+            vr["note"] = "algorithmic bytes = SURVEY 8(d)'s config-5 figure: one read of the frames + the three tables"
         out = {"value": round(self.n * self.w * self.h / (sus["ms_per_step"] * 1e-3) / 1e9, 3), "unit": "Gpix/s", "components": f"{comp:#04x}",
                "ms_per_step": sus["ms_per_step"], "steps": sus["steps"], "parity": ok, "roofline": vr}
         del vw
@@ -1134,11 +1185,11 @@ class Legs:
         def both(rgb, yuv, trio=True):
             a = self.variant("vectorscope", rgb, yuv, 0x07, steps=10, seconds=0.5)
             b = self.variant("vectorscope_rgb", rgb, yuv, 0x07, steps=10, seconds=0.5)
-            res = {"vectorscope": {"frac": a["roofline"]["frac"], "frac_whole_step": a["roofline"]["frac_whole_step"], "gpix_per_s": a["value"], "parity": a["parity"]},
-                   "vectorscope_rgb": {"frac": b["roofline"]["frac"], "frac_whole_step": b["roofline"]["frac_whole_step"], "gpix_per_s": b["value"], "parity": b["parity"]}}
+            res = {"vectorscope": {"frac": a["roofline"]["frac"], "frac_kernel": a["roofline"]["frac_kernel"], "gpix_per_s": a["value"], "parity": a["parity"]},
+                   "vectorscope_rgb": {"frac": b["roofline"]["frac"], "frac_kernel": b["roofline"]["frac_kernel"], "gpix_per_s": b["value"], "parity": b["parity"]}}
             if trio:  # the one-read three-scope kernel is LDS / VALU bound: same-address LDS atomics make it content dependent
                 c = self.variant("three_scope", rgb, yuv, 0x07, steps=6, seconds=0.4)
-                res["three_scope"] = {"gpix_per_s": c["value"], "frac_whole_step": c["roofline"]["frac_whole_step"], "parity": c["parity"]}
+                res["three_scope"] = {"gpix_per_s": c["value"], "frac": c["roofline"]["frac"], "parity": c["parity"]}
             return res
 
         for kind in ("natural", "concentrated", "flat", "screen", "ramp"):
@@ -1153,13 +1204,13 @@ class Legs:
         hy = yuv_uniform[:self.n]
         a = self.variant("histogram", holes, hy, 0x07, steps=10, seconds=0.5)
         b = self.variant("waveform", holes, hy, 0x07, steps=10, seconds=0.5)
-        out["alpha_holes"] = {"histogram": {"frac": a["roofline"]["frac"], "gpix_per_s": a["value"], "parity": a["parity"]},
-                              "waveform": {"frac": b["roofline"]["frac"], "gpix_per_s": b["value"], "parity": b["parity"]},
+        out["alpha_holes"] = {"histogram": {"frac": a["roofline"]["frac"], "frac_kernel": a["roofline"]["frac_kernel"], "gpix_per_s": a["value"], "parity": a["parity"]},
+                              "waveform": {"frac": b["roofline"]["frac"], "frac_kernel": b["roofline"]["frac_kernel"], "gpix_per_s": b["value"], "parity": b["parity"]},
                               "note": "the vectorscope ignores alpha (src/vectorscope.c:217-238): histogram and waveform are what D5 exercises"}
         del holes
         self.dev.empty_cache()
-        out["what"] = (f"{self.n} frames per launch, kernel frac = algorithmic bytes / the accumulation kernel's own begin/end stamps / 8 TB/s; "
-                       "pools taken as allocated (no placement search); uniform noise is the headline")
+        out["what"] = (f"{self.n} frames per launch; frac = algorithmic bytes / the whole step / 8 TB/s, frac_kernel = / the accumulation "
+                       "kernel's own begin/end stamps; pools taken as allocated; uniform noise is the headline")
         return out
 
 

@@ -120,3 +120,54 @@ def test_nothing_works_still_one_line(shm_rccl, tmp_path):
     # every rung dies at once (an unknown option value): the launcher's own line, exit code 5
     rc, d, err = run_bench(["--gpus", "2", *SMALL, "--no-extras", "--option", "no_such_option=1", "--launch-timeout", "60"], clean_env())
     assert rc == 5 and d["value"] == 0.0 and "error" in d and len(d["launcher"]["attempts"]) == 3
+
+
+# ---- N = 4 and N = 8: the driver's 8-GPU run must not be the launcher's first 8-process run ----------------------
+
+
+def test_gpus8_config4_real_tile_self_launched(shm_rccl):
+    """BASELINE config 4's real shape: 7680x4320 frames, rank r owns rows [540 r, 540 (r + 1)), eight ranks, the tables summed
+    through scope_table_allreduce and compared with the oracle's table of every rank's tile (summed over gloo, clamped once)."""
+    rc, d, err = run_bench(["--gpus", "8", *SMALL, "--config4-geometry", "7680x4320", "--config4-frames", "2", "--strong"], clean_env(),
+                           timeout=900)
+    assert rc == 0, err[-3000:]
+    assert d["n_gpus"] == 8 and d["parity"].startswith("bit-exact") and d["scaling"] == "strong"
+    la = d["launcher"]
+    assert len(la["attempts"]) == 1 and la["attempts"][0]["exit_codes"] == [0] * 8 and la["attempts"][0]["failure"] is None
+    assert d["config"]["rccl"]["ranks_in_communicator"] == 8
+    c4 = d["config4"]
+    assert c4["parity"] is True and c4["rccl_ranks_in_communicator"] == 8 and c4["rows_of_this_rank"] == [0, 540]
+    assert "8 row tile(s) of 7680x540" in c4["partition"]
+
+
+def test_gpus4_config4_real_frame_self_launched(shm_rccl):
+    rc, d, err = run_bench(["--gpus", "4", *SMALL, "--config4-geometry", "7680x4320", "--config4-frames", "1", "--strong"], clean_env(),
+                           timeout=900)
+    assert rc == 0, err[-3000:]
+    assert d["n_gpus"] == 4 and d["parity"].startswith("bit-exact")
+    assert d["launcher"]["attempts"][0]["exit_codes"] == [0] * 4 and d["config"]["rccl"]["ranks_in_communicator"] == 4
+    c4 = d["config4"]
+    assert c4["parity"] is True and c4["rccl_ranks_in_communicator"] == 4 and c4["rows_of_this_rank"] == [0, 1080]
+
+
+def test_gpus8_under_torch_distributed_run(shm_rccl):
+    """The driver's own command line at N = 8: eight supervised ranks, one stdout line, config 4 in eight row tiles."""
+    env = clean_env(MASTER_ADDR="127.0.0.1")
+    prefix = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29523"]
+    rc, d, err = run_bench(["--gpus", "8", *SMALL, "--config4-geometry", "256x64", "--config4-frames", "2", "--strong"], env, prefix=prefix, timeout=900)
+    assert rc == 0, err[-3000:]
+    assert d["n_gpus"] == 8 and d["config"]["launch"] == "supervised rank under torch.distributed.run"
+    assert len(d["launcher"]["attempts"]) == 1 and d["launcher"]["attempts"][0]["exit_codes"] == [0] * 8
+    assert d["config"]["rccl"]["ranks_in_communicator"] == 8 and d["parity"].startswith("bit-exact")
+    assert d["config4"]["parity"] is True and d["config4"]["rows_of_this_rank"] == [0, 8] and d["config4"]["rccl_ranks_in_communicator"] == 8
+    assert d["scaling"] == "strong"
+
+
+def test_gpus8_one_hung_rank_still_prints_a_line(shm_rccl):
+    """Rank 5 of 8 never enters its first collective: seven ranks wait, the watchdogs end the attempt, the next rung carries the line."""
+    env = clean_env(SHM_RCCL_HANG_RANK="5", SHM_RCCL_TIMEOUT_S="1000")
+    rc, d, err = run_bench(["--gpus", "8", *SMALL, "--no-extras", "--launch-timeout", "40"], env, timeout=900)
+    assert rc == 0, err[-3000:]
+    attempts = d["launcher"]["attempts"]
+    assert len(attempts) == 2 and attempts[0]["failure"] and attempts[1]["failure"] is None and attempts[1]["extra_args"] == ["--torch-reduce"]
+    assert d["n_gpus"] == 8 and d["config"]["reduce"].startswith("torch.distributed") and d["parity"].startswith("bit-exact")
