@@ -534,7 +534,8 @@ int run_dock(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t 
 				return fail(ctx, SCOPE_EINVAL, "three scopes: chunks of one call disagree on the launch shape", hipSuccess);
 			return 0;
 		}
-		const uint32_t slices = old_form ? scope_wvs_strips(width, 1) : scope_trio_slices(fs, (uint32_t)ctx->num_cu);
+		const uint32_t sw = scope_trio_strip_width(fs, (uint32_t)ctx->num_cu, ctx->tn);
+		const uint32_t slices = old_form ? scope_wvs_strips(width, 1) : scope_trio_slices(fs, (uint32_t)ctx->num_cu, sw);
 		const bool partials = slices > 1 || old_form; /* scope_dock_kernel always writes a sparse partial per strip */
 		if (partials) {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * SCOPE_VSS_BINS);
@@ -547,7 +548,7 @@ int run_dock(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t 
 			TIMED_LAUNCH(ctx, scope_launch_dock(fs, cw, colorspace, wvs_dst, his_dst ? &sink : NULL, ctx->partial, ctx->pmask,
 							    ctx->stream, tm_));
 		} else {
-			TIMED_LAUNCH(ctx, scope_launch_trio(fs, slices, cw, colorspace, wvs_dst, his_dst ? &sink : NULL,
+			TIMED_LAUNCH(ctx, scope_launch_trio(fs, slices, sw, cw, colorspace, wvs_dst, his_dst ? &sink : NULL,
 							    slices > 1 ? ctx->partial : vss_dst, ctx->pmask, ctx->stream, tm_));
 		}
 		if (partials)
@@ -780,6 +781,8 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.fold = 1;
 	ctx->tn.vss_sparse = 1;
 	ctx->tn.nt_loads = 1;
+	ctx->tn.trio_strip = 0;
+	ctx->tn.vss_run = 0;
 	ctx->err[0] = 0;
 	*out = ctx;
 	return SCOPE_OK;
@@ -926,6 +929,10 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.wvs_deep = value != 0;
 	else if (!strcmp(key, "dock"))
 		ctx->tn.dock = value < 0 ? 0 : (value > 2 ? 1 : value);
+	else if (!strcmp(key, "trio.strip"))
+		ctx->tn.trio_strip = value == 16 || value == 32 ? value : 0;
+	else if (!strcmp(key, "vss.run"))
+		ctx->tn.vss_run = value != 0;
 	else if (!strcmp(key, "slices"))
 		ctx->slices_override = value;
 	else

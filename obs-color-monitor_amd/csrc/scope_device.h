@@ -284,16 +284,33 @@ __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
  * halves of one register (vss_add_pair): 4.5 VALU instructions per pixel from the fixed-point sums to the two LDS
  * operands instead of 7. */
 #define VSS_PITCH2 136u
+/* HASH 3 (scope_trio_kernel, where K0 is fused and the table shares the LDS with the waveform's): only the chroma K0 can
+ * produce.  Over all 2^24 colours and both matrices U lies in [15, 239] and V in [16, 240] (data/common.effect:23-43 are
+ * limited-range chroma rows; tests/test_oracle.py::test_k0_chroma_range enumerates them, test_dock_kernel_all_colours
+ * runs every colour through the kernel), so the table holds rows v = 16 .. 240 and the columns u = 8 .. 239:
+ * word (v - 16) * 116 + ((u - 8) >> 1), 225 rows of 116 words = 104 400 bytes instead of 131 072.  The pitch is 4 words
+ * more than a multiple of 16: eight consecutive rows start on eight different multiples of four words, and every
+ * 16-bin output group is two aligned uint4.  The table lies at byte VSS3_BASE of the LDS block, behind the waveform's;
+ * the origin (row 16, column 8) and the base are ONE constant, carried by the ds instruction's immediate offset, so
+ * the address arithmetic is HASH 2's: the raw word v * 116 + (u >> 1) fits 16 bits (vss_add_pair). */
+#define VSS3_PITCH 116u
+#define VSS3_ROWS 225u
+#define VSS3_V0 16u
+#define VSS3_U0 8u
+#define VSS3_BASE 49152u
+#define VSS3_BIAS (VSS3_BASE - 4u * (VSS3_V0 * VSS3_PITCH + (VSS3_U0 >> 1)))
 template <int HASH> struct VssTable {
-	static constexpr u32 words = HASH == 2 ? 256u * VSS_PITCH2 : VSS_WORDS;
+	static constexpr u32 words = HASH == 3 ? VSS3_ROWS * VSS3_PITCH : HASH == 2 ? 256u * VSS_PITCH2 : VSS_WORDS;
+	static constexpr u32 pitch = HASH == 3 ? VSS3_PITCH : HASH == 2 ? VSS_PITCH2 : 128u;
+	static constexpr u32 bias = HASH == 3 ? VSS3_BIAS : 0u; /* bytes added to 4 * (v * pitch + (u >> 1)) */
 };
 
 template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u32 n)
 {
 	const u32 t = key >> 7; /* v << 9 | u << 1 */
 	u32 byte;
-	if (HASH == 2)
-		byte = (key >> 16) * (VSS_PITCH2 * 4u) + (t & 0x1fcu); /* the slow door of the pair layout: see vss_add_pair */
+	if (HASH == 2 || HASH == 3) /* the slow door of the pair layouts: see vss_add_pair */
+		byte = (key >> 16) * (VssTable<HASH>::pitch * 4u) + (t & 0x1fcu) + VssTable<HASH>::bias;
 	else if (HASH == 1)
 		byte = t & 0x1fffcu;
 	else
@@ -305,12 +322,13 @@ template <int HASH> __device__ __forceinline__ void vss_add(u32 *tab, u32 key, u
 /* HASH 2, two pixels at once: pu = U0 | U1 << 16, pv = V0 | V1 << 16 (scope_k0_cell_uv).  Word indices in 16-bit halves
  * (v_pk_lshrrev_b16, v_pk_mad_u16), then per pixel one SDWA shift for the byte address and one for the increment
  * 1 << 16 (u & 1), whose count is the byte (u & 15) << 4 of pu << 4 (the shifter reads five bits). */
-__device__ __forceinline__ void vss_add_pair(u32 *tab, u32 pu, u32 pv)
+template <int HASH = 2> __device__ __forceinline__ void vss_add_pair(u32 *tab, u32 pu, u32 pv)
 {
-	const u32 w = scope_pk_mad_u16(pv, VSS_PITCH2 | (VSS_PITCH2 << 16), scope_pk_lshr_u16(pu, 1));
+	constexpr u32 pitch = VssTable<HASH>::pitch, bias = VssTable<HASH>::bias;
+	const u32 w = scope_pk_mad_u16(pv, pitch | (pitch << 16), scope_pk_lshr_u16(pu, 1));
 	const u32 q = pu << 4;
-	scope_lds_add_at(tab, scope_shl_word0(2u, w), scope_shl_by_byte0(q, 1u));
-	scope_lds_add_at(tab, scope_shl_word1(2u, w), scope_shl_by_byte2(q, 1u));
+	scope_lds_add_at(tab, scope_shl_word0(2u, w) + bias, scope_shl_by_byte0(q, 1u)); /* bias: the ds offset field */
+	scope_lds_add_at(tab, scope_shl_word1(2u, w) + bias, scope_shl_by_byte2(q, 1u));
 }
 /* the key (0, U, V, 0) of either pixel of a pair: what the absorb mode and the votes compare */
 __device__ __forceinline__ u32 vss_pair_key(u32 pu, u32 pv, int odd)
@@ -407,8 +425,9 @@ __device__ __forceinline__ void vss_absorb_pairs(u32 *tab, VssLane &st, u32 &lan
 }
 
 /* one pair (scope_trio_kernel's slot) */
-__device__ __forceinline__ void vss_absorb_pair(u32 *tab, VssLane &st, u32 &lane_u, u32 &lane_v, u32 pu, u32 pv)
+template <int HASH = 2> __device__ __forceinline__ void vss_absorb_pair(u32 *tab, VssLane &st, u32 &lane_u, u32 &lane_v, u32 pu, u32 pv)
 {
+	constexpr u32 pitch = VssTable<HASH>::pitch, bias = VssTable<HASH>::bias;
 	u32 x = scope_bitop3<0xf6>(pu ^ lane_u, pv, lane_v);
 	if (x == 0u) {
 		st.count += 2;
@@ -417,7 +436,7 @@ __device__ __forceinline__ void vss_absorb_pair(u32 *tab, VssLane &st, u32 &lane
 	bool e0 = (x & 0xffffu) == 0u, e1 = (x >> 16) == 0u;
 	if (!(e0 | e1)) {
 		if (st.count)
-			vss_add<2>(tab, st.colour, st.count);
+			vss_add<HASH>(tab, st.colour, st.count);
 		st.colour = vss_pair_key(pu, pv, 0);
 		st.count = 0;
 		lane_u = scope_perm(0u, pu, 0x0c000c00u);
@@ -428,11 +447,11 @@ __device__ __forceinline__ void vss_absorb_pair(u32 *tab, VssLane &st, u32 &lane
 	}
 	st.count += (u32)e0 + (u32)e1;
 	if (!(e0 & e1)) {
-		const u32 w = scope_pk_mad_u16(pv, VSS_PITCH2 | (VSS_PITCH2 << 16), scope_pk_lshr_u16(pu, 1)), q = pu << 4;
+		const u32 w = scope_pk_mad_u16(pv, pitch | (pitch << 16), scope_pk_lshr_u16(pu, 1)), q = pu << 4;
 		if (!e0)
-			scope_lds_add_at(tab, scope_shl_word0(2u, w), scope_shl_by_byte0(q, 1u));
+			scope_lds_add_at(tab, scope_shl_word0(2u, w) + bias, scope_shl_by_byte0(q, 1u));
 		if (!e1)
-			scope_lds_add_at(tab, scope_shl_word1(2u, w), scope_shl_by_byte2(q, 1u));
+			scope_lds_add_at(tab, scope_shl_word1(2u, w) + bias, scope_shl_by_byte2(q, 1u));
 	}
 }
 

@@ -68,6 +68,8 @@ struct ScopeTuning {
 			      * for launches of one round of strips only (scope_dock_kernel), two passes otherwise; 0 = always two passes */
 	int wvs_strip;       /* 0: 16-column strips for launches that would otherwise need row bands, 64 elsewhere; 64 / 16: always */
 	int nt_loads;        /* 1: non-temporal pixel loads */
+	int trio_strip;      /* scope_trio_kernel's strip width: 0 = 32 columns for batches, 16 for small launches; 16 / 32: always */
+	int vss_run;         /* the fused-K0 vectorscope under vss_merge 3: 0 = run mode by wave vote, 1 = run mode always (tests) */
 };
 
 /* Optional last argument of the accumulation launchers: two HIP events that receive the kernel's own begin and end time
@@ -145,9 +147,13 @@ hipError_t scope_launch_dock(const ScopeFrameSet &fs, uint32_t chmask, int color
  * tables, vss_mask unused; else vss_dst / vss_mask = sparse partials as scope_launch_vss writes them with 1024 mask bytes
  * per slice, for scope_launch_sat_reduce_sparse.  Where scope_trio_fits says so (vector shape, height <= 65535). */
 bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const ScopeTuning &tn);
-uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu);
-hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int colorspace, uint8_t *wvs_dst,
-			     const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st, const ScopeTiming *tm = NULL);
+/* strip width of the launch (32 columns for batches, 16 for the reference's call shape; tn.trio_strip forces one), the slices
+ * per frame that go with it, and the launch */
+uint32_t scope_trio_strip_width(const ScopeFrameSet &fs, uint32_t num_cu, const ScopeTuning &tn);
+uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu, uint32_t strip_width);
+hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t strip_width, uint32_t chmask, int colorspace,
+			     uint8_t *wvs_dst, const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st,
+			     const ScopeTiming *tm = NULL);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
  * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */

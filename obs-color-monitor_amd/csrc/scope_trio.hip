@@ -59,32 +59,83 @@
 			* screen content (721 -> 685; with the vectorscope's looser vote 9 %): entirely flat frames are not worth
 			* that, so it is compiled out */
 #endif
+#ifndef TRIO_INTERLEAVE
+#define TRIO_INTERLEAVE 1 /* 32-column strips: a frame's slices interleave its strips (see the kernel); 0: contiguous ranges (A/B) */
+#endif
+#ifndef TRIO_SKIP_EMPTY
+#define TRIO_SKIP_EMPTY 1
+#endif
+#ifndef TRIO_FASTSLOT
+#define TRIO_FASTSLOT 1 /* 0: every slot runs the checked form (round 3's; A/B) */
+#endif
 #ifndef TRIO_EXP
 #define TRIO_EXP 0 /* measurement only (wrong tables): bit 0 no waveform adds, 1 no vectorscope adds, 2 no K0, 3 no clamp pass */
 #endif
+#ifndef TRIO_COMPACT
+#define TRIO_COMPACT 1 /* round 4: the LDS map below.  0: round 3's map (A/B: `make trio_variant VARIANT_FLAGS=-DTRIO_COMPACT=0`) */
+#endif
+/* ---- the LDS map (TRIO_COMPACT) ---------------------------------------------------------------------------------------
+ * Round 3's map -- the vectorscope's full 128 KiB table and ONE waveform replica of 8 KiB per channel -- left the kernel waiting
+ * for the LDS: a half wave is 4 rows x 8 column pairs and a counter's bank was (value mod 4) * 8 + pair, so two of the four rows
+ * met in a bank whenever their values agreed mod 4 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.64,
+ * profiles/round3/pmc_sq_three_scope_x64_f1.txt), and four rows of flat content met on one ADDRESS.
+ * K0 is fused here, and its chroma rows are limited-range: U in [15, 239], V in [16, 240] for every colour and both matrices
+ * (scope_device.h, HASH 3).  The vectorscope table shrinks to that rectangle -- 225 rows of 116 words, 104 400 bytes -- and the
+ * 26 KiB that frees buy a SECOND waveform replica (four for a one-channel mask):
+ *     bytes      0 ..  49 151   waveform: [channel][256 values][REP replicas][8 column pairs] words of two 16-bit counters
+ *     bytes 49 152 .. 153 551   vectorscope, HASH 3
+ * A lane's replica is its row within the half wave mod REP, so the bank is (value mod (4 / REP)) * 8 REP + replica * 8 + pair:
+ * with two replicas only the rows r and r + 2 can meet, two-way at most -- which costs a ds_add nothing
+ * (profiles/round1/lds_atomic_microbench.txt: "same bank, distinct address x 2" = the conflict-free 4.5 clk) -- and flat content
+ * puts two lanes on an address instead of four; with four replicas (one channel) no two lanes of a half wave share a bank.
+ * The strip's read-out adds the replicas (packed 16-bit adds: a column's total is at most H <= 65 535).
+ *
+ * The same 48 KiB hold ONE replica of a strip twice as wide (SW = 32 columns: 16 column pairs, a wave is 4 rows x 32 columns,
+ * word = value * 16 + pair): the bank is (value mod 2) * 16 + pair, the two rows of a half wave meet two-way at most as
+ * above -- and a strip's row segment is now a whole 128-byte line (no partner workgroup fetching the other half from the L2),
+ * a launch has half the strips (half the barriers and read-outs per texel) and the read-out stores 128 contiguous bytes per
+ * value instead of 64.  Batches run this form; launches too small to give every CU four such strips (one frame, the ring of
+ * three) keep 16-column strips with the replicas, so that a one-frame call still spreads over 240 workgroups.
+ * scope_trio_slices decides; "trio.strip" (scope_ctx_set_option) forces 16 or 32. */
+#if TRIO_COMPACT
+#undef TRIO_HASH
+#define TRIO_HASH 3
+#ifndef TRIO_PAIR
+#define TRIO_PAIR 1 /* the vectorscope's adds in pair form (vss_add_pair<3>): with the LDS relieved, VALU issue is what is short */
+#endif
+#define TRIO_REP(nch, sw) ((sw) == 32u ? 1u : (nch) == 1u ? 4u : 2u)
+#define TRIO_WVS_BASE 0u
+#define TRIO_VSS_BASE VSS3_BASE
+#define TRIO_LDS_BYTES(nch) (VSS3_BASE + VssTable<3>::words * 4u)
+#else
 #ifndef TRIO_HASH
 #define TRIO_HASH 0 /* the vectorscope table's layout.  0: as scope_vss_kernel's plain form.  2: rows of 136 words, a slot's two
 		     * texels addressed as a pair (vss_add_pair: 4.5 VALU instructions per texel instead of 7, what gave the fused-K0
-		     * vectorscope 4 %); with the waveform's 24 KiB that is all 160 KiB of the CU.  Measured here (visit p10, same
-		     * process, 64 x 4K): noise 3779 -> 3758 GB/s, natural 3724 -> 3746, flat 2890 -> 2938, screen 3074 -> 2847 --
-		     * this kernel waits for the LDS (the waveform's single replica), not for VALU issue slots: left at 0 */
+		     * vectorscope 4 %); with the waveform's 24 KiB that is all 160 KiB of the CU.  Measured in round 3 (visit p10, same
+		     * process, 64 x 4K): noise 3779 -> 3758 GB/s, natural 3724 -> 3746, flat 2890 -> 2938, screen 3074 -> 2847 */
 #endif
-#define TRIO_CH_BYTES 8192u
+#define TRIO_PAIR (TRIO_HASH == 2)
+#define TRIO_REP(nch, sw) 1u
+#define TRIO_VSS_BASE 0u
+#define TRIO_WVS_BASE (VssTable<TRIO_HASH>::words * 4u)
+#define TRIO_LDS_BYTES(nch) (VssTable<TRIO_HASH>::words * 4u + (nch) * 8192u)
+#endif
 #define TRIO_VSS_WORDS (VssTable<TRIO_HASH>::words)
-#define TRIO_WVS_BASE (TRIO_VSS_WORDS * 4u)
 
-template <int CH> __device__ __forceinline__ void trio_count(u32 *tab, u32 px, u32 lane_base, u32 inc)
+/* one texel into the waveform table: value v of channel c -> byte c * CHB + v * 4 VS + lane_base (replica and column pair) */
+template <int CH, u32 VS> __device__ __forceinline__ void trio_count(u32 *tab, u32 px, u32 lane_base, u32 inc)
 {
 	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1);
+	constexpr u32 CHB = 256u * VS * 4u, SH = VS == 32 ? 7u : VS == 16 ? 6u : 5u; /* VS = words per value: 8, 16 or 32 */
 	if (CH & 1)
-		scope_lds_add_at(tab, lane_base + ((px & 0xffu) << 5), inc);
+		scope_lds_add_at(tab, lane_base + ((px & 0xffu) << SH), inc);
 	if (CH & 2)
-		scope_lds_add_at(tab, lane_base + slot1 * TRIO_CH_BYTES + (((px >> 8) & 0xffu) << 5), inc);
+		scope_lds_add_at(tab, lane_base + slot1 * CHB + (((px >> 8) & 0xffu) << SH), inc);
 	if (CH & 4)
-		scope_lds_add_at(tab, lane_base + slot2 * TRIO_CH_BYTES + (((px >> 16) & 0xffu) << 5), inc);
+		scope_lds_add_at(tab, lane_base + slot2 * CHB + (((px >> 16) & 0xffu) << SH), inc);
 }
 
-template <int CH, bool HIS>
+template <int CH, bool HIS, int SW>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet fs, u32 strips, u32 slices, ScopeK0 k0_arg,
 								uint8_t *wvs_dst, ScopeWvsHis his, uint8_t *vss_dst, uint8_t *vss_mask)
 {
@@ -94,17 +145,20 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	constexpr int D = TRIO_D;
 	u32 *tab = scope_lds;
 	scope_lds_is_at_zero(tab);
-	u32 *wt = tab + TRIO_VSS_WORDS; /* [nch][256 values][8 column pairs] */
+	constexpr u32 P = SW / 2, PL = SW == 32 ? 4u : 3u, RW = 64u / P; /* column pairs per strip (and its log2); rows of a wave */
+	constexpr u32 REP = TRIO_REP(nch, (u32)SW), VS = P * REP, CHW = 256u * VS; /* replicas; words per value / per channel */
+	u32 *wt = tab + TRIO_WVS_BASE / 4u; /* [nch][256 values][REP replicas][P column pairs] */
+	u32 *vt = tab + TRIO_VSS_BASE / 4u; /* the vectorscope table (the add functions address it from LDS byte 0 themselves) */
 	const u32 W = fs.width, H = fs.height;
 	const u32 lane = threadIdx.x & 63u;
-	const u32 pair = lane & 7u, rsub = lane >> 3;
+	const u32 pair = lane & (P - 1u), rsub = lane >> PL;
 	const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const u32 nwaves = blockDim.x >> 6;
 
 	/* ---- which strips are mine ------------------------------------------------------------------------------------ */
 	const u32 b = blockIdx.x, total = gridDim.x;
 	u32 frame, slice, first, last, stride;
-	if ((slices & 1u) == 0) {
+	if (SW == 16 && (slices & 1u) == 0) {
 		/* pairs: workgroups b and b + 8 of a block of 16 share a range of strip PAIRS (a pair = one 128-byte line per row) and
 		 * take its even / odd strips */
 		const u32 half = slices >> 1, base = total & ~15u;
@@ -123,6 +177,15 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		last = min(2u * scope_slice_begin(spairs, q + 1u, half), strips);
 		stride = 2;
 		slice = 2u * q + parity;
+	} else if (TRIO_INTERLEAVE && SW == 32) {
+		/* the slices of a frame take its strips in turn -- slice s walks strips s, s + slices, ... -- so that the workgroups of a
+		 * frame, which start together and run at one pace, are on NEIGHBOURING strips at any moment: their 128-byte row segments
+		 * are pieces of the same DRAM pages, asked for at about the same time */
+		frame = b / slices;
+		slice = b - frame * slices;
+		first = slice;
+		last = strips;
+		stride = slices;
 	} else {
 		frame = b / slices;
 		slice = b - frame * slices;
@@ -134,12 +197,12 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	const uint8_t *plane = fs.plane[frame];
 
 	/* rows of a lane: rsub * rps + i, i = wave, wave + nwaves, ...; G loads per lane and strip, rounded up to whole rounds of D */
-	const u32 rps = (H + 7u) >> 3;
+	const u32 rps = (H + RW - 1u) / RW;
 	const u32 row0 = rsub * rps;
 	const u32 G = (rps + nwaves - 1u) / nwaves;
 	const u32 Gp = ((G + (u32)D - 1u) / (u32)D) * (u32)D;
 	const u32 dstep = nwaves * fs.linesize;
-	const u32 lane_base = TRIO_WVS_BASE + (pair << 2);
+	const u32 lane_base = TRIO_WVS_BASE + (rsub & (REP - 1u)) * (P * 4u) + (pair << 2); /* the lane's replica: its row in the half wave mod REP */
 
 	/* ---- issue side ------------------------------------------------------------------------------------------------
 	 * TRIO_BUF (default): buffer addressing -- the plane is a buffer resource of H * linesize bytes in SGPRs, a lane holds ONE
@@ -159,11 +222,14 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	 * behind the last row to be allocated, and lanes of a ragged last strip (x0 >= W) must not touch it */
 	const u32 plane_bytes = (H - 1u) * fs.linesize + W * 4u;
 	const scope_buf buf = scope_buf_make(plane, plane_bytes);
+	/* the shortest row range of the wave is the last lane's (the highest row range ends with the frame) */
+	const u32 nv_min = TRIO_BUF ? (u32)__builtin_amdgcn_readlane((int)nv, 63) : 0u;
+	(void)nv_min;
 	(void)buf;
 	(void)nv;
 	(void)live_i;
 	auto strip_start = [&](u32 s) {
-		const u32 x0 = (first + s * stride) * 16u + 2u * pair;
+		const u32 x0 = (first + s * stride) * (u32)SW + 2u * pair;
 		live_i = s < nst && x0 < W; /* W % 4 == 0: both texels of the pair or none */
 		off_i = (row0 + wave) * fs.linesize + x0 * 4u;
 		if (TRIO_BUF && s >= nst)
@@ -210,13 +276,13 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	/* both tables zeroed under the first loads */
 	{
 		const uint4 zero = make_uint4(0, 0, 0, 0);
-		for (u32 i = threadIdx.x * 4; i < TRIO_VSS_WORDS + nch * (TRIO_CH_BYTES / 4u); i += blockDim.x * 4)
+		for (u32 i = threadIdx.x * 4; i < TRIO_LDS_BYTES(nch) / 4u; i += blockDim.x * 4)
 			*(uint4 *)&tab[i] = zero;
 	}
 	__syncthreads();
 
 	VssLane st = {0xffffffffu, 0};
-	u32 lane_u = 0xffffffffu, lane_v = 0xffffffffu; /* TRIO_HASH 2: the lane's colour in pair form (vss_absorb_pair) */
+	u32 lane_u = 0xffffffffu, lane_v = 0xffffffffu; /* pair form: the lane's colour (vss_absorb_pair) */
 	(void)lane_u;
 	(void)lane_v;
 	bool absorb = false, wflat = false; /* wave-uniform */
@@ -227,8 +293,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	const u32 value = threadIdx.x >> 2, g4 = threadIdx.x & 3u;
 
 	for (u32 s_b = 0; s_b < nst; s_b++) {
-		const bool live_b = (first + s_b * stride) * 16u + 2u * pair < W; /* this lane's column pair exists in the strip */
+		const bool live_b = (first + s_b * stride) * (u32)SW + 2u * pair < W; /* this lane's column pair exists in the strip */
+		const bool strip_whole = (first + s_b * stride + 1u) * (u32)SW <= W;  /* ... and so does every lane's (uniform) */
 		(void)live_b;
+		(void)strip_whole;
 		for (u32 g_b = 0; g_b < Gp; g_b += (u32)D) {
 			/* the vectorscope's 16-bit counters: a clamp pass (every counter min(c, 255): exact, the reference saturates
 			 * at 255) before the round that could carry one past 65535 -- at round granularity, not per strip: a 4K strip is
@@ -237,17 +305,24 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 			if (since + round_px > VSS_EPOCH_PIXELS && !(TRIO_EXP & 8)) { /* uniform across the workgroup */
 				vss_flush_lane<TRIO_HASH>(tab, st); /* pending texels belong to the epoch that ends here */
 				__syncthreads();
-				vss_clamp_pass(tab, TRIO_VSS_WORDS);
+				vss_clamp_pass(vt, TRIO_VSS_WORDS);
 				__syncthreads();
 				since = 0;
 			}
 			since += round_px;
-#pragma unroll
-			for (int d = 0; d < D; d++) {
-				const bool v = TRIO_OK(d, g_b + (u32)d);
+			/* One slot = the two texels a lane loaded.  FAST: every lane of the wave holds a real texel pair (the strip is whole
+			 * and the slot lies inside the shortest row range of the wave: all but the last slots of a strip, all but a ragged
+			 * last strip) -- no validity mask and no exec-mask branches at all; the other slots run the checked form. */
+			auto slot = [&](auto fast_tag, const int d) __attribute__((always_inline)) {
+				constexpr bool FAST = decltype(fast_tag)::value;
+				const bool v = FAST || TRIO_OK(d, g_b + (u32)d);
+				if (!FAST && TRIO_SKIP_EMPTY && __ballot(v) == 0)
+					return; /* a slot no lane of the wave has a texel for: the rounding of a strip's slots up to whole rounds of D
+						 * (two of 36 at 4K) and the rows past a short last row range.  (Round 3 found this test too dear --
+						 * it sat in front of every slot; here only the checked form carries it.) */
 				const u32 p0 = px[d][0], p1 = px[d][1];
 				u32 key[2] = {p0, p1};
-				u32 pu[1] = {0}, pv[1] = {0}; /* TRIO_HASH 2: the slot's chroma in pair form */
+				u32 pu[1] = {0}, pv[1] = {0}; /* pair form: the slot's chroma */
 				if (v && !(TRIO_EXP & 1)) {
 					if (TRIO_WABSORB && wflat) {
 						/* Flat content -- EVERY lane of the wave held a horizontally equal texel pair at the last vote
@@ -263,49 +338,56 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 						} else {
 							if (wn) {
 								if ((wp0 >> 24) != 0)
-									trio_count<CH>(tab, wp0, lane_base, wn);
+									trio_count<CH, VS>(tab, wp0, lane_base, wn);
 								if ((wp1 >> 24) != 0)
-									trio_count<CH>(tab, wp1, lane_base, wn << 16);
+									trio_count<CH, VS>(tab, wp1, lane_base, wn << 16);
 							}
 							wp0 = p0;
 							wp1 = p1;
 							wn = 1;
 						}
 					} else {
-						if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
-							trio_count<CH>(tab, p0, lane_base, 1u);
-						if ((p1 >> 24) != 0)
-							trio_count<CH>(tab, p1, lane_base, 65536u);
+						if (FAST) {
+							/* the alpha test (src/waveform.c:247-248) as the increment: min(alpha, 1), in the low half for the even
+							 * column and in the high half for the odd one -- one SDWA instruction each, no exec mask, and the whole
+							 * slot is one basic block (adding 0 for a transparent texel changes nothing) */
+							trio_count<CH, VS>(tab, p0, lane_base, scope_min_byte3_lo(p0, 1u));
+							trio_count<CH, VS>(tab, p1, lane_base, scope_min_byte3_hi(p1, 1u));
+						} else {
+							if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
+								trio_count<CH, VS>(tab, p0, lane_base, 1u);
+							if ((p1 >> 24) != 0)
+								trio_count<CH, VS>(tab, p1, lane_base, 65536u);
+						}
 					}
 				}
 				if (TRIO_EXP & 4) {
 					key[0] = vss_bin(p0);
 					key[1] = vss_bin(p1);
-				} else if (TRIO_HASH == 2) {
+				} else if (TRIO_PAIR) {
 					scope_k0_cell_uv<1>(key, k0, pu, pv);
 				} else {
 					scope_k0_cell<2, true>(key, k0, true, false); /* wave votes inside: every lane goes through, valid or not */
 				}
 				if (((g_b + (u32)d) & 3u) == 0) { /* content is coherent: the verdict holds for four loads */
-					const bool same = TRIO_HASH == 2 ? ((pu[0] == scope_perm(0u, pu[0], 0x01000302u)) & (pv[0] == scope_perm(0u, pv[0], 0x01000302u)))
+					const bool same = TRIO_PAIR ? ((pu[0] == scope_perm(0u, pu[0], 0x01000302u)) & (pv[0] == scope_perm(0u, pv[0], 0x01000302u)))
 									 : key[0] == key[1];
 					const u32 flat_lanes = (u32)__popcll(__ballot(!v || same));
 					absorb = flat_lanes >= 48;
 					wflat = flat_lanes >= 64;
 				}
-				TRIO_ISSUE(d); /* ONE issue point per slot, whatever the slot held: the load queue has the same shape on every path */
 				if (!v || (TRIO_EXP & 2))
-					continue;
-				if (TRIO_HASH == 2) {
+					return;
+				if (TRIO_PAIR) {
 					if (absorb)
-						vss_absorb_pair(tab, st, lane_u, lane_v, pu[0], pv[0]);
+						vss_absorb_pair<TRIO_HASH>(tab, st, lane_u, lane_v, pu[0], pv[0]);
 					else
-						vss_add_pair(tab, pu[0], pv[0]);
+						vss_add_pair<TRIO_HASH>(tab, pu[0], pv[0]);
 				} else if (absorb) {
 					bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
 					if (!(e0 | e1)) {
 						if (st.count)
-							vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, st.colour, st.count);
+							vss_add<TRIO_HASH>(tab, st.colour, st.count);
 						st.colour = key[0];
 						st.count = 0;
 						e0 = true;
@@ -313,20 +395,29 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 					}
 					st.count += (u32)e0 + (u32)e1;
 					if (!e0)
-						vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, key[0], 1);
+						vss_add<TRIO_HASH>(tab, key[0], 1);
 					if (!e1)
-						vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, key[1], 1);
+						vss_add<TRIO_HASH>(tab, key[1], 1);
 				} else {
-					vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, key[0], 1);
-					vss_add<TRIO_HASH == 2 ? 0 : TRIO_HASH>(tab, key[1], 1);
+					vss_add<TRIO_HASH>(tab, key[0], 1);
+					vss_add<TRIO_HASH>(tab, key[1], 1);
 				}
+			};
+#pragma unroll
+			for (int d = 0; d < D; d++) {
+				if (TRIO_FASTSLOT && strip_whole && g_b + (u32)d < nv_min) /* wave-uniform */
+					slot(std::true_type{}, d);
+				else
+					slot(std::false_type{}, d);
+				TRIO_ISSUE(d); /* ONE issue point per slot, behind both forms: the load queue has the same shape (and the same
+						* registers) on every path */
 			}
 		}
 		if (TRIO_WABSORB && wn) { /* the waveform's pending pair belongs to this strip's table */
 			if ((wp0 >> 24) != 0)
-				trio_count<CH>(tab, wp0, lane_base, wn);
+				trio_count<CH, VS>(tab, wp0, lane_base, wn);
 			if ((wp1 >> 24) != 0)
-				trio_count<CH>(tab, wp1, lane_base, wn << 16);
+				trio_count<CH, VS>(tab, wp1, lane_base, wn << 16);
 			wn = 0;
 		}
 		const bool last_strip = s_b + 1u == nst;
@@ -335,27 +426,42 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		__syncthreads();
 		{
 			/* the strip's 256 x 16 waveform texels: thread -> (value, group of four columns); the reader of a counter zeroes it */
-			const u32 xs = (first + s_b * stride) * 16u;
-			const u32 groups = (min(W - xs, 16u)) >> 2;
-			u32 o[4] = {0, 0, 0, 0};
+			const u32 xs = (first + s_b * stride) * (u32)SW;
+			const u32 groups = (min(W - xs, (u32)SW)) >> 2; /* groups of four columns that exist */
+			constexpr u32 GPT = (u32)SW / 16u;              /* ... and how many of them a thread reads out, side by side */
+			u32 o[GPT][4] = {};
 #pragma unroll
 			for (u32 c = 0; c < 3; c++) {
 				if (!((CH >> c) & 1))
 					continue;
-				uint2 *w = (uint2 *)&wt[slot_of[c] * (TRIO_CH_BYTES / 4u) + (value << 3) + 2u * g4];
-				const uint2 q = *w;
-				*w = make_uint2(0, 0);
-				o[0] |= min(q.x & 0xffffu, 255u) << (8u * c);
-				o[1] |= min(q.x >> 16, 255u) << (8u * c);
-				o[2] |= min(q.y & 0xffffu, 255u) << (8u * c);
-				o[3] |= min(q.y >> 16, 255u) << (8u * c);
-				if (HIS) /* columns past the right edge were never counted: their counters are zero */
-					hs[c] += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16);
+#pragma unroll
+				for (u32 gq = 0; gq < GPT; gq++) {
+					uint2 *w = (uint2 *)&wt[slot_of[c] * CHW + value * VS + 2u * (g4 * GPT + gq)];
+					uint2 q = w[0];
+					w[0] = make_uint2(0, 0);
+#pragma unroll
+					for (u32 r = 1; r < REP; r++) { /* a column's total over the replicas is at most H <= 65 535: the halves never carry */
+						const uint2 qr = w[(P / 2u) * r];
+						w[(P / 2u) * r] = make_uint2(0, 0);
+						q.x += qr.x;
+						q.y += qr.y;
+					}
+					o[gq][0] |= min(q.x & 0xffffu, 255u) << (8u * c);
+					o[gq][1] |= min(q.x >> 16, 255u) << (8u * c);
+					o[gq][2] |= min(q.y & 0xffffu, 255u) << (8u * c);
+					o[gq][3] |= min(q.y >> 16, 255u) << (8u * c);
+					if (HIS) /* columns past the right edge were never counted: their counters are zero */
+						hs[c] += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16);
+				}
 			}
-			if (g4 < groups) {
-				uint8_t *table = wvs_dst + (size_t)frame * ((size_t)SCOPE_WVS_ROWS * W * 4);
-				const scope_v4 t = {o[0], o[1], o[2], o[3]};
-				__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g4 << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
+			uint8_t *table = wvs_dst + (size_t)frame * ((size_t)SCOPE_WVS_ROWS * W * 4);
+#pragma unroll
+			for (u32 gq = 0; gq < GPT; gq++) {
+				const u32 g = g4 * GPT + gq;
+				if (g < groups) {
+					const scope_v4 t = {o[gq][0], o[gq][1], o[gq][2], o[gq][3]};
+					__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
+				}
 			}
 		}
 		if (last_strip)
@@ -373,8 +479,22 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		u32 wrote = 0, k = 0;
 		for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
 			const u32 row = 255u - (g >> 4);
-			const u32 w0 = TRIO_HASH == 2 ? row * VSS_PITCH2 + ((g & 15u) << 3) : (row << 7) + (((g & 15u) << 3) ^ ((row & 15u) << 3));
-			const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
+			uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+			if (TRIO_HASH == 3) {
+				/* output group (row, k) = bins u in [16 k, 16 k + 15] = words 8 k - 4 .. 8 k + 3 of table row `row` - 16; what lies
+				 * outside the table (rows 0..15 and 241..255, u < 8, u >= 240) no colour reaches: zero */
+				const u32 k16 = g & 15u;
+				if (row - VSS3_V0 < VSS3_ROWS && k16 != 15u) {
+					const u32 w0 = (row - VSS3_V0) * VSS3_PITCH + (k16 << 3);
+					hi = *(const uint4 *)&vt[w0];
+					if (k16 != 0u)
+						lo = *(const uint4 *)&vt[w0 - 4u];
+				}
+			} else {
+				const u32 w0 = TRIO_HASH == 2 ? row * VSS_PITCH2 + ((g & 15u) << 3) : (row << 7) + (((g & 15u) << 3) ^ ((row & 15u) << 3));
+				lo = *(const uint4 *)&vt[w0];
+				hi = *(const uint4 *)&vt[w0 + 4];
+			}
 			if (!vss_mask) {
 				out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
 						    vss_clamp_pair(hi.z, hi.w));
@@ -432,34 +552,39 @@ struct TrioArgs {
 	hipStream_t st;
 	const ScopeTiming *tm;
 };
-template <int CH, bool HIS> hipError_t trio_variant(const TrioArgs *a)
+template <int CH, bool HIS, int SW> hipError_t trio_variant(const TrioArgs *a)
 {
 	constexpr u32 nch = (CH & 1) + ((CH >> 1) & 1) + ((CH >> 2) & 1);
-	constexpr u32 lds = TRIO_VSS_WORDS * 4u + nch * TRIO_CH_BYTES;
+	constexpr u32 lds = TRIO_LDS_BYTES(nch);
+	(void)nch; /* the compact map has one size for every mask */
 	if (!a)
-		return hipFuncSetAttribute((const void *)scope_trio_kernel<CH, HIS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	SCOPE_LAUNCH((scope_trio_kernel<CH, HIS>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), lds, a->st, a->tm, *a->fs,
+		return hipFuncSetAttribute((const void *)scope_trio_kernel<CH, HIS, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	SCOPE_LAUNCH((scope_trio_kernel<CH, HIS, SW>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), lds, a->st, a->tm, *a->fs,
 		     a->strips, a->slices, a->k0, a->wvs_dst, a->his, a->vss_dst, a->vss_mask);
 	return hipGetLastError();
 }
-template <bool HIS> hipError_t trio_pick_ch(u32 chmask, const TrioArgs *a)
+template <bool HIS, int SW> hipError_t trio_pick_ch(u32 chmask, const TrioArgs *a)
 {
 	switch (chmask & 7u) {
 	case 1:
-		return trio_variant<1, HIS>(a);
+		return trio_variant<1, HIS, SW>(a);
 	case 2:
-		return trio_variant<2, HIS>(a);
+		return trio_variant<2, HIS, SW>(a);
 	case 3:
-		return trio_variant<3, HIS>(a);
+		return trio_variant<3, HIS, SW>(a);
 	case 4:
-		return trio_variant<4, HIS>(a);
+		return trio_variant<4, HIS, SW>(a);
 	case 5:
-		return trio_variant<5, HIS>(a);
+		return trio_variant<5, HIS, SW>(a);
 	case 6:
-		return trio_variant<6, HIS>(a);
+		return trio_variant<6, HIS, SW>(a);
 	default:
-		return trio_variant<7, HIS>(a);
+		return trio_variant<7, HIS, SW>(a);
 	}
+}
+template <bool HIS> hipError_t trio_pick_sw(u32 sw, u32 chmask, const TrioArgs *a)
+{
+	return sw == 32u && TRIO_COMPACT ? trio_pick_ch<HIS, TRIO_COMPACT ? 32 : 16>(chmask, a) : trio_pick_ch<HIS, 16>(chmask, a);
 }
 
 } // namespace
@@ -467,12 +592,13 @@ template <bool HIS> hipError_t trio_pick_ch(u32 chmask, const TrioArgs *a)
 hipError_t scope_trio_init(void)
 {
 	hipError_t e = hipSuccess;
-	for (u32 chmask = 1; chmask <= 7; chmask++) {
-		if (e == hipSuccess)
-			e = trio_pick_ch<false>(chmask, NULL);
-		if (e == hipSuccess)
-			e = trio_pick_ch<true>(chmask, NULL);
-	}
+	for (u32 sw = 16; sw <= 32; sw += 16)
+		for (u32 chmask = 1; chmask <= 7; chmask++) {
+			if (e == hipSuccess)
+				e = trio_pick_sw<false>(sw, chmask, NULL);
+			if (e == hipSuccess)
+				e = trio_pick_sw<true>(sw, chmask, NULL);
+		}
 	return e;
 }
 
@@ -483,11 +609,23 @@ bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const Scop
 	       (u64)fs.height * fs.linesize < (1ull << 31);
 }
 
-uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu)
+/* 32-column strips (whole 128-byte lines, one waveform replica) where every CU still gets at least four of them; 16-column
+ * strips with replicas below that: the reference's call shape (one frame, the ring of three) then spreads over 240 workgroups */
+uint32_t scope_trio_strip_width(const ScopeFrameSet &fs, uint32_t num_cu, const ScopeTuning &tn)
 {
-	/* one workgroup per CU, every slice the same number of strips where that divides: 64 frames -> 4 slices of 60 strips,
-	 * three frames -> 80 of three, one -> 240 of one; even counts so that slices pair up (see the kernel) */
-	const u32 strips = scope_wvs_strips(fs.width, 1);
+	if (!TRIO_COMPACT || tn.trio_strip == 16)
+		return 16u;
+	if (tn.trio_strip == 32)
+		return 32u;
+	return (u64)fs.n_frames * ((fs.width + 31u) / 32u) >= 4ull * num_cu ? 32u : 16u;
+}
+
+uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu, uint32_t strip_width)
+{
+	/* one workgroup per CU, every slice the same number of strips where that divides: 64 frames -> 4 slices of 30 strips of 32
+	 * columns, three frames -> 80 slices of three 16-column strips, one -> 240 of one; even counts so that 16-column slices pair
+	 * up (see the kernel) */
+	const u32 strips = (fs.width + strip_width - 1u) / strip_width;
 	u32 s0 = max(1u, num_cu / max(1u, fs.n_frames));
 	s0 = min(min(s0, strips), 256u);
 	const u32 per = (strips + s0 - 1u) / s0;
@@ -497,16 +635,16 @@ uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu)
 	return min(s, 256u);
 }
 
-hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t chmask, int colorspace, uint8_t *wvs_dst,
-			     const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st, const ScopeTiming *tm)
+hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t strip_width, uint32_t chmask, int colorspace,
+			     uint8_t *wvs_dst, const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st,
+			     const ScopeTiming *tm)
 {
-	if ((chmask & 7u) == 0 || slices == 0 || slices > 256u || (slices > 1 && !vss_mask))
+	if ((chmask & 7u) == 0 || slices == 0 || slices > 256u || (slices > 1 && !vss_mask) || (strip_width != 16u && strip_width != 32u))
 		return hipErrorInvalidValue;
 	ScopeWvsHis h = {NULL, NULL, NULL, 0};
 	if (his)
 		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
-	const TrioArgs a = {&fs, scope_wvs_strips(fs.width, 1), slices, scope_k0_matrix(colorspace), wvs_dst, h, vss_dst,
+	const TrioArgs a = {&fs, (fs.width + strip_width - 1u) / strip_width, slices, scope_k0_matrix(colorspace), wvs_dst, h, vss_dst,
 			    slices > 1 ? vss_mask : NULL, st, tm};
-	return his ? trio_pick_ch<true>(chmask, &a) : trio_pick_ch<false>(chmask, &a);
+	return his ? trio_pick_sw<true>(strip_width, chmask, &a) : trio_pick_sw<false>(strip_width, chmask, &a);
 }
-

@@ -189,6 +189,21 @@ SCOPE_SHL_SEL(scope_shl_by_byte0, "BYTE_0", "DWORD") /* value << (count & 31) */
 SCOPE_SHL_SEL(scope_shl_by_byte2, "BYTE_2", "DWORD") /* value << (count >> 16 & 31) */
 #undef SCOPE_SHL_SEL
 
+/* min(byte 3 of x, cap) in the low half / in the high half (low half zero) of the result: the waveform's alpha test as an
+ * increment, one SDWA instruction (byte select on the source, word select + zero padding on the destination). */
+__device__ __forceinline__ unsigned scope_min_byte3_lo(unsigned x, unsigned cap)
+{
+	unsigned r;
+	asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(x), "s"(cap));
+	return r;
+}
+__device__ __forceinline__ unsigned scope_min_byte3_hi(unsigned x, unsigned cap)
+{
+	unsigned r;
+	asm("v_min_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(x), "s"(cap));
+	return r;
+}
+
 /* A wave-uniform value pinned into a VECTOR register for the rest of the kernel.  v_mad_i32_i24 takes one scalar operand
  * (gfx9 constant bus): with coefficient AND constant term in SGPRs hipcc moves the constant into a VGPR again before every
  * multiply-add -- one VALU instruction per matrix row and cell in the fused kernels.  The asm is opaque, so the copy is

@@ -148,6 +148,14 @@ static inline unsigned scope_pk_mad_u16(unsigned a, unsigned b, unsigned c)
 	const unsigned hi = ((a >> 16) * (b >> 16) + (c >> 16)) & 0xffffu;
 	return lo | (hi << 16);
 }
+static inline unsigned scope_min_byte3_lo(unsigned x, unsigned cap)
+{
+	return (x >> 24) < cap ? (x >> 24) : cap;
+}
+static inline unsigned scope_min_byte3_hi(unsigned x, unsigned cap)
+{
+	return scope_min_byte3_lo(x, cap) << 16;
+}
 static inline unsigned scope_shl_word0(unsigned count, unsigned value)
 {
 	return (value & 0xffffu) << (count & 31u);

@@ -12,7 +12,7 @@ COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
 
 
 DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 0, "vss.hash": 0, "vss.fused_hash": -1, "vss.groups": -1, "his.unroll": 0, "wvs.wide": 1, "wvs.strip": 0, "wvs.deep": 1, "dock": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.block": 0, "his.block": 0,
-            "nt": 1, "slices": 0}
+            "nt": 1, "slices": 0, "trio.strip": 0, "vss.run": 0}
 
 
 class options:

@@ -179,6 +179,20 @@ def test_three_scopes_one_read(emul_ctx, oracle, dock):
             dev(16, 4090, [3], reps=1)                    # a tall flat strip: clamp passes inside the strip
 
 
+@pytest.mark.parametrize("strip", [16, 32])
+def test_three_scopes_strip_widths(emul_ctx, oracle, strip):
+    """scope_trio_kernel's two shapes: 16-column strips with waveform replicas (two; four for a one-channel mask) and 32-column
+    strips with one -- ragged last strips, fewer rows than a wave's row ranges, clamp passes, every mask width."""
+    with pc.options(emul_ctx, **{"trio.strip": strip}):
+        dev = lambda *a, **k: pc.check_three_scopes_dev(emul_ctx, oracle, _np_dev, lambda hnd: hnd, *a, **k)  # noqa: E731
+        dev(72, 19, [5])                                  # the last strip 8 columns wide
+        dev(100, 37, [1, 2], 0x07, 0x03, 100 * 4 + 24, 1)  # ragged (100 = 3 * 32 + 4), padded pitch, BT.601, two frames
+        dev(64, 150, [3], 0x04, 0x04, reps=1)             # one channel, flat: four replicas of one counter
+        dev(36, 3, [1], 0x06, 0x02, reps=2)               # three rows: most row ranges of a wave are empty
+        dev(32, 2100, [3, 1, 5], reps=1)                  # clamp passes between and inside strips
+        dev(200, 40, [1, 5, 2, 4], 0x05, 0x05, reps=1)
+
+
 def test_three_scopes_host_planes(emul_ctx, oracle):
     pc.check_three_scopes_host(emul_ctx, oracle, 72, 19, 5)
     pc.check_three_scopes_host(emul_ctx, oracle, 70, 9, 1, 0x05, 0x04, colorspace=1)

@@ -229,6 +229,27 @@ def test_three_scopes_batches_one_read(hip_ctx, oracle):
     dev(7680, 4320, [1], reps=1)  # BASELINE config 4's frame: 480 strips, 240 slices of two, clamp passes inside a strip
 
 
+@pytest.mark.parametrize("strip", [16, 32])
+def test_three_scopes_strip_widths(hip_ctx, oracle, strip):
+    """scope_trio_kernel's two shapes forced on launches of every size: 16-column strips with waveform replicas, 32-column strips
+    with one replica (what batches run by default); 4K content of every kind, one- and two-channel masks, ragged widths."""
+    to_dev, to_host = _torch_dev()
+
+    def dev(*a, **k):
+        pc.check_three_scopes_dev(hip_ctx, oracle, to_dev, to_host, *a, **k)
+
+    with pc.options(hip_ctx, **{"trio.strip": strip}):
+        dev(3840, 2160, [1, 2, 3, 4, 5, 1, 3, 2], reps=1)
+        dev(3840, 2160, [5], 0x02, 0x02, reps=1)
+        dev(3840, 2160, [1, 3], 0x05, 0x04, reps=1)
+        dev(1924, 1083, [1, 2], 0x07, 0x05, 1924 * 4 + 64, colorspace=1, reps=1)
+        for comp in (0x01, 0x03, 0x04, 0x06):
+            dev(328, 77, [5, 3], comp, comp, reps=1)
+        dev(100, 5, [1], reps=2)
+        dev(320, 180, [(i % 5) + 1 for i in range(64)], reps=1)
+        dev(7680, 4320, [2], reps=1)
+
+
 @pytest.mark.parametrize("strip", [16, 64])
 def test_waveform_strip_widths(hip_ctx, oracle, strip):
     """Both shapes a small launch can take -- 16-column strips (eight rows per wave instruction into four table

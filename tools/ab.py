@@ -68,7 +68,7 @@ def main():
                     fn = lambda: c.vectorscope_batch_dev(b, out, sync=False)  # noqa: E731
                 elif wl == "three_scope":
                     b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
-                    fn = lambda: c.three_scopes_batch_dev(b, 0x07, 0x07, o_vss, o_wvs, o_his, sync=False)  # noqa: E731
+                    fn = lambda: c.three_scopes_batch_dev(b, comp, comp, o_vss, o_wvs, o_his, sync=False)  # noqa: E731
                 elif wl.startswith("histogram"):
                     b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
                     fn = lambda: c.histogram_counts_batch_dev(b, comp, out, sync=False)  # noqa: E731
