@@ -125,7 +125,10 @@ int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
  *   "wvs.wide" 0|1, "wvs.persist" 0|1, "wvs.per_cu" 0|1|2   waveform load shape / persistent walk / workgroups per CU
  *   "wvs.strip" 0|16|64      waveform strip width: 16 columns for launches that would otherwise need row bands (0), or fixed
  *   "wvs.deep" 0|1           batches: more loads in flight across each unit's table flush
- *   "dock" 0|1               scope_three_scopes_batch: one read for small launches (1) or always two passes (0)
+ *   "dock" 0|1|2             scope_three_scopes_batch: one read of the planes for any launch (1, scope_trio_kernel), round 2's form
+ *                            (2: one read for one-round launches only) or always two passes (0)
+ *   "trio.strip" 0|16|32     scope_trio_kernel's strip width: 32 columns (whole 128-byte lines, one waveform replica) for batches
+ *                            and 16 (two replicas; four for a one-channel mask) for launches of a few frames (0), or fixed
  *   "fold" 0|1   the slices of a histogram frame meet inside the launch (atomics + last arrival) | partial tables + a second kernel
  *   "vss.sparse" 0|1   vectorscope partial tables hold only the 16-bin groups that are not empty
  *   "nt" 0|1     streaming (non-temporal) loads
@@ -208,12 +211,11 @@ int scope_waveform_histogram(scope_ctx *ctx, const struct scope_surface_data *sd
  * All three scopes of every frame of a batch of RGB planes (b->planes_are_rgb; the vectorscope goes through the fused K0
  * with b->colorspace): vss_out = uint8[n][256][256], wvs_out = uint8[n][256][width][4], his_counts = uint32[n][256][4],
  * exactly the tables of scope_vectorscope_batch (SCOPE_FUSE_K0 semantics), scope_waveform_batch and
- * scope_histogram_counts_batch.  For device-resident planes and tables (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE), RGB
- * component masks (the histogram's a subset of the waveform's) and a launch of one round of 16-column strips -- one 4K
- * frame, the reference's call shape (src/common.c:366-368) -- the planes are read ONCE: a strip's texels stay in
- * registers and are walked for the waveform (the histogram riding on its flush) and again for the vectorscope.  Any
- * other combination runs the vectorscope's pass and then the waveform's with the histogram on it.  All three outputs
- * are host or all device. */
+ * scope_histogram_counts_batch.  For device-resident planes and tables (SCOPE_IN_DEVICE | SCOPE_OUT_DEVICE), RGB component
+ * masks (the histogram's a subset of the waveform's), width % 4 == 0 and height <= 65535 the planes are read ONCE, whatever
+ * the number of frames (scope_trio_kernel: the vectorscope's table and a waveform table of one strip of columns both live
+ * in the LDS, the histogram rides on the waveform's read-out).  Any other combination runs the vectorscope's pass and then
+ * the waveform's with the histogram on it.  All three outputs are host or all device. */
 int scope_three_scopes_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t wvs_components, uint32_t his_components,
 			     uint32_t flags, uint8_t *vss_out, uint8_t *wvs_out, uint32_t *his_counts);
 int scope_waveform_histogram_batch(scope_ctx *ctx, const struct scope_batch *b, uint32_t wvs_components,

@@ -9,36 +9,33 @@
 #include "scope_device.h"
 
 /* ------------------------------------------------------------------------------------------
- * The dock's three scopes from ONE read, for ANY number of frames: scope_trio_kernel (round 3).
+ * The dock's three scopes from ONE read, for ANY number of frames: scope_trio_kernel.
  *
- * scope_dock_kernel (scope_kernels.hip, round 2) reads a frame once but only where one round of strips covers the launch (one 4K frame), because it
- * time-shares the LDS between the waveform's and the vectorscope's table and has to hold a strip's texels in registers in
- * between; the ring of three and every batch fell back to two reads of the planes (1.91 x the algorithmic traffic).
+ * BOTH tables are resident in the LDS: the vectorscope's (16-bit counters; the compact HASH 3 form of scope_device.h: only
+ * the chroma K0 can produce, 104 400 bytes) and a waveform table of ONE strip of columns (48 KiB; the map is described at
+ * TRIO_COMPACT below).  A workgroup owns strips of one frame and streams them like any other kernel here: every texel is
+ * loaded once (8 bytes = a column pair per lane, TRIO_D loads per lane in flight, buffer addressing), counted in the waveform
+ * table (alpha test, src/waveform.c:247-248), sent through the fixed-point K0 and counted in the vectorscope table.  Per
+ * strip: barrier, the waveform's 256 x SW output texels leave (the thread that reads a counter zeroes it; the histogram's
+ * totals accumulate in three registers per thread over all strips of the slice), barrier; the loads of the next strip are in
+ * flight across it.  The vectorscope's clamp pass runs before the round of loads that could overflow 16 bits.  Per slice:
+ * ONE vectorscope partial (sparse, as scope_vss_kernel writes them; the final table when the frame has one slice) and
+ * <= 768 device atomics for the histogram.
  *
- * Here BOTH tables are resident: the vectorscope's 128 KiB (16-bit counters, swizzled rows, as scope_vss_kernel) plus a
- * waveform table of ONE replica for a 16-column strip -- 256 values x 8 column pairs x 4 bytes = 8 KiB per channel, 24 KiB
- * for RGB -- 152 KiB of the CU's 160.  A workgroup owns the strips of one slice of one frame and streams them like any
- * other kernel here: every texel is loaded once, counted in the waveform table (alpha test, src/waveform.c:247-248), sent
- * through the fixed-point K0 and counted in the vectorscope table, with TRIO_D loads per lane in flight and no register-held
- * strip.  Per strip: barrier, the waveform's 256 x 16 output texels leave (the thread that reads a counter zeroes it, the
- * histogram's totals accumulate in three registers per thread over all strips of the slice), barrier; the loads of the next
- * strip are in flight across it.  The vectorscope's clamp pass runs before the round of loads that could overflow 16 bits.  Per
- * slice: ONE vectorscope partial (sparse, as scope_vss_kernel writes them; the final table when the frame has one slice)
- * and <= 768 device atomics for the histogram.  64 frames: 4 slices of 60 strips per frame; three frames: 80 slices of
- * three strips; one frame: 240 slices of one -- the dock kernel's shape.
+ * Launch shapes (scope_trio_strip_width / scope_trio_slices): batches run 32-column strips -- 64 frames of 4K: 4 slices per
+ * frame, slice s walks strips s, s + 4, ... (30 each); the reference's call shape runs 16-column strips so that it still
+ * spreads over the chip -- three frames: 80 slices of three strips, one frame: 240 slices of one.  The rows of a wave
+ * instruction lie H / 4 (32 columns) or H / 8 (16) apart, so that the equal values of vertically neighbouring texels do not
+ * meet on one ADDRESS.  With 16-column strips a row segment is half a cache line: slices come in pairs that split a range of
+ * strips even / odd, and the two workgroups of a pair are b and b + 8 (same XCD, same L2, same moment).
  *
- * What the single replica costs: a half wave is 4 rows x 8 column pairs, word = value * 8 + pair, so two rows whose values
- * agree mod 4 meet in one bank (2.1 x the conflict-free time on noise by the bank model of profiles/round1/
- * lds_atomic_microbench.txt) -- LDS issue, not HBM, bounds this kernel.  The eight rows of a wave instruction lie H/8 apart
- * (as in scope_dock_kernel), so that the equal values of vertically neighbouring texels do not meet on one ADDRESS.
- *
- * A strip's row segment is 64 bytes, half a cache line.  Slices come in pairs that split a range of strips even / odd, and
- * the two workgroups of a pair are b and b + 8 (same XCD, same L2, same moment): the other half of every line is wanted by
- * the partner while it is still in the L2.
- * Tried and dropped: skipping the K0 / vote work of slots that are empty for a whole wave (one of 18 per strip at 4K; the
- * uniform branch around a slot's work cost hipcc's schedule of the round 8 %: 632 -> 685 us for 64 x 4K), deeper or
- * shallower load queues (4 / 8 / 12 per lane: 674 / 739 / 738 us against 641 at 6 -- a strip's 17 slots are rounded up to
- * whole rounds of D, and empty slots still run K0); profiles/round3/trio_variants.txt.
+ * What bounds it (profiles/round4/pmc_sq_three_scope_x64_b5.txt, trio_variants.txt): VALU issue.  30 VALU instructions per
+ * texel (K0 11.5, the waveform's three adds 7, the vectorscope's 3.5, the rest loop, read-outs, clamp passes) keep each SIMD's
+ * VALU busy 70 % of the kernel with the four waves a 1024-thread workgroup gives it, and the LDS footprint allows one
+ * workgroup per CU.  Round 4 measured every other suspect out: halving the waveform's bank conflicts (two replicas) +0 %,
+ * whole-line loads and half the barriers (32-column strips) +3 ... 5 %, pair-form vectorscope adds +2 %, a slot without any
+ * exec-mask branch +0.5 %, skipping the slots a strip's rounding leaves empty +2 %, more or fewer loads in flight 0 %.
+ * Tried and dropped in round 3: deeper or shallower load queues, skipping K0 work of empty slots in front of EVERY slot.
  * Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables), H <= 65535 (a column's rows fit the waveform's
  * 16-bit counters).
  * ---------------------------------------------------------------------------------------- */

@@ -12,7 +12,7 @@ COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
 
 
 DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 0, "vss.hash": 0, "vss.fused_hash": -1, "vss.groups": -1, "his.unroll": 0, "wvs.wide": 1, "wvs.strip": 0, "wvs.deep": 1, "dock": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.block": 0, "his.block": 0,
-            "nt": 1, "slices": 0, "trio.strip": 0, "vss.run": 0}
+            "nt": 1, "slices": 0, "trio.strip": 0}
 
 
 class options:
@@ -61,6 +61,55 @@ def check_vectorscope(ctx, oracle, w, h, dist, linesize=None, fuse=False, colors
         got, st = ctx.vectorscope(yuv=yuv, width=w)
     assert st == 0
     assert_same(got, want, f"vectorscope {w}x{h} d{dist} ls{linesize} fuse{fuse}")
+
+
+def screen_frame(w, h, seed, detail=0.03, rects=12, linesize=None, grey=False, alpha_noise=False):
+    """Screen-capture-like content for the absorb mode of the vectorscope kernels: a flat background, flat rectangles, a sprinkle of
+    single-texel detail; grey=True: every colour a grey (the chroma never changes while the RGB does); alpha_noise: random alpha
+    bytes (the vectorscope ignores alpha, src/vectorscope.c:217-238: runs must not break on it)."""
+    rng = np.random.default_rng(seed)
+
+    def colour():
+        c = rng.integers(0, 256, 3, dtype=np.uint8)
+        return np.array([c[0]] * 3, np.uint8) if grey else c
+
+    img = np.empty((h, w, 4), np.uint8)
+    img[..., :3] = colour()
+    for _ in range(rects):
+        x0, y0 = int(rng.integers(0, max(w - 1, 1))), int(rng.integers(0, max(h - 1, 1)))
+        ww, hh = int(rng.integers(1, max(w // 2, 2))), int(rng.integers(1, max(h // 2, 2)))
+        img[y0:y0 + hh, x0:x0 + ww, :3] = colour()
+    mask = rng.random((h, w)) < detail
+    n = int(mask.sum())
+    d = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    img[..., :3][mask] = np.repeat(d[:, :1], 3, axis=1) if grey else d
+    img[..., 3] = rng.integers(0, 256, (h, w), dtype=np.uint8) if alpha_noise else 255
+    ls = linesize or 4 * w
+    out = np.zeros((h, ls), np.uint8)
+    out[:, : 4 * w] = img.reshape(h, 4 * w)
+    return out
+
+
+def check_vectorscope_rgb_frame(ctx, oracle, rgb, w, colorspace=2, what=""):
+    """The fused-K0 vectorscope of an arbitrary RGB plane against oracle K0 + oracle K1."""
+    want = oracle.vectorscope(oracle.rgb_to_yuv(rgb, w, colorspace), w)
+    got, st = ctx.vectorscope(rgb=rgb, width=w, colorspace=colorspace, fuse_k0=True)
+    assert st == 0
+    assert_same(got, want, f"fused vectorscope {w}x{rgb.shape[0]} cs{colorspace} {what}")
+
+
+def check_fused_screen_content(ctx, oracle, sizes, forced):
+    """The fused vectorscope on screen-like content -- flat areas, rectangles, sprinkled detail, greys (the chroma never changes
+    while the RGB does), random alpha -- and on the oracle's distributions, with the absorb mode by wave vote (vss.merge 3, the
+    default) or forced on ANY content (vss.merge 2: on noise nearly every cell takes the mixed road)."""
+    with options(ctx, **{"vss.merge": 2 if forced else 3}):
+        for (w, h, ls) in sizes:
+            for seed, kw in enumerate(({}, {"detail": 0.0}, {"detail": 0.3}, {"grey": True}, {"alpha_noise": True, "detail": 0.01},
+                                       {"rects": 200, "detail": 0.0})):
+                rgb = screen_frame(w, h, 77 + seed, linesize=ls, **kw)
+                check_vectorscope_rgb_frame(ctx, oracle, rgb, w, 1 + seed % 2, f"screen {kw} forced={forced}")
+            for dist in (1, 2, 3, 4, 5):
+                check_vectorscope(ctx, oracle, w, h, dist, ls, fuse=True, colorspace=2)
 
 
 def check_waveform(ctx, oracle, w, h, dist, components, linesize=None, fuse=False, colorspace=2):

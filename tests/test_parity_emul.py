@@ -158,6 +158,19 @@ def test_waveform_deep_queue_across_flushes(emul_ctx, oracle):
         pc.check_waveform(emul_ctx, oracle, 512, 265, 1, 0x20, None, fuse=True, colorspace=2)
 
 
+@pytest.mark.parametrize("forced", [0, 1])
+def test_fused_vectorscope_screen_content(emul_ctx, oracle, forced):
+    """Screen-like content (flat areas, rectangles, sprinkled detail, greys, random alpha) and the oracle's distributions through
+    the fused vectorscope with the absorb mode voted / forced; several unroll factors, one workgroup per frame (clamp passes between
+    runs) and the default slicing, a padded pitch and a ragged width."""
+    for slices, unroll in ((0, 0), (1, 4), (2, 2), (1, 1)):
+        with pc.options(emul_ctx, **{"slices": slices, "vss.fused_unroll": unroll}):
+            pc.check_fused_screen_content(emul_ctx, oracle, [(256, 96, None), (132, 50, 132 * 4 + 16)] if slices == 0 else [(160, 64, None)], forced)
+    with pc.options(emul_ctx, slices=1):
+        rgb = pc.screen_frame(512, 300, 5, detail=0.0, rects=0)   # one colour, 153 600 texels in one workgroup: counts past 65 535
+        pc.check_vectorscope_rgb_frame(emul_ctx, oracle, rgb, 512, 2, "one flat colour")
+
+
 @pytest.mark.parametrize("dock", [1, 2, 0])
 def test_three_scopes_one_read(emul_ctx, oracle, dock):
     """One read of the plane for waveform + histogram + vectorscope.  dock=1: scope_trio_kernel (both tables resident in LDS,

@@ -408,6 +408,30 @@ def test_fused_vectorscope_layouts_and_modes(hip_ctx, oracle, merge, hash_):
             pc.check_vectorscope(hip_ctx, oracle, 509, 130, 2, 2048, fuse=True, colorspace=1)
 
 
+@pytest.mark.parametrize("forced", [0, 1])
+def test_fused_vectorscope_screen_content(hip_ctx, oracle, forced):
+    """The fused vectorscope on screen-like content -- flat areas, rectangles, sprinkled detail, greys, random alpha -- and the
+    oracle's distributions, with the absorb mode voted and forced, at 4K, on small ragged frames, with one workgroup per frame
+    and with the batch's unroll; then a batch of 4K screen frames as bench.py --dist screen launches them."""
+    pc.check_fused_screen_content(hip_ctx, oracle, [(3840, 2160, None)], forced)
+    for slices, unroll in ((0, 0), (1, 4), (1, 2), (7, 1)):
+        with pc.options(hip_ctx, **{"slices": slices, "vss.fused_unroll": unroll}):
+            pc.check_fused_screen_content(hip_ctx, oracle, [(640, 360, None), (509, 130, 2048)], forced)
+    # a batch of eight 4K frames of screen content, as bench.py --dist screen launches them (device planes)
+    import torch
+
+    w, h, n = 3840, 2160, 8
+    frames_ = [pc.screen_frame(w, h, 900 + i, detail=0.03, rects=300) for i in range(n)]
+    d = torch.from_numpy(np.stack(frames_)).cuda()
+    b = hip_ctx.make_device_batch(d, 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+    out = torch.empty((n, 256, 256), dtype=torch.uint8, device="cuda")
+    with pc.options(hip_ctx, **{"vss.merge": 2 if forced else 3}):
+        hip_ctx.vectorscope_batch_dev(b, out)
+    got = out.cpu().numpy()
+    for i in range(n):
+        pc.assert_same(got[i], oracle.vectorscope(oracle.rgb_to_yuv(frames_[i], w, 2), w), f"screen batch frame {i} forced={forced}")
+
+
 @pytest.mark.parametrize("cs", [1, 2])
 @pytest.mark.parametrize("hash_", [0, 1, 2])
 def test_fused_vectorscope_all_colours(hip_ctx, oracle, cs, hash_):
