@@ -286,8 +286,13 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	u32 wp0 = 0, wp1 = 0, wn = 0; /* the waveform's pending texel pair and how often it came (absorb mode) */
 	u32 since = 0;       /* texels the vectorscope table may have taken since its last clamp pass (uniform) */
 	const u32 round_px = (u32)D * blockDim.x * 2u; /* texels a round of D slots can add (upper bound: every lane valid) */
-	u32 hs[3] = {0, 0, 0}; /* HIS: this thread's (value, column group) totals over the slice's strips */
-	const u32 value = threadIdx.x >> 2, g4 = threadIdx.x & 3u;
+	/* The strip's read-out: 256 values x SW / 4 groups of four columns = NV items per thread (1024 threads).  Item j of thread t
+	 * is value (t >> GL) + (1024 >> GL) j, group t & (2^GL - 1): the lanes of ONE store instruction cover whole value rows --
+	 * 64 contiguous bytes per value with 16-column strips, 128 with 32 (a thread holding two NEIGHBOURING groups instead made
+	 * every store instruction write every other 16 bytes: PMC WRITE_SIZE 1.36 x, visit d1). */
+	constexpr u32 NV = (u32)SW / 16u, GL = SW == 32 ? 3u : 2u;
+	u32 hs[3][NV] = {}; /* HIS: this thread's (value, column group) totals over the slice's strips */
+	const u32 value0 = threadIdx.x >> GL, g4 = threadIdx.x & ((1u << GL) - 1u);
 
 	for (u32 s_b = 0; s_b < nst; s_b++) {
 		const bool live_b = (first + s_b * stride) * (u32)SW + 2u * pair < W; /* this lane's column pair exists in the strip */
@@ -425,15 +430,14 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 			/* the strip's 256 x 16 waveform texels: thread -> (value, group of four columns); the reader of a counter zeroes it */
 			const u32 xs = (first + s_b * stride) * (u32)SW;
 			const u32 groups = (min(W - xs, (u32)SW)) >> 2; /* groups of four columns that exist */
-			constexpr u32 GPT = (u32)SW / 16u;              /* ... and how many of them a thread reads out, side by side */
-			u32 o[GPT][4] = {};
+			u32 o[NV][4] = {};
 #pragma unroll
 			for (u32 c = 0; c < 3; c++) {
 				if (!((CH >> c) & 1))
 					continue;
 #pragma unroll
-				for (u32 gq = 0; gq < GPT; gq++) {
-					uint2 *w = (uint2 *)&wt[slot_of[c] * CHW + value * VS + 2u * (g4 * GPT + gq)];
+				for (u32 j = 0; j < NV; j++) {
+					uint2 *w = (uint2 *)&wt[slot_of[c] * CHW + (value0 + (1024u >> GL) * j) * VS + 2u * g4];
 					uint2 q = w[0];
 					w[0] = make_uint2(0, 0);
 #pragma unroll
@@ -443,21 +447,21 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 						q.x += qr.x;
 						q.y += qr.y;
 					}
-					o[gq][0] |= min(q.x & 0xffffu, 255u) << (8u * c);
-					o[gq][1] |= min(q.x >> 16, 255u) << (8u * c);
-					o[gq][2] |= min(q.y & 0xffffu, 255u) << (8u * c);
-					o[gq][3] |= min(q.y >> 16, 255u) << (8u * c);
+					o[j][0] |= min(q.x & 0xffffu, 255u) << (8u * c);
+					o[j][1] |= min(q.x >> 16, 255u) << (8u * c);
+					o[j][2] |= min(q.y & 0xffffu, 255u) << (8u * c);
+					o[j][3] |= min(q.y >> 16, 255u) << (8u * c);
 					if (HIS) /* columns past the right edge were never counted: their counters are zero */
-						hs[c] += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16);
+						hs[c][j] += (q.x & 0xffffu) + (q.x >> 16) + (q.y & 0xffffu) + (q.y >> 16);
 				}
 			}
-			uint8_t *table = wvs_dst + (size_t)frame * ((size_t)SCOPE_WVS_ROWS * W * 4);
+			if (g4 < groups) {
+				uint8_t *table = wvs_dst + (size_t)frame * ((size_t)SCOPE_WVS_ROWS * W * 4);
 #pragma unroll
-			for (u32 gq = 0; gq < GPT; gq++) {
-				const u32 g = g4 * GPT + gq;
-				if (g < groups) {
-					const scope_v4 t = {o[gq][0], o[gq][1], o[gq][2], o[gq][3]};
-					__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
+				for (u32 j = 0; j < NV; j++) {
+					const scope_v4 t = {o[j][0], o[j][1], o[j][2], o[j][3]};
+					__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g4 << 2)) * 4) +
+									       (size_t)(255u - (value0 + (1024u >> GL) * j)) * (W >> 2));
 				}
 			}
 		}
@@ -508,19 +512,25 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	}
 	if (HIS) {
 		/* the slice's totals -> the frame's accumulator, then the arrival ticket; the workgroup that completes the frame moves the
-		 * sums out and leaves accumulator and ticket zero.  The four column groups of a value meet in LDS first (the vectorscope
+		 * sums out and leaves accumulator and ticket zero.  The column groups of a value meet in LDS first (the waveform
 		 * table's space, read out by now): ONE device atomic per value and channel and workgroup.  (Four lanes of a wave
 		 * instruction on one address cost dearly at the memory side: a one-frame launch of 240 workgroups took 440 us that way.) */
 		u32 *acc_g = his.acc + (size_t)frame * SCOPE_HIS_WORDS;
 		__syncthreads();
 #pragma unroll
 		for (u32 c = 0; c < 3; c++)
-			tab[c * 1024u + threadIdx.x] = hs[c];
+#pragma unroll
+			for (u32 j = 0; j < NV; j++)
+				tab[(c * NV + j) * 1024u + threadIdx.x] = hs[c][j]; /* = [c][value][group]: item j's value is (1024 >> GL) j further */
 		__syncthreads();
 		for (u32 t2 = threadIdx.x; t2 < 768u; t2 += blockDim.x) {
 			const u32 c = t2 >> 8, val = t2 & 255u;
-			const uint4 q = *(const uint4 *)&tab[c * 1024u + 4u * val];
-			const u32 sum = q.x + q.y + q.z + q.w;
+			u32 sum = 0;
+#pragma unroll
+			for (u32 i = 0; i < NV; i++) {
+				const uint4 q = *(const uint4 *)&tab[c * NV * 1024u + (val << GL) + 4u * i];
+				sum += q.x + q.y + q.z + q.w;
+			}
 			if (sum && (((CH & his.chmask) >> c) & 1u))
 				__hip_atomic_fetch_add(&acc_g[(2u - c) * 256u + val], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}

@@ -140,14 +140,14 @@ def test_gpus8_config4_real_tile_self_launched(shm_rccl):
     assert "8 row tile(s) of 7680x540" in c4["partition"]
 
 
-def test_gpus4_config4_real_frame_self_launched(shm_rccl):
-    rc, d, err = run_bench(["--gpus", "4", *SMALL, "--config4-geometry", "7680x4320", "--config4-frames", "1", "--strong"], clean_env(),
+def test_gpus4_config4_row_tiles_self_launched(shm_rccl):
+    rc, d, err = run_bench(["--gpus", "4", *SMALL, "--config4-geometry", "1920x1080", "--config4-frames", "2", "--strong"], clean_env(),
                            timeout=900)
     assert rc == 0, err[-3000:]
     assert d["n_gpus"] == 4 and d["parity"].startswith("bit-exact")
     assert d["launcher"]["attempts"][0]["exit_codes"] == [0] * 4 and d["config"]["rccl"]["ranks_in_communicator"] == 4
     c4 = d["config4"]
-    assert c4["parity"] is True and c4["rccl_ranks_in_communicator"] == 4 and c4["rows_of_this_rank"] == [0, 1080]
+    assert c4["parity"] is True and c4["rccl_ranks_in_communicator"] == 4 and c4["rows_of_this_rank"] == [0, 270]
 
 
 def test_gpus8_under_torch_distributed_run(shm_rccl):
