@@ -1162,14 +1162,13 @@ class Legs:
         tr, _ = pmc_traffic(wl, self.n, self.w, self.h, comp == 0x07 and vw.linesize == 4 * self.w)
         vr = roofline(wl, vw.algo_bytes, ln, kms, sus["ms_per_step"], tr)
         if wl == "three_scope":
-            # SURVEY 8(d)'s config-5 bytes (ONE read of the frames + the three tables) over the whole step.  The label
-            # "hbm" would flatter this workload: with four LDS atomics and K0 per pixel its own ceiling is LDS / VALU
-            # issue, which profiles/round1/lds_atomic_microbench.txt prices at about 1.3 Tpix/s = 0.64 of the HBM peak.
-            vr["bound"] = "lds/valu issue (4 LDS atomics + K0 per pixel); hbm is the yardstick, not the ceiling"
-            vr["ceiling_estimate"] = {"gpix_per_s": 1100, "frac_of_hbm_peak": 0.62,
-                                      "from": "the larger of LDS issue (3 waveform adds at 2.1 x the conflict-free 4.5 clk per wave instruction "
-                                              "-- one table replica -- + 1 vectorscope add at 7.5: 0.56 clk per pixel and CU) and VALU issue "
-                                              "(31.3 instructions per pixel / 64 lanes per clk = 0.49), 256 CUs at 2.4 GHz; DESIGN.md 3.8"}
+            # SURVEY 8(d)'s config-5 bytes (ONE read of the frames + the three tables).  The label "hbm" would flatter this
+            # workload: its ceiling is VALU issue (profiles/round4/pmc_sq_three_scope_x64_*.txt).
+            vr["bound"] = "valu issue (K0 + three waveform adds + one vectorscope add per texel); hbm is the yardstick, not the ceiling"
+            vr["ceiling_estimate"] = {"gpix_per_s": 1200, "frac_of_hbm_peak": 0.67,
+                                      "from": "the per-texel instruction floor of this structure (K0 11.5 + waveform addresses 6 + alpha 1 + "
+                                              "vectorscope 3.5 + load 1 = 23 VALU instructions) at the 73 % VALU occupancy four waves per SIMD "
+                                              "reach (measured: 29.2 instructions per texel, 947 Gpix/s); DESIGN.md 3.5"}
             vr["note"] = "algorithmic bytes = SURVEY 8(d)'s config-5 figure: one read of the frames + the three tables"
         out = {"value": round(self.n * self.w * self.h / (sus["ms_per_step"] * 1e-3) / 1e9, 3), "unit": "Gpix/s", "components": f"{comp:#04x}",
                "ms_per_step": sus["ms_per_step"], "steps": sus["steps"], "parity": ok, "roofline": vr}
