@@ -524,7 +524,7 @@ def kernel_us(ctx, fn, warm=12, reps=24):
 
 def place_pool(torch, dev, ctx, frames, candidates, keep_alive):
     """WHERE a frame pool lies in HBM decides a few per cent of every streaming kernel's rate, and the first pools a
-    process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt).  The
+    process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt; profiles/HISTORY.md section 5).  The
     product offers a host that keeps a long-lived pool a way to look before it settles -- scope_frame_pool_alloc:
     `candidates` allocations held at once, each read with the accumulation kernel timed by its own stamps, the fastest
     kept -- and this bench is such a host: the frames move into a pool the LIBRARY placed.  Untimed set-up, rank-local.

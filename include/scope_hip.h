@@ -370,7 +370,7 @@ int scope_rccl_comm_info(void *rccl_comm, int *n_ranks, int *rank, int *version)
 
 /* ---- frame pools ----------------------------------------------------------------------------
  * Where a long-lived pool of frames lies in HBM decides a few per cent of every streaming kernel's rate on this chip
- * (allocations come in fast and slow physical ranges, +-2.5 %, and the first ones a process makes
+ * (profiles/HISTORY.md section 5: allocations come in fast and slow physical ranges, +-2.5 %, and the first ones a process makes
  * are regularly the slow ones).  A host that keeps frames resident -- a ring of staged surfaces, a batch it reduces again
  * and again -- can let the library look before it settles: scope_frame_pool_alloc makes up to `candidates` device
  * allocations of `bytes` (all held at the same time: candidates x bytes of HBM for a few milliseconds), reads each with the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-process A/B of two builds of libscope_hip.so on the SAME HBM-resident frames.
 
-Between processes the streaming kernels land in one of two placement modes 3 % apart, which
+Between processes the streaming kernels land in one of two placement modes 3 % apart (profiles/HISTORY.md section 5), which
 drowns the 1-2 % effects kernel tuning is about; here both libraries read the very same buffers, alternately.
 
     python tools/ab.py /path/to/libA.so /path/to/libB.so [--workload vectorscope|vectorscope_rgb|histogram|histogram_yuv|waveform|waveform_yuv|three_scope]

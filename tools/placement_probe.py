@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How much does WHERE a frame pool lies in HBM decide?  One process, K allocations of the same
+"""How much does WHERE a frame pool lies in HBM decide (profiles/HISTORY.md section 5)?  One process, K allocations of the same
 64 x 3840x2160 frames; per allocation the vectorscope kernel's own time (64 frames per launch) and the histogram's,
 which does not depend on content.  Prints GB/s of each and the rank correlation.
 
