@@ -782,6 +782,7 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.vss_sparse = 1;
 	ctx->tn.nt_loads = 1;
 	ctx->tn.trio_strip = 0;
+	ctx->tn.vss_rle = 0;
 	ctx->err[0] = 0;
 	*out = ctx;
 	return SCOPE_OK;
@@ -930,6 +931,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.dock = value < 0 ? 0 : (value > 2 ? 1 : value);
 	else if (!strcmp(key, "trio.strip"))
 		ctx->tn.trio_strip = value == 16 || value == 32 ? value : 0;
+	else if (!strcmp(key, "vss.rle"))
+		ctx->tn.vss_rle = value != 0;
 	else if (!strcmp(key, "slices"))
 		ctx->slices_override = value;
 	else

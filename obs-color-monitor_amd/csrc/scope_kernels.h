@@ -69,6 +69,7 @@ struct ScopeTuning {
 	int wvs_strip;       /* 0: 16-column strips for launches that would otherwise need row bands, 64 elsewhere; 64 / 16: always */
 	int nt_loads;        /* 1: non-temporal pixel loads */
 	int trio_strip;      /* scope_trio_kernel's strip width: 0 = 32 columns for batches, 16 for small launches; 16 / 32: always */
+	int vss_rle;         /* the fused-K0 vectorscope under vss_merge 3: 0 = run-length mode by wave vote, 1 = always (tests) */
 };
 
 /* Optional last argument of the accumulation launchers: two HIP events that receive the kernel's own begin and end time

@@ -265,10 +265,20 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 #undef SCOPE_BIN
 }
 
+#ifndef VSS_RLE
+#define VSS_RLE 1 /* 0: the fused vectorscope without its run-length mode (round 3's kernel; A/B with `make variant`) */
+#endif
+/* The mode lives in the batch form of the kernel only (four loads per lane per batch).  The form small launches run (two loads:
+ * one frame per call, the ring of three) is dominated by its start-up, and carrying the mode's code cost it 2.5-4 % on noise and
+ * natural content for +4 % (one frame) / +14 % (three) on screen content (visit c4/c5, profiles/round4/ab_fused_vectorscope.txt). */
+#define VSS_RLE_IN(U) (VSS_RLE && (U) == 4)
+/* run-length mode's scratch behind the fused kernel's table: per wave, texels 1-3 of up to 64 lanes */
+#define VSS_RLE_SCRATCH_WORDS_PER_WAVE 192u
+#define VSS_RLE_SCRATCH_BYTES (16u * VSS_RLE_SCRATCH_WORDS_PER_WAVE * 4u)
 template <int VECW, int U, bool NT, int MERGE, bool FUSE, int HASH, typename Pro>
 __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 rows,
-					   u32 slice, u32 slices, u32 glog2, const ScopeK0 &k0, u32 &since_clamp, VssLane &st,
-					   Pro &&prologue)
+					   u32 slice, u32 slices, u32 glog2, u32 rle_force, const ScopeK0 &k0, u32 &since_clamp,
+					   VssLane &st, Pro &&prologue)
 {
 	if (ncols == 0)
 		return;
@@ -294,7 +304,91 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		/* the lane's colour as U | U << 16 and V | V << 16; 0xffffffff (no pair looks like that) while it has none */
 		u32 lane_u = st.colour == 0xffffffffu ? 0xffffffffu : scope_perm(0u, st.colour, 0x0c010c01u);
 		u32 lane_v = st.colour == 0xffffffffu ? 0xffffffffu : scope_perm(0u, st.colour, 0x0c020c02u);
+		/* ---- RUN-LENGTH MODE: the wave's window as runs of flat cells --------------------------------------------------
+		 * Screen capture -- OBS's daily bread -- is flat areas with a little single-texel detail.  The per-lane absorb mode
+		 * below suits content on which a LANE's stream is one colour for long; but a lane's consecutive cells lie 2 KiB apart
+		 * (a wave's loads are contiguous, its batches are not), so there a lane changes colour with almost every cell, some
+		 * lane of the 64 holds detail in almost every cell, and the wave runs K0 on all four texels, the fast path, the
+		 * colour change AND the mixed path for every cell: 26-28 VALU instructions per texel, 0.50 of the HBM peak
+		 * (profiles/round3/pmc_sq_screen_p9.txt).  What IS coherent is the neighbourhood across lanes: the lanes of a lane
+		 * group hold ADJACENT cells.  So, with no per-lane state at all:
+		 *   - a cell is FLAT when its four texels agree in raw RGB (the vectorscope ignores alpha, src/vectorscope.c:217-238);
+		 *     K0 runs on texel 0 of every lane only (one vote, 11 instructions);
+		 *   - flat cells that continue the cell of the lane below (same key, same lane group: one DPP move and a compare)
+		 *     add nothing; the HEAD of each run adds 4 x the run's length, which it reads off a ballot of the run breaks
+		 *     (a 64-bit shift and a find-first-bit);
+		 *   - the lanes whose cell is not flat add their texel 0 themselves and write texels 1-3 to a scratch row of the wave
+		 *     in the LDS, packed (v_mbcnt gives the slot); the wave then converts and adds the packed texels 64 at a time --
+		 *     any lane may add any texel -- so the detail of a whole wave-cell (about 7 lanes x 3 texels on the synthetic
+		 *     screen content) costs ONE more K0 round instead of three.
+		 * Exact: every texel is counted once, in the bin K0 gives it (same K0, same votes).  Two per-lane forms of the same
+		 * idea were measured and dropped this round (profiles/round4/ab_fused_vectorscope.txt). */
+		const u32 lane_id = threadIdx.x & 63u;
+		const u32 run_lanes = min(64u >> glog2, 16u); /* a run lives inside a lane group and inside a DPP row */
+		/* this lane's place among the wave's lanes and the wave's width, written so that the CPU emulation -- whose waves are ONE
+		 * lane wide, with that lane's ballot bit at its thread's position -- gets 0 and 1 */
+		const u32 lane_w = scope_lanes_below(~0ull), wave_w = (u32)__popcll(__ballot(1));
+		u32 *rle_scr = tab + VssTable<HASH>::words + (threadIdx.x >> 6) * VSS_RLE_SCRATCH_WORDS_PER_WAVE;
+		auto bin_rle = [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
+#pragma unroll
+			for (int k = 0; k < U; k++) {
+				const u32 p0 = q[k][0], p1 = q[k][1], p2 = q[k][2], p3 = q[k][3];
+				const bool flat = ok[k] && (scope_bitop3<0xf6>(p0 ^ p1, p0, p2) | (p0 ^ p3)) << 8 == 0u;
+				u32 key0[1] = {p0};
+				scope_k0_cell<1, true>(key0, k0, true, false); /* wave votes inside: every lane goes through */
+				/* keys have bytes 0 and 3 zero: bit 31 marks a flat cell, bit 30 + the lane a cell that continues nothing */
+				const u32 tag = flat ? (key0[0] | 0x80000000u) : (0x40000000u | lane_id);
+				const bool cont = flat && tag == scope_lane_below(tag, 0u) && (lane_id & (run_lanes - 1u)) != 0u;
+				const u64 breaks = ~__ballot(cont); /* every lane that continues nothing (and every lane there is none of) */
+				if (flat && !cont) { /* the head of a run: the next break above this lane ends it */
+					const u64 above = ((breaks >> 1) | (1ull << 63)) >> lane_id;
+					vss_add<HASH>(tab, key0[0], 4u * (u32)__ffsll((long long)above));
+				}
+				const bool nf = ok[k] && !flat;
+				const u64 rough = __ballot(nf);
+				if (rough != 0) { /* wave-uniform */
+					const u32 n3 = 3u * (u32)__popcll(rough);
+					if (nf) {
+						vss_add<HASH>(tab, key0[0], 1);
+						u32 *slot = rle_scr + 3u * scope_lanes_below(rough);
+						slot[0] = p1;
+						slot[1] = p2;
+						slot[2] = p3;
+					}
+					/* a wave's LDS operations are performed in order: the reads below see the writes above */
+					for (u32 base = 0; base < n3; base += wave_w) {
+						const u32 idx = base + lane_w;
+						u32 key[1] = {idx < n3 ? rle_scr[idx] : 0u};
+						scope_k0_cell<1, true>(key, k0, true, false);
+						if (idx < n3)
+							vss_add<HASH>(tab, key[0], 1);
+					}
+				}
+			}
+		};
+		/* Which mode a wave runs.  The run-length mode is entered from the absorb vote below (chroma, after K0, every 64 texels
+		 * per lane -- noise and natural video never pass it, so they never pay for the second question) when the same batch
+		 * also passes on RAW texels: at least a quarter of the wave holds nothing but cells that are flat in RGB.  Content whose
+		 * chroma is flat while its RGB is not (a black-and-white film) passes the first vote only and stays in the per-lane
+		 * absorb mode.  Once in, the wave re-asks the raw question every 64 texels per lane and leaves when it fails. */
+		u32 rle_on = rle_force, rle_clock = 0; /* wave-uniform, kept in scalar registers */
+		auto rgb_vote = [&](const scope_v4(&q)[U], const bool(&ok)[U]) -> u32 {
+			bool all_flat = true;
+#pragma unroll
+			for (int k = 0; k < U; k++)
+				all_flat &= !ok[k] || (scope_bitop3<0xf6>(q[k][0] ^ q[k][1], q[k][0], q[k][2]) | (q[k][0] ^ q[k][3])) << 8 == 0u;
+			return (u32)__builtin_amdgcn_readfirstlane((int)(__popcll(__ballot(all_flat)) >= 16));
+		};
 		auto bin_pairs = [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
+			if (VSS_RLE_IN(U) && MERGE == 3 && __builtin_expect(__builtin_amdgcn_readfirstlane(rle_on) != 0, false)) {
+				if ((rle_clock++ & (16u / U - 1u)) == 0 && !rle_force)
+					rle_on = rgb_vote(q, ok);
+				if (__builtin_amdgcn_readfirstlane(rle_on) != 0) {
+					bin_rle(q, ok);
+					return;
+				}
+				/* left the mode: it keeps nothing in the lanes, so the forms below go on where they were */
+			}
 			u32 pu[U][2], pv[U][2];
 #pragma unroll
 			for (int k = 0; k < U; k++) {
@@ -311,6 +405,9 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 								   (pu[k][0] == scope_perm(0u, pu[k][0], 0x01000302u)) &
 								   (pv[k][0] == scope_perm(0u, pv[k][0], 0x01000302u)));
 					absorb_verdict = (u32)__builtin_amdgcn_readfirstlane((int)(__popcll(__ballot(flat)) >= 16));
+					if (VSS_RLE_IN(U) && absorb_verdict != 0 && rgb_vote(q, ok) != 0) {
+						rle_on = 2u; /* from the next batch on: run-length mode (this batch is still the absorb mode's, then it hands over) */
+					}
 				}
 				absorb = __builtin_amdgcn_readfirstlane(absorb_verdict) != 0;
 			}
@@ -319,6 +416,13 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 				for (int k = 0; k < U; k++)
 					if (ok[k])
 						vss_absorb_pairs(tab, st, lane_u, lane_v, pu[k][0], pv[k][0], pu[k][1], pv[k][1]);
+				if (VSS_RLE_IN(U) && MERGE == 3 && __builtin_amdgcn_readfirstlane(rle_on) == 2u) {
+					/* entering the run-length mode with the next batch: it keeps nothing in the lanes, so what the absorb mode
+					 * holds goes to the table now (rare; every lane of the wave takes part) */
+					vss_flush_lane<HASH>(tab, st);
+					rle_on = 1u;
+					rle_clock = 1u;
+				}
 			} else {
 #pragma unroll
 				for (int k = 0; k < U; k++)
@@ -411,7 +515,8 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
  * twice the partials' bytes) -- are in profiles/round2/flush_microbench_r2a.txt. */
 template <int U, bool NT, int MERGE, bool FUSE, int HASH>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
-							       u32 xbyte_b, u32 glog2, ScopeK0 k0_arg, uint8_t *dst, uint8_t *pmask)
+							       u32 xbyte_b, u32 glog2, u32 rle_force, ScopeK0 k0_arg, uint8_t *dst,
+							       uint8_t *pmask)
 {
 	const ScopeK0 k0 = FUSE ? scope_k0_pinned(k0_arg, true, false) : k0_arg;
 	u32 *tab = scope_lds;
@@ -436,10 +541,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	SCOPE_STAMP(0);
 	u32 since_clamp = 0;
 	VssLane st = {0xffffffffu, 0};
-	vss_region<4, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, glog2, k0,
+	vss_region<4, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, 0, ncols_a, fs.height, slice, slices, glog2, rle_force, k0,
 						 since_clamp, st, zero_table);
 	vss_region<1, U, NT, MERGE, FUSE, HASH>(tab, plane, fs.linesize, xbyte_b, ncols_b, fs.height, slice, slices, glog2,
-						 k0, since_clamp, st, zero_table);
+						 rle_force, k0, since_clamp, st, zero_table);
 	zero_table(); /* a slice without pixels */
 	vss_flush_lane<HASH>(tab, st);
 	__syncthreads();
@@ -1493,7 +1598,7 @@ const u32 WVS_LDS_BYTES = 3u * WVS_CH_WORDS * 4u + WVS_HIS_LDS_BYTES;
  * (scope_kernels_init walks all variants once with allow = true). */
 struct VssArgs {
 	const ScopeFrameSet *fs;
-	u32 slices, glog2, block;
+	u32 slices, glog2, block, rle_force;
 	Regions rg;
 	ScopeK0 k0;
 	uint8_t *dst, *pmask;
@@ -1503,12 +1608,12 @@ struct VssArgs {
 
 template <int U, bool NT, int MERGE, bool FUSE, int HASH> hipError_t vss_variant(const VssArgs *a)
 {
-	constexpr u32 lds = VssTable<HASH>::words * 4u;
+	constexpr u32 lds = VssTable<HASH>::words * 4u + (FUSE && HASH == 2 && MERGE == 3 && VSS_RLE_IN(U) ? VSS_RLE_SCRATCH_BYTES : 0u);
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_vss_kernel<U, NT, MERGE, FUSE, HASH>,
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	SCOPE_LAUNCH((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(a->block),
-		     lds, a->st, a->tm, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->k0,
+		     lds, a->st, a->tm, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->rle_force, a->k0,
 		     a->dst, a->pmask);
 	return hipGetLastError();
 }
@@ -1778,7 +1883,8 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 	const int unroll = fuse_k0 ? fused_unroll : (tn.vss_unroll > 0 ? tn.vss_unroll : (small ? 2 : 4));
 	if (pmask && !scope_vss_mask_block(tn))
 		return hipErrorInvalidValue;
-	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), split_regions(fs), scope_k0_matrix(colorspace), dst, pmask, st, tm};
+	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), tn.vss_rle != 0 ? 1u : 0u, split_regions(fs), scope_k0_matrix(colorspace),
+			   dst, pmask, st, tm};
 	return vss_pick(unroll, tn.nt_loads, tn.vss_merge, fuse_k0, fuse_k0 ? fused_hash : tn.vss_hash, &a);
 }
 

@@ -234,6 +234,18 @@ __device__ __forceinline__ void scope_row16_add(unsigned *dst, unsigned x)
 		atomicAdd(dst, x);
 }
 
+/* The value of the lane below (lane - 1), `fill` for the first lane of a DPP row of 16 (row_shr:1, bound_ctrl off).  Every lane
+ * must be active. */
+__device__ __forceinline__ unsigned scope_lane_below(unsigned x, unsigned fill)
+{
+	return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x111, 0xf, 0xf, false);
+}
+/* How many bits of `mask` belong to lanes below this one (v_mbcnt_lo / v_mbcnt_hi). */
+__device__ __forceinline__ unsigned scope_lanes_below(unsigned long long mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
 /* Sum over the 64 lanes of a wave; every lane must be active (uniform control flow). */
 __device__ __forceinline__ unsigned scope_wave_sum(unsigned x)
 {

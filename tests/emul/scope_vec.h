@@ -102,6 +102,15 @@ template <unsigned TT> static inline unsigned scope_bitop3(unsigned a, unsigned 
 	return out;
 }
 
+/* the emulated wave has one lane = one DPP row of its own: there is no lane below, and no bit of a ballot belongs to one */
+static inline unsigned scope_lane_below(unsigned, unsigned fill)
+{
+	return fill;
+}
+static inline unsigned scope_lanes_below(unsigned long long)
+{
+	return 0;
+}
 /* the emulated wave has one lane = one DPP row of its own */
 static inline void scope_row16_add(unsigned *dst, unsigned x)
 {

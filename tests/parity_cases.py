@@ -12,7 +12,7 @@ COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
 
 
 DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 0, "vss.hash": 0, "vss.fused_hash": -1, "vss.groups": -1, "his.unroll": 0, "wvs.wide": 1, "wvs.strip": 0, "wvs.deep": 1, "dock": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.block": 0, "his.block": 0,
-            "nt": 1, "slices": 0, "trio.strip": 0}
+            "nt": 1, "slices": 0, "trio.strip": 0, "vss.rle": 0}
 
 
 class options:
@@ -100,9 +100,12 @@ def check_vectorscope_rgb_frame(ctx, oracle, rgb, w, colorspace=2, what=""):
 
 def check_fused_screen_content(ctx, oracle, sizes, forced):
     """The fused vectorscope on screen-like content -- flat areas, rectangles, sprinkled detail, greys (the chroma never changes
-    while the RGB does), random alpha -- and on the oracle's distributions, with the absorb mode by wave vote (vss.merge 3, the
-    default) or forced on ANY content (vss.merge 2: on noise nearly every cell takes the mixed road)."""
-    with options(ctx, **{"vss.merge": 2 if forced else 3}):
+    while the RGB does), random alpha -- and on the oracle's distributions.  forced 0: the modes by wave vote (the default);
+    1: run-length mode on ANY content (vss.rle = 1: on noise every cell is rough and goes through the packed road, three
+    rounds per wave-cell; the mode lives in the kernel's batch form, vss.fused_unroll 4); 2: the per-lane absorb mode on any
+    content (vss.merge 2)."""
+    opts = {1: {"vss.rle": 1}, 2: {"vss.merge": 2}}.get(forced, {})
+    with options(ctx, **opts):
         for (w, h, ls) in sizes:
             for seed, kw in enumerate(({}, {"detail": 0.0}, {"detail": 0.3}, {"grey": True}, {"alpha_noise": True, "detail": 0.01},
                                        {"rects": 200, "detail": 0.0})):

@@ -158,7 +158,7 @@ def test_waveform_deep_queue_across_flushes(emul_ctx, oracle):
         pc.check_waveform(emul_ctx, oracle, 512, 265, 1, 0x20, None, fuse=True, colorspace=2)
 
 
-@pytest.mark.parametrize("forced", [0, 1])
+@pytest.mark.parametrize("forced", [0, 1, 2])
 def test_fused_vectorscope_screen_content(emul_ctx, oracle, forced):
     """Screen-like content (flat areas, rectangles, sprinkled detail, greys, random alpha) and the oracle's distributions through
     the fused vectorscope with the absorb mode voted / forced; several unroll factors, one workgroup per frame (clamp passes between

@@ -408,7 +408,7 @@ def test_fused_vectorscope_layouts_and_modes(hip_ctx, oracle, merge, hash_):
             pc.check_vectorscope(hip_ctx, oracle, 509, 130, 2, 2048, fuse=True, colorspace=1)
 
 
-@pytest.mark.parametrize("forced", [0, 1])
+@pytest.mark.parametrize("forced", [0, 1, 2])
 def test_fused_vectorscope_screen_content(hip_ctx, oracle, forced):
     """The fused vectorscope on screen-like content -- flat areas, rectangles, sprinkled detail, greys, random alpha -- and the
     oracle's distributions, with the absorb mode voted and forced, at 4K, on small ragged frames, with one workgroup per frame
@@ -425,7 +425,8 @@ def test_fused_vectorscope_screen_content(hip_ctx, oracle, forced):
     d = torch.from_numpy(np.stack(frames_)).cuda()
     b = hip_ctx.make_device_batch(d, 4 * w, w, h, planes_are_rgb=True, colorspace=2)
     out = torch.empty((n, 256, 256), dtype=torch.uint8, device="cuda")
-    with pc.options(hip_ctx, **{"vss.merge": 2 if forced else 3}):
+    # vss.fused_unroll 4: the batch form of the kernel (the one a 64-frame launch runs, and the one that carries the run-length mode)
+    with pc.options(hip_ctx, **dict({"vss.fused_unroll": 4}, **({1: {"vss.rle": 1}, 2: {"vss.merge": 2}}.get(forced, {})))):
         hip_ctx.vectorscope_batch_dev(b, out)
     got = out.cpu().numpy()
     for i in range(n):
