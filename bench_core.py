@@ -1,0 +1,454 @@
+"""bench_core.py -- what every part of bench.py shares: the constants of the metric, the device plumbing (the real thing is
+torch.cuda + libscope_hip.so; `--backend emul` is the CPU emulation build of the same sources, tests/emul, so that the N-rank
+logic can run without a GPU), the gloo control plane (class Ctl), one scope workload over a pool of HBM-resident frames
+(class Workload), the timed run, the roofline object, the flat summary, the sources fingerprint and the PMC traffic look-up.
+Nothing here is the product; nothing here calls the oracle except Workload.check (the checker, never inside a timed region)."""
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+W4K, H4K = 3840, 2160
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", r) for r in ("round4", "round3", "round2")]
+METRIC = "Gpix/s scope accumulation @3840×2160; achieved HBM GB/s vs peak"
+UNPINNED = " (parity unpinned: the oracle is this build's restatement of the reference loops, DESIGN.md section 4)"
+
+WORKLOAD_TEXT = {
+    "vectorscope": "vectorscope 256x256 CbCr scatter (K1) over staged Y'CbCr planes",
+    "vectorscope_rgb": "vectorscope with fused K0 over RGB planes",
+    "waveform": "waveform per-column 256-bin (K2)",
+    "histogram": "histogram 3x256 u32 (K3)",
+    "three_scope": "vectorscope (fused K0) + waveform + histogram of every frame from ONE read of its plane (scope_three_scopes_batch)",
+}
+KERNEL = {"vectorscope": "scope_vss_kernel", "vectorscope_rgb": "scope_vss_kernel", "waveform": "scope_wvs_kernel",
+          "histogram": "scope_his_kernel", "three_scope": "scope_trio_kernel (one read; two passes = scope_vss_kernel + scope_wvs_kernel with dock=0)"}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def table_bytes_of(wl, w):
+    return {"vectorscope": 65536, "vectorscope_rgb": 65536, "waveform": 256 * w * 4, "histogram": 4096,
+            "three_scope": 65536 + 256 * w * 4 + 4096}[wl]
+
+
+class HostEvent:
+    def __init__(self):
+        self.t = 0.0
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class HostStream:
+    cuda_stream = None
+
+    def wait_event(self, ev):
+        pass
+
+
+class Dev:
+    def __init__(self, torch, args, local_rank):
+        self.torch, self.emul = torch, args.backend == "emul"
+        if self.emul:
+            self.device, self.index, self.shared = "cpu", 0, False
+            return
+        have = torch.cuda.device_count()
+        if have < 1:
+            raise RuntimeError("no HIP device is visible: the scope path has no CPU implementation (--backend emul is the "
+                               "test-only emulation build)")
+        if local_rank >= have and not args.oversubscribe:
+            raise RuntimeError(f"rank {local_rank} has no GPU of its own ({have} visible); --oversubscribe lets ranks share one")
+        self.index = local_rank % have
+        self.shared = int(os.environ.get("WORLD_SIZE", "1")) > have
+        self.device = "cuda"
+        torch.cuda.set_device(self.index)
+
+    def sync(self):
+        if not self.emul:
+            self.torch.cuda.synchronize()
+
+    def stream(self):
+        return HostStream() if self.emul else self.torch.cuda.Stream()
+
+    def event(self, timing=False):
+        return HostEvent() if self.emul else self.torch.cuda.Event(enable_timing=timing)
+
+    def empty_cache(self):
+        if not self.emul:
+            self.torch.cuda.empty_cache()
+
+
+class Ctl:
+    """Control plane of an N-rank run: barriers, agreement flags, max / sum over ranks -- gloo on CPU tensors, so that
+    nothing of it is ever queued on a GPU beside the data path's collectives."""
+
+    def __init__(self, torch, dist, world):
+        self.torch, self.dist, self.world = torch, dist, world
+
+    def _reduce(self, values, op, dtype):
+        if self.dist is None:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=dtype)
+        self.dist.all_reduce(t, op=op)
+        return t.tolist()
+
+    def barrier(self):
+        if self.dist is not None:
+            self._reduce([1], self.dist.ReduceOp.SUM, self.torch.int32)
+
+    def max(self, x):
+        return self._reduce([x], self.dist.ReduceOp.MAX if self.dist else None, self.torch.float64)[0]
+
+    def all_true(self, flag):
+        return bool(self._reduce([1 if flag else 0], self.dist.ReduceOp.MIN if self.dist else None, self.torch.int32)[0])
+
+    def any_true(self, flag):
+        return bool(self._reduce([1 if flag else 0], self.dist.ReduceOp.MAX if self.dist else None, self.torch.int32)[0])
+
+    def sum_array(self, arr):
+        """int64 numpy array summed over ranks (oracle tables of the ranks' tiles)."""
+        if self.dist is None:
+            return arr
+        t = self.torch.from_numpy(arr.copy())
+        self.dist.all_reduce(t)
+        return t.numpy()
+
+    def bcast(self, obj):
+        if self.dist is None:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+
+def spread(n, k):
+    """k frame indices spread over a launch of n frames, first and last included."""
+    return sorted({round(i * (n - 1) / max(k - 1, 1)) for i in range(min(k, n))})
+
+
+class Workload:
+    """One scope workload over a pool of HBM-resident frames, `n` frames per step, rotating through the pool."""
+
+    def __init__(self, torch, ctx, wl, rgb, yuv, w, h, n, components=0x07, side_reduce=False):
+        self.torch, self.ctx, self.wl, self.w, self.h, self.n, self.comp = torch, ctx, wl, w, h, n, components
+        self.side = side_reduce  # vectorscope only: SCOPE_SIDE_REDUCE, the reduction of call i under the accumulation of call i + 1
+        pool = rgb.shape[0]
+        dev = rgb.device
+        self.groups = pool // n
+        src = yuv if wl == "vectorscope" else rgb
+        self.linesize = int(src.shape[2])
+        self.batches = [ctx.make_device_batch(src[g * n:(g + 1) * n], self.linesize, w, h, planes_are_rgb=(wl != "vectorscope"), colorspace=2)
+                        for g in range(self.groups)]
+        self.tbytes = table_bytes_of(wl, w)
+        if wl == "three_scope":
+            self.vss = [torch.empty((n, 65536), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.wvs = [torch.empty((n, 256 * w * 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.his = [torch.empty((n, 1024), dtype=torch.int32, device=dev) for _ in range(2)]
+        else:
+            self.tables = [torch.empty((n, self.tbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.last = (0, 0)
+        # 4 B per pixel read once + the tables once per frame
+        self.algo_bytes = n * (4 * w * h + self.tbytes)
+
+    def step(self, i):
+        ctx, b, buf = self.ctx, self.batches[i % self.groups], i & 1
+        wl = self.wl
+        if wl in ("vectorscope", "vectorscope_rgb"):
+            ctx.vectorscope_batch_dev(b, self.tables[buf], sync=False, side_reduce=self.side)
+        elif wl == "waveform":
+            ctx.waveform_batch_dev(b, self.comp, self.tables[buf], sync=False)
+        elif wl == "histogram":
+            ctx.histogram_counts_batch_dev(b, self.comp, self.tables[buf], sync=False)
+        else:
+            ctx.three_scopes_batch_dev(b, self.comp, self.comp, self.vss[buf], self.wvs[buf], self.his[buf], sync=False)
+        self.last = (i % self.groups, buf)
+
+    def finish(self):
+        """What a host does before it reads a table of a side_reduce call: the context's stream waits for the side stream."""
+        if self.side:
+            self.ctx.fence()
+
+    def check(self, o, rgb, yuv, np, frames=None):
+        """Tables of the most recent step against the oracle (frames: indices inside the step's batch)."""
+        g, buf = self.last
+        torch = self.torch
+        ok = True
+        for f in (frames if frames is not None else spread(self.n, 8)):
+            pr, py = rgb[g * self.n + f].cpu().numpy(), yuv[g * self.n + f].cpu().numpy()
+            if self.wl in ("vectorscope", "vectorscope_rgb", "three_scope"):
+                got = (self.vss if self.wl == "three_scope" else self.tables)[buf][f].cpu().numpy().reshape(256, 256)
+                ok &= bool(np.array_equal(got, o.vectorscope(py, self.w)))
+            if self.wl in ("waveform", "three_scope"):
+                got = (self.wvs if self.wl == "three_scope" else self.tables)[buf][f].cpu().numpy().reshape(256, self.w, 4)
+                ok &= bool(np.array_equal(got, o.waveform(pr, py, self.w, self.comp)))
+            if self.wl in ("histogram", "three_scope"):
+                t = (self.his[buf][f].view(torch.uint8) if self.wl == "three_scope" else self.tables[buf][f])
+                ok &= bool(np.array_equal(t.cpu().numpy().view(np.uint32).reshape(256, 4), o.histogram_counts(pr, py, self.w, self.comp)))
+        return ok
+
+
+def timed_run(dev, ctl, ctx, stream, step, steps, warmup, settle_s, min_s, multi=False, finish=None):
+    """settle -> warm-up -> EXACTLY `steps` steps between barrier + synchronize -> at least min_s more of the same ->
+    a short leg with the accumulation kernel bracketed by its own begin/end stamps.
+    Loops that run 'for so many seconds' run the SAME number of steps on every rank (a step may hold a collective, and a
+    rank that enqueues one more than its peers waits for ever): no single rank's clock decides, the loop goes on while
+    ANY rank wants to.  Returns (elapsed of the K steps, sustained dict, bracketed launches, their summed ms)."""
+    def go_on(flag):
+        if not multi:
+            return flag
+        dev.sync()
+        return ctl.any_true(flag)
+
+    t_end = time.perf_counter() + settle_s
+    i = 0
+    while go_on(time.perf_counter() < t_end):
+        for _ in range(8):
+            step(i)
+            i += 1
+        dev.sync()
+    for j in range(warmup):
+        step(j)
+    dev.sync()
+    ctl.barrier()
+    dev.sync()
+    t0 = time.perf_counter()
+    for j in range(steps):
+        step(j)
+    if finish:
+        finish()
+    dev.sync()
+    ctl.barrier()
+    elapsed = time.perf_counter() - t0
+    # the sustained leg: the same step for >= min_s; the host only enqueues (its own pace is reported beside the GPU's)
+    s_steps, e0, e1 = 0, dev.event(True), dev.event(True)
+    chunk = max(8, steps)
+    t1 = time.perf_counter()
+    e0.record(stream)
+    while True:
+        for j in range(chunk):
+            step(s_steps + j)
+        s_steps += chunk
+        if not go_on(time.perf_counter() - t1 < min_s):
+            break
+    host_s = time.perf_counter() - t1
+    if finish:
+        finish()
+    e1.record(stream)
+    dev.sync()
+    sustained = {"seconds": round(time.perf_counter() - t1, 3), "steps": s_steps,
+                 "ms_per_step": round(e0.elapsed_time(e1) / s_steps, 5),
+                 "host_enqueue_ms_per_step": round(host_s / s_steps * 1e3, 5)}
+    ctx.profile(True)
+    for j in range(min(400, max(60, steps)) if not dev.emul else 2):
+        step(j)
+    dev.sync()
+    launches, kernel_ms = ctx.kernel_ms()
+    ctx.profile(False)
+    return elapsed, sustained, launches, kernel_ms
+
+
+def kernel_us(ctx, fn, warm=12, reps=24):
+    """Average duration of the accumulation kernel fn() launches: the kernel's own begin / end stamps."""
+    for _ in range(warm):
+        fn()
+    ctx.sync()
+    ctx.profile(True)
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    nl, ms = ctx.kernel_ms()
+    ctx.profile(False)
+    return round(ms / max(nl, 1) * 1e3, 2)
+
+
+def place_pool(torch, dev, ctx, frames, candidates, keep_alive):
+    """WHERE a frame pool lies in HBM decides a few per cent of every streaming kernel's rate, and the first pools a
+    process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt; profiles/HISTORY.md section 5).  The
+    product offers a host that keeps a long-lived pool a way to look before it settles -- scope_frame_pool_alloc:
+    `candidates` allocations held at once, each read with the accumulation kernel timed by its own stamps, the fastest
+    kept -- and this bench is such a host: the frames move into a pool the LIBRARY placed.  Untimed set-up, rank-local.
+    Returns (the frames in the placed pool, read GB/s per candidate with the kept one first)."""
+    pool, rates = ctx.frame_pool_alloc(frames.numel(), candidates)
+    keep_alive.append(pool)
+    placed = pool.tensor(torch, tuple(frames.shape))
+    placed.copy_(frames)
+    dev.sync()
+    return placed, rates
+
+
+class Overlap:
+    """The table sum of step i under the accumulation of step i + 1: a second scope context on a second hipStream carries
+    ncclAllReduce + unpack/clamp, events order it behind the accumulation that filled the buffer and hold the accumulation
+    that will overwrite the buffer (two steps later) until the sum has left it.  Nothing is skipped, bucketed or deferred
+    beyond the timed region: the closing synchronize waits for both streams."""
+
+    def __init__(self, dev, ocm, lib_path, compute_stream):
+        self.compute = compute_stream
+        self.stream = dev.stream()
+        self.ctx = ocm.ScopeContext(dev.index, lib_path)
+        if not dev.emul:
+            self.ctx.set_stream(self.stream.cuda_stream)
+        self.filled = [dev.event() for _ in range(2)]
+        self.summed = [dev.event() for _ in range(2)]
+        self.used = [False, False]
+
+    def before_compute(self, buf):
+        if self.used[buf]:
+            self.compute.wait_event(self.summed[buf])
+
+    def after_compute(self, buf):
+        self.filled[buf].record(self.compute)
+        self.stream.wait_event(self.filled[buf])
+
+    def after_reduce(self, buf):
+        self.summed[buf].record(self.stream)
+        self.used[buf] = True
+
+
+def roofline(wl, algo_bytes, launches, kernel_ms, ms_per_step, traffic):
+    """`achieved` / `frac` are the WHOLE STEP's: algorithmic bytes over everything the call enqueues (the accumulation kernel, the
+    partial-table reduction, the gaps between launches) as the K timed steps saw it -- the conservative figure, and the one an
+    outside clock around the run reproduces.  The accumulation kernel alone (HIP events on its stream around each launch, the
+    figure rocprofv3's average duration for that kernel agrees with) is `achieved_kernel` / `frac_kernel`."""
+    kern_avg_ms = kernel_ms / launches if launches else float("nan")
+    kern = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if launches and kern_avg_ms > 0 else float("nan")
+    whole = algo_bytes / (ms_per_step * 1e-3) / 1e9 if ms_per_step > 0 else float("nan")
+    return {
+        "bound": "hbm",
+        "kernel": KERNEL[wl],
+        "achieved": round(whole, 1),
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": round(whole / HBM_PEAK_GBPS, 4),
+        "frac_is": "whole step (every kernel of the call + launch gaps) over the K timed steps",
+        "achieved_kernel": round(kern, 1),
+        "frac_kernel": round(kern / HBM_PEAK_GBPS, 4),
+        "frac_whole_step": round(whole / HBM_PEAK_GBPS, 4),
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "avg_launch_ms": round(kern_avg_ms, 5),
+        "launches_timed": launches,
+    }
+
+
+def flat_summary(result):
+    """{name: scalar} of the other legs: <variant>_gpix / _frac (whole step) / _frac_kernel, <workload>_x1_us / _x3_us (the
+    reference's call shape), <content>_<workload>_frac_kernel, stream / config 1 / config 4 figures, and all_parity."""
+    flat, ok = {}, result["parity"].startswith("bit-exact")
+    for name, v in (result.get("variants") or {}).items():
+        flat[f"{name}_gpix"] = v["value"]
+        flat[f"{name}_frac"] = v["roofline"]["frac"]
+        flat[f"{name}_frac_kernel"] = v["roofline"]["frac_kernel"]
+        ok = ok and v["parity"] is not False
+    for name, v in (result.get("latency") or {}).items():
+        if isinstance(v, dict):
+            flat[f"{name}_us"] = v["us_per_call"]
+            ok = ok and bool(v["parity"])
+    for kind, v in (result.get("distributions") or {}).items():
+        if not isinstance(v, dict):
+            continue
+        for wl, r in v.items():
+            if isinstance(r, dict):
+                if "frac_kernel" in r:
+                    flat[f"{kind}_{wl}_frac_kernel"] = r["frac_kernel"]
+                flat[f"{kind}_{wl}_gpix"] = r.get("gpix_per_s")
+                ok = ok and r.get("parity") is not False
+    st = result.get("stream") or {}
+    if "flat_out" in st:
+        flat["stream_fps"] = st["flat_out"].get("fps")
+        flat["stream_paced_240fps_latency_ms"] = (st.get("paced_240fps") or {}).get("latency_ms_mean")
+        ok = ok and str(st.get("parity", "")).startswith("bit-exact")
+    c1 = result.get("config1") or {}
+    if "ms_per_frame" in c1:
+        flat["config1_cpu_ms_per_frame"] = c1["ms_per_frame"]
+        ok = ok and bool(c1.get("gpu_tables_bit_exact"))
+    c4 = result.get("config4") or {}
+    if "value" in c4:
+        flat["config4_gpix"] = c4["value"]
+        flat["config4_ranks_in_communicator"] = c4.get("rccl_ranks_in_communicator")
+        ok = ok and bool(c4.get("parity"))
+    pl = (result.get("config") or {}).get("frame_pool_placement") or {}
+    if "value" in pl:
+        flat["placed_pool_gpix"] = pl["value"]
+    flat["all_parity"] = bool(ok)
+    return flat
+
+
+def code_only(src):
+    """The source text without comments and without white space: an edit of a comment is not another kernel."""
+    import re
+
+    src = re.sub(rb"/\*.*?\*/", b"", src, flags=re.S)
+    src = re.sub(rb"//[^\n]*", b"", src)
+    return re.sub(rb"\s+", b"", src)
+
+
+def kernel_fingerprint():
+    """sha256 of the kernel sources the library was built from: PMC traffic files are only believed for this build."""
+    hsh = hashlib.sha256()
+    for f in ("scope_kernels.hip", "scope_trio.hip", "scope_device.h", "scope_kernels.h", "scope_vec.h", "scope_api.hip"):
+        with open(os.path.join(ROOT, "obs-color-monitor_amd", "csrc", f), "rb") as fh:
+            hsh.update(code_only(fh.read()))
+    return hsh.hexdigest()[:16]
+
+
+def pmc_traffic(wl, n, w, h, plain):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), measured with
+    rocprofv3 on this exact workload by tools/gpu_job.sh and committed with the fingerprint of the kernel sources.
+    bench.py cannot run under a counter pass itself; a file measured on OTHER kernel sources is refused, loudly."""
+    pmc, path = None, None
+    for d in PROFILE_DIRS:
+        path = os.path.join(d, "pmc_traffic.json")
+        try:
+            pmc = json.load(open(path))
+            break
+        except (OSError, ValueError):
+            continue
+    if pmc is None:
+        return None, "no profiles/round*/pmc_traffic.json"
+    if pmc.get("kernel_sources_sha256_16") != kernel_fingerprint():
+        log(f"bench.py: {path} was measured on other kernel sources ({pmc.get('kernel_sources_sha256_16')} != "
+            f"{kernel_fingerprint()}): roofline.traffic is null until tools/gpu_job.sh traffic is re-run")
+        return None, "stale: measured on other kernel sources"
+    if not plain:
+        return None, "non-default options"
+    for e in pmc.get("entries", []):
+        if (e["workload"], e["frames_per_step"], e["width"], e["height"]) == (wl, n, w, h):
+            return e["bytes_per_launch"], "rocprofv3 PMC, " + pmc.get("job", "?")
+    return None, "not measured for this workload"
+
+
+def make_comm(ctx, ctl, world, rank):
+    """A communicator for the C-ABI's table sum: rank 0's unique id travels over the control plane, every rank creates
+    its end, and the verdict is agreed on (all ranks use it or none does).  Returns (comm or None, reason)."""
+    uid, comm, why = None, None, ""
+    if rank == 0:
+        try:
+            uid = ctx.rccl_unique_id()
+        except Exception as e:  # noqa: BLE001
+            why = repr(e)
+    uid = ctl.bcast(uid)  # every rank takes part in every control-plane collective, whatever failed before it
+    if uid is not None:
+        try:
+            comm = ctx.rccl_comm_create(uid, world, rank)
+        except Exception as e:  # noqa: BLE001
+            why = repr(e)
+    else:
+        why = why or "rank 0 could not make a unique id (no collective library)"
+    if not ctl.all_true(comm is not None):
+        if comm:
+            ctx.rccl_comm_destroy(comm)
+        return None, why or "a peer could not create its end"
+    return comm, ""
