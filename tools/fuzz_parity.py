@@ -58,7 +58,8 @@ def run(ctx, o, cases, seed, log=print, to_dev=None, to_host=None):
             n = rnd.choice([5, 8, 17, 66])  # batches of small frames: several strips per slice, more frames than a launch takes
         tag = f"case {case}: {w}x{h} pitch {ls} dist {dist} cs {cs} wc {wc:#x} hc {hc:#x} n {n}"
         try:
-            pc.check_three_scopes_dev(ctx, o, to_dev, to_host, w, h, [dist] * n if n > 1 else [dist], wc, hc, ls, cs, reps=1)
+            with pc.options(ctx, **{"trio.strip": rnd.choice([0, 0, 16, 32])}):  # round 4: both strip widths on any launch size
+                pc.check_three_scopes_dev(ctx, o, to_dev, to_host, w, h, [dist] * n if n > 1 else [dist], wc, hc, ls, cs, reps=1)
             with pc.options(ctx, dock=rnd.choice([0, 2])):  # the two-pass form / round 2's one-frame kernel
                 pc.check_three_scopes_dev(ctx, o, to_dev, to_host, w, h, [dist], wc, hc, ls, cs, reps=1)
             comp = rnd.choice(pc.COMPONENTS)
@@ -67,10 +68,15 @@ def run(ctx, o, cases, seed, log=print, to_dev=None, to_host=None):
             fuse = rnd.random() < 0.5
             opts = {}
             if fuse and rnd.random() < 0.7:  # the batch form of the fused kernel (pair-addressed table) on any geometry
-                opts = {"vss.fused_hash": rnd.choice([0, 2, 2]), "vss.fused_unroll": rnd.choice([1, 2, 4]),
-                        "slices": rnd.choice([0, 1, 3]), "vss.merge": rnd.choice([0, 2, 3, 3]), "vss.groups": rnd.choice([-1, 0, 2, 3])}
+                opts = {"vss.fused_hash": rnd.choice([0, 2, 2]), "vss.fused_unroll": rnd.choice([1, 2, 4, 4]),
+                        "slices": rnd.choice([0, 1, 3]), "vss.merge": rnd.choice([0, 2, 3, 3]), "vss.groups": rnd.choice([-1, 0, 2, 3]),
+                        "vss.rle": rnd.choice([0, 1, 1])}  # round 4: the run-length mode voted / forced (lives in the unroll-4 form)
             with pc.options(ctx, **opts):
                 pc.check_vectorscope(ctx, o, w, h, dist, ls, fuse=fuse, colorspace=cs)
+                if fuse and w >= 4:  # screen-like content: flat areas, rectangles, sprinkled detail, greys, random alpha
+                    rgb = pc.screen_frame(w, h, case, detail=rnd.choice([0.0, 0.01, 0.03, 0.3]), rects=rnd.choice([0, 3, 12, 60]), linesize=ls,
+                                          grey=rnd.random() < 0.2, alpha_noise=rnd.random() < 0.3)
+                    pc.check_vectorscope_rgb_frame(ctx, o, rgb, w, cs, "fuzz screen")
         except Exception as e:  # noqa: BLE001
             log("FAIL " + tag + " -- " + repr(e)[:300])
             raise
