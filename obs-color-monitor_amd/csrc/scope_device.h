@@ -245,6 +245,34 @@ __device__ __forceinline__ bool scope_last_arrival(u32 *ticket, u32 group_size, 
 	return *lds_flag != 0;
 }
 
+/* Fair shares of the SIMD.  The instruction arbiter serves the OLDEST ready wave first; in a loop with workgroup barriers that
+ * starves the youngest waves for good -- in scope_trio_kernel waves 0-3 of a workgroup (the oldest on their SIMDs) were through
+ * their share of a 64-frame launch in 321 us, waves 12-15 in 503 us, and everybody waited for those at every barrier while the
+ * SIMD ran on fewer and fewer waves (tools/trio_trace.py, profiles/round4/trio_trace.txt).  So the issue priority goes round:
+ * in round r the age class (wave / 4 + r) mod 4 is served first.  wave and round are wave-uniform. */
+#ifndef SCOPE_PRIO_ROUNDS
+#define SCOPE_PRIO_ROUNDS 1 /* 0: left to the arbiter (A/B) */
+#endif
+__device__ __forceinline__ void scope_prio_round(u32 wave, u32 round)
+{
+	if (!SCOPE_PRIO_ROUNDS)
+		return;
+	switch (((wave >> 2) + round) & 3u) {
+	case 0:
+		__builtin_amdgcn_s_setprio(0);
+		break;
+	case 1:
+		__builtin_amdgcn_s_setprio(1);
+		break;
+	case 2:
+		__builtin_amdgcn_s_setprio(2);
+		break;
+	default:
+		__builtin_amdgcn_s_setprio(3);
+		break;
+	}
+}
+
 /* Slice s of S of `total` cells. */
 __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
 {

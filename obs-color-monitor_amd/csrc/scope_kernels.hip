@@ -140,6 +140,12 @@ __device__ __forceinline__ u32 scope_slice_begin_cells(u32 total, u32 s, u32 S)
 	return c & ~((u32)SCOPE_SLICE_ALIGN - 1u);
 }
 
+#ifndef WVS_PRIO
+#define WVS_PRIO 1 /* the same inside scope_wvs_kernel's units, narrow-strip form only (see there); 0: A/B */
+#endif
+#ifndef SCOPE_STREAM_PRIO
+#define SCOPE_STREAM_PRIO 1 /* the waves' issue priority goes round, a step per pair of batches (scope_prio_round); 0: A/B */
+#endif
 #ifndef SCOPE_STREAM_MAIN
 #define SCOPE_STREAM_MAIN 1 /* 0: every batch through the checked form (A/B) */
 #endif
@@ -151,6 +157,8 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	if (c0 >= c1)
 		return;
 	const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const u32 wave_u = (u32)__builtin_amdgcn_readfirstlane((int)wave);
+	(void)wave_u;
 	const u32 lg = 64u >> glog2;            /* lanes per group */
 	const u32 g = lane >> (6u - glog2);     /* my group = my stream */
 	const u32 tg = blockDim.x >> glog2;     /* lanes of the workgroup on one stream */
@@ -160,6 +168,9 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	const u32 longest = (len + (1u << glog2) - 1u) >> glog2;
 	const u32 step = (u32)U * tg;
 	const u32 batches = (longest + step - 1u) / step;
+	/* the priority rounds only where a slice is many batches long: launches of a few frames run two to six batches per slice
+	 * and lost 1 % to them (visit p1, profiles/round4/ab_prio_rounds.txt) */
+	const bool PRIO = SCOPE_STREAM_PRIO != 0 && batches >= 16u;
 
 	u32 c = s0 + wave * lg + (lane & (lg - 1u));
 	const u32 dq = tg / ncols;
@@ -247,6 +258,8 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 		c += step;                                                                         \
 	} while (0)
 		for (; b + 2 < full; b += 2) {
+			if (PRIO)
+				scope_prio_round(wave_u, b >> 1);
 			SCOPE_ISSUE_FULL(vb);
 			SCOPE_BIN(va, yes);
 			SCOPE_ISSUE_FULL(va);
@@ -255,6 +268,8 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 #undef SCOPE_ISSUE_FULL
 	}
 	for (; b < batches; b += 2) {
+		if (PRIO)
+			scope_prio_round(wave_u, b >> 1);
 		SCOPE_ISSUE(vb, okb);
 		SCOPE_BIN(va, oka);
 		SCOPE_ISSUE(va, oka);
@@ -934,6 +949,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 			sl += 2;
 		}
 		for (; sl < ub.slots; sl += 2) {
+			if (WVS_PRIO && SW == 16) /* the narrow-strip form only (one frame per call: +1.7 %); batches of 64-column strips LOSE 2 % to it (visit p2) */
+				scope_prio_round((u32)__builtin_amdgcn_readfirstlane((int)wave), sl >> 1); /* fair shares of the SIMD: scope_device.h */
 			WVS_BIN(va, oka);
 			WVS_ISSUE(va, oka);
 			WVS_BIN(vb, okb);

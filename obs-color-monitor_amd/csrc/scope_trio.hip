@@ -59,6 +59,9 @@
 #ifndef TRIO_INTERLEAVE
 #define TRIO_INTERLEAVE 1 /* 32-column strips: a frame's slices interleave its strips (see the kernel); 0: contiguous ranges (A/B) */
 #endif
+#ifndef TRIO_PRIO
+#define TRIO_PRIO 1 /* the waves' issue priority goes round (see the kernel); 0: left to the arbiter (oldest first) */
+#endif
 #ifndef TRIO_SKIP_EMPTY
 #define TRIO_SKIP_EMPTY 1
 #endif
@@ -118,6 +121,22 @@
 #define TRIO_LDS_BYTES(nch) (VssTable<TRIO_HASH>::words * 4u + (nch) * 8192u)
 #endif
 #define TRIO_VSS_WORDS (VssTable<TRIO_HASH>::words)
+
+/* Development build only (`make trio_variant VARIANT_FLAGS=-DTRIO_TRACE VARIANT_TAG=trace`, tools/trio_trace.py): every wave adds up
+ * where its time goes -- waiting at the strip's barriers, the read-out, the clamp passes (their barriers included), everything --
+ * in 100 MHz ticks, and leaves the four sums in a device array.  Never the product. */
+#ifdef TRIO_TRACE
+__device__ unsigned long long scope_trio_dbg[256 * 16 * 4];
+extern "C" int scope_trio_debug_read(unsigned long long *out)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scope_trio_dbg), sizeof(scope_trio_dbg));
+}
+#define TRIO_T(var) const unsigned long long var = wall_clock64()
+#define TRIO_T_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define TRIO_T(var) do { } while (0)
+#define TRIO_T_ADD(acc, a, b) do { } while (0)
+#endif
 
 /* one texel into the waveform table: value v of channel c -> byte c * CHB + v * 4 VS + lane_base (replica and column pair) */
 template <int CH, u32 VS> __device__ __forceinline__ void trio_count(u32 *tab, u32 px, u32 lane_base, u32 inc)
@@ -294,22 +313,32 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	u32 hs[3][NV] = {}; /* HIS: this thread's (value, column group) totals over the slice's strips */
 	const u32 value0 = threadIdx.x >> GL, g4 = threadIdx.x & ((1u << GL) - 1u);
 
+#ifdef TRIO_TRACE
+	unsigned long long t_barrier = 0, t_readout = 0, t_clamp = 0;
+	const unsigned long long t_start = wall_clock64();
+#endif
+	u32 prio_round = 0; /* uniform */
 	for (u32 s_b = 0; s_b < nst; s_b++) {
 		const bool live_b = (first + s_b * stride) * (u32)SW + 2u * pair < W; /* this lane's column pair exists in the strip */
 		const bool strip_whole = (first + s_b * stride + 1u) * (u32)SW <= W;  /* ... and so does every lane's (uniform) */
 		(void)live_b;
 		(void)strip_whole;
 		for (u32 g_b = 0; g_b < Gp; g_b += (u32)D) {
+			if (TRIO_PRIO)
+				scope_prio_round(wave, prio_round++); /* fair shares of the SIMD: scope_device.h */
 			/* the vectorscope's 16-bit counters: a clamp pass (every counter min(c, 255): exact, the reference saturates
 			 * at 255) before the round that could carry one past 65535 -- at round granularity, not per strip: a 4K strip is
 			 * 34 560 texels, two strips would overflow, but five rounds of 12 288 fit, so 60 strips need 36 passes and
 			 * not 59 (a pass reads the whole 128 KiB table: 5 % of the kernel when taken once per strip) */
 			if (since + round_px > VSS_EPOCH_PIXELS && !(TRIO_EXP & 8)) { /* uniform across the workgroup */
+				TRIO_T(tc0);
 				vss_flush_lane<TRIO_HASH>(tab, st); /* pending texels belong to the epoch that ends here */
 				__syncthreads();
 				vss_clamp_pass(vt, TRIO_VSS_WORDS);
 				__syncthreads();
 				since = 0;
+				TRIO_T(tc1);
+				TRIO_T_ADD(t_clamp, tc0, tc1);
 			}
 			since += round_px;
 			/* One slot = the two texels a lane loaded.  FAST: every lane of the wave holds a real texel pair (the strip is whole
@@ -425,7 +454,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		const bool last_strip = s_b + 1u == nst;
 		if (last_strip)
 			vss_flush_lane<TRIO_HASH>(tab, st); /* the lanes' pending texels, before the table is read out */
+		TRIO_T(tb0);
 		__syncthreads();
+		TRIO_T(tb1);
+		TRIO_T_ADD(t_barrier, tb0, tb1);
 		{
 			/* the strip's 256 x 16 waveform texels: thread -> (value, group of four columns); the reader of a counter zeroes it */
 			const u32 xs = (first + s_b * stride) * (u32)SW;
@@ -465,10 +497,23 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 				}
 			}
 		}
+		TRIO_T(tb2);
+		TRIO_T_ADD(t_readout, tb1, tb2);
 		if (last_strip)
 			break;
 		__syncthreads();
+		TRIO_T(tb3);
+		TRIO_T_ADD(t_barrier, tb2, tb3);
 	}
+#ifdef TRIO_TRACE
+	if (lane == 0) {
+		unsigned long long *d = &scope_trio_dbg[((size_t)(blockIdx.x & 255u) * 16u + wave) * 4u];
+		d[0] = wall_clock64() - t_start;
+		d[1] = t_barrier;
+		d[2] = t_readout;
+		d[3] = t_clamp;
+	}
+#endif
 #undef TRIO_ISSUE
 #undef TRIO_OK
 

@@ -175,6 +175,7 @@ static inline int __ffsll(long long v)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
 #define __hip_atomic_exchange(p, v, order, scope) __atomic_exchange_n((p), (v), __ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0) /* issue priority: nothing to emulate */
 static inline void __threadfence()
 {
 	__sync_synchronize();
