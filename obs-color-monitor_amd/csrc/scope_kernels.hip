@@ -149,7 +149,7 @@ __device__ __forceinline__ u32 scope_slice_begin_cells(u32 total, u32 s, u32 S)
 #ifndef SCOPE_STREAM_MAIN
 #define SCOPE_STREAM_MAIN 1 /* 0: every batch through the checked form (A/B) */
 #endif
-template <int VECW, int U, bool NT, bool CONTIG, bool MAIN = CONTIG, typename Pro, typename Hook, typename F>
+template <int VECW, int U, bool NT, bool CONTIG, bool MAIN = CONTIG, bool ROUNDS = false, typename Pro, typename Hook, typename F>
 __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 c0, u32 c1,
 					     u32 glog2, Pro &&after_first_issue, Hook &&before_batch, F &&fn)
 {
@@ -168,9 +168,11 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	const u32 longest = (len + (1u << glog2) - 1u) >> glog2;
 	const u32 step = (u32)U * tg;
 	const u32 batches = (longest + step - 1u) / step;
-	/* the priority rounds only where a slice is many batches long: launches of a few frames run two to six batches per slice
-	 * and lost 1 % to them (visit p1, profiles/round4/ab_prio_rounds.txt) */
-	const bool PRIO = SCOPE_STREAM_PRIO != 0 && batches >= 16u;
+	/* priority rounds (scope_prio_round): the histogram's kernels only -- RGB +0.8 ... 1.6 %, the fused Y'CbCr form +5 %; the
+	 * vectorscope's forms are indifferent to them or lose (plain +0.2 % on noise, -0.7 % on ramps; fused -0.8 % on noise) -- and
+	 * only where a slice is many batches long: launches of a few frames run two to six batches per slice and lost 1 % to them
+	 * (visits p1 - p3, profiles/round4/ab_prio_rounds.txt) */
+	const bool PRIO = ROUNDS && SCOPE_STREAM_PRIO != 0 && batches >= 16u;
 
 	u32 c = s0 + wave * lg + (lane & (lg - 1u));
 	const u32 dq = tg / ncols;
@@ -645,9 +647,9 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 					       }
 		};
 		if (linesize == ncols * 16u) /* uniform: rows without padding */
-			scope_stream<4, U, NT, true, FUSE>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
+			scope_stream<4, U, NT, true, FUSE, true>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
 		else
-			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
+			scope_stream<4, U, NT, false, false, true>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
 	} else {
 		scope_stream<1, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing,
 				       [&](const u32(&q)[U], const bool(&ok)[U]) {
