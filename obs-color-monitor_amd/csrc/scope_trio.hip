@@ -29,12 +29,15 @@
  * meet on one ADDRESS.  With 16-column strips a row segment is half a cache line: slices come in pairs that split a range of
  * strips even / odd, and the two workgroups of a pair are b and b + 8 (same XCD, same L2, same moment).
  *
- * What bounds it (profiles/round4/pmc_sq_three_scope_x64_b5.txt, trio_variants.txt): VALU issue.  30 VALU instructions per
- * texel (K0 11.5, the waveform's three adds 7, the vectorscope's 3.5, the rest loop, read-outs, clamp passes) keep each SIMD's
- * VALU busy 70 % of the kernel with the four waves a 1024-thread workgroup gives it, and the LDS footprint allows one
- * workgroup per CU.  Round 4 measured every other suspect out: halving the waveform's bank conflicts (two replicas) +0 %,
- * whole-line loads and half the barriers (32-column strips) +3 ... 5 %, pair-form vectorscope adds +2 %, a slot without any
- * exec-mask branch +0.5 %, skipping the slots a strip's rounding leaves empty +2 %, more or fewer loads in flight 0 %.
+ * What bounds it (profiles/round4/trio_variants.txt, ab_prio_rounds.txt): 29 VALU instructions per texel (K0 11.5,
+ * the waveform's three adds 7, the vectorscope's 3.5, the rest loop, read-outs, clamp passes) keep each SIMD's VALU busy 74 % of
+ * the kernel with the four waves a 1024-thread workgroup gives it (the LDS footprint allows one workgroup per CU), and the
+ * waveform's three LDS atomics per texel are about as near their limit: with the vectorscope's adds AND K0 compiled out the
+ * kernel reaches 0.59 of the HBM peak, without the waveform's adds 0.565.  Measured in round 4, each in a same-process A/B: two
+ * waveform replicas (bank conflicts halved) +0 %, whole-line loads and half the barriers (32-column strips) +3 ... 5 %, pair-form
+ * vectorscope adds +2 %, a slot without any exec-mask branch +0.5 %, skipping the slots a strip's rounding leaves empty +2 %,
+ * contiguous read-out stores +2.4 %, the waves' issue priority going round (scope_prio_round: the arbiter's oldest-first order
+ * starved waves 12-15 of every workgroup) +2.3 % on noise and +7.4 % on screen content, more or fewer loads in flight 0 %.
  * Tried and dropped in round 3: deeper or shallower load queues, skipping K0 work of empty slots in front of EVERY slot.
  * Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables), H <= 65535 (a column's rows fit the waveform's
  * 16-bit counters).
