@@ -12,8 +12,6 @@ import os
 import numpy as np
 import pytest
 
-import parity_cases as pc
-
 pytestmark = pytest.mark.gpu
 
 W, H, N = 3840, 2160, 64

@@ -433,6 +433,29 @@ def test_fused_vectorscope_screen_content(hip_ctx, oracle, forced):
         pc.assert_same(got[i], oracle.vectorscope(oracle.rgb_to_yuv(frames_[i], w, 2), w), f"screen batch frame {i} forced={forced}")
 
 
+def test_fused_vectorscope_run_length_mode_stress(hip_ctx, oracle):
+    """The run-length mode keeps nothing in registers between cells but packs rough cells through a scratch row of the wave in the
+    LDS: 400 back-to-back launches of the batch form with the mode forced, on noise (every cell rough: three packed rounds per
+    wave-cell), screen-like content and bars, every table of every launch compared (the tables of one input must never change)."""
+    import torch
+
+    w, h, n = 1280, 720, 6
+    frames_ = [oracle.fill_frame(w, h, 1, 700 + i) for i in range(2)] + [pc.screen_frame(w, h, 800 + i, detail=0.05, rects=40) for i in range(2)] + \
+              [oracle.fill_frame(w, h, 4, 3), pc.screen_frame(w, h, 9, detail=0.5, rects=5, alpha_noise=True)]
+    want = np.stack([oracle.vectorscope(oracle.rgb_to_yuv(f, w, 2), w) for f in frames_])
+    d = torch.from_numpy(np.stack(frames_)).cuda()
+    b = hip_ctx.make_device_batch(d, 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+    outs = [torch.empty((n, 256, 256), dtype=torch.uint8, device="cuda") for _ in range(8)]
+    with pc.options(hip_ctx, **{"vss.rle": 1, "vss.fused_unroll": 4, "slices": 2}):
+        for rep in range(50):
+            for o in outs:
+                hip_ctx.vectorscope_batch_dev(b, o, sync=False)
+            hip_ctx.sync()
+            for k, o in enumerate(outs):
+                got = o.cpu().numpy()
+                assert np.array_equal(got, want), f"launch {rep * 8 + k}: run-length mode changed a table"
+
+
 @pytest.mark.parametrize("cs", [1, 2])
 @pytest.mark.parametrize("hash_", [0, 1, 2])
 def test_fused_vectorscope_all_colours(hip_ctx, oracle, cs, hash_):
