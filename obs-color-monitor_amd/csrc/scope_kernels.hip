@@ -289,6 +289,14 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
  * one frame per call, the ring of three) is dominated by its start-up, and carrying the mode's code cost it 2.5-4 % on noise and
  * natural content for +4 % (one frame) / +14 % (three) on screen content (visit c4/c5, profiles/round4/ab_fused_vectorscope.txt). */
 #define VSS_RLE_IN(U) (VSS_RLE && (U) == 4)
+#ifndef VSS_RLE_KEYS
+#define VSS_RLE_KEYS 1 /* 0: the plain (staged-plane) vectorscope without the run-length form of its absorb mode (A/B) */
+#endif
+#ifndef VSS_RK_LO
+#define VSS_RK_LO 16u /* flat lanes of 64 at the vote: from here the run-length form ... */
+#define VSS_RK_HI 60u /* ... up to here (above: the per-lane absorb mode, whose colour then rarely changes) */
+#endif
+#define VSS_RLE_KEYS_IN(U, FUSE) (VSS_RLE_KEYS && (U) == 4 && !(FUSE))
 /* run-length mode's scratch behind the fused kernel's table: per wave, texels 1-3 of up to 64 lanes */
 #define VSS_RLE_SCRATCH_WORDS_PER_WAVE 192u
 #define VSS_RLE_SCRATCH_BYTES (16u * VSS_RLE_SCRATCH_WORDS_PER_WAVE * 4u)
@@ -454,6 +462,10 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		else
 			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_pairs);
 	} else if (VECW == 4) {
+		u32 keys_rle = 0; /* wave-uniform */
+		const u32 rk_lane = threadIdx.x & 63u, rk_run = min(64u >> glog2, 16u);
+		(void)rk_lane;
+		(void)rk_run;
 		auto bin_cells = [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
 					       u32 idx[U][4];
 #pragma unroll
@@ -479,11 +491,41 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 							       for (int k = 0; k < U; k++)
 								       flat &= !ok[k] || ((idx[k][0] == idx[k][1]) & (idx[k][1] == idx[k][2]) &
 											  (idx[k][2] == idx[k][3]));
-							       absorb_verdict = (u32)__builtin_amdgcn_readfirstlane((int)(__popcll(__ballot(flat)) >= 16));
+							       const u32 nflat = (u32)__popcll(__ballot(flat));
+							       absorb_verdict = (u32)__builtin_amdgcn_readfirstlane((int)(nflat >= 16));
+							       /* MIXED windows -- some lanes flat, some not: screen capture -- take the run-length form of the
+								* absorb mode (below): no per-lane colour, which on such content changes with every cell */
+							       if (VSS_RLE_KEYS_IN(U, FUSE)) {
+								       const u32 mixed = (u32)__builtin_amdgcn_readfirstlane((int)((nflat >= VSS_RK_LO && nflat < VSS_RK_HI) || rle_force));
+								       if (mixed && !keys_rle) /* entering: the lanes' counts go to the table (rare) */
+									       vss_flush_lane<HASH>(tab, st);
+								       keys_rle = mixed;
+							       }
 						       }
 						       absorb = __builtin_amdgcn_readfirstlane(absorb_verdict) != 0;
 					       }
-					       if (__builtin_expect(absorb, false)) {
+					       if (VSS_RLE_KEYS_IN(U, FUSE) && MERGE == 3 && __builtin_expect(__builtin_amdgcn_readfirstlane(keys_rle) != 0, false)) {
+						       /* Run-length form on keys (the fused kernel's bin_rle without K0): flat cells that continue the
+							* cell of the lane below add nothing, the head of a run adds 4 x its length, the other cells add
+							* their four texels. */
+#pragma unroll
+						       for (int k = 0; k < U; k++) {
+							       const u32 i0 = idx[k][0];
+							       const bool flat = ok[k] && ((i0 == idx[k][1]) & (i0 == idx[k][2]) & (i0 == idx[k][3]));
+							       const u32 tag = flat ? (i0 | 0x80000000u) : (0x40000000u | rk_lane);
+							       const bool cont = flat && tag == scope_lane_below(tag, 0u) && (rk_lane & (rk_run - 1u)) != 0u;
+							       const u64 breaks = ~__ballot(cont);
+							       if (flat && !cont) {
+								       const u64 above = ((breaks >> 1) | (1ull << 63)) >> rk_lane;
+								       vss_add<HASH>(tab, i0, 4u * (u32)__ffsll((long long)above));
+							       } else if (ok[k] && !flat) {
+								       vss_add<HASH>(tab, i0, 1);
+								       vss_add<HASH>(tab, idx[k][1], 1);
+								       vss_add<HASH>(tab, idx[k][2], 1);
+								       vss_add<HASH>(tab, idx[k][3], 1);
+							       }
+						       }
+					       } else if (__builtin_expect(absorb, false)) {
 #pragma unroll
 						       for (int k = 0; k < U; k++)
 							       if (ok[k])

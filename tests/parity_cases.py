@@ -115,6 +115,27 @@ def check_fused_screen_content(ctx, oracle, sizes, forced):
                 check_vectorscope(ctx, oracle, w, h, dist, ls, fuse=True, colorspace=2)
 
 
+def check_plain_screen_content(ctx, oracle, sizes, forced=0):
+    """The plain (staged-plane) vectorscope on the Y'CbCr planes of screen-like content: windows of cells where some lanes are
+    flat and some are not take the run-length form of the absorb mode (scope_kernels.hip, keys_rle; the batch form, vss.unroll 4),
+    all-flat and all-rough windows the forms they took before.  forced 1: that form on any content (vss.rle = 1)."""
+    with options(ctx, **({"vss.rle": 1} if forced else {})):
+        _plain_screen_content(ctx, oracle, sizes, forced)
+
+
+def _plain_screen_content(ctx, oracle, sizes, forced):
+    for (w, h, ls) in sizes:
+        for seed, kw in enumerate(({}, {"detail": 0.0}, {"detail": 0.3}, {"grey": True}, {"alpha_noise": True, "detail": 0.01},
+                                   {"rects": 200, "detail": 0.0}, {"rects": 60, "detail": 0.1})):
+            rgb = screen_frame(w, h, 177 + seed, linesize=ls, **kw)
+            yuv = oracle.rgb_to_yuv(rgb, w, 1 + seed % 2)
+            got, st = ctx.vectorscope(yuv=yuv, width=w)
+            assert st == 0
+            assert_same(got, oracle.vectorscope(yuv, w), f"plain vectorscope {w}x{h} ls{ls} screen {kw} forced={forced}")
+        for dist in (1, 2, 3, 4, 5):
+            check_vectorscope(ctx, oracle, w, h, dist, ls, fuse=False)
+
+
 def check_waveform(ctx, oracle, w, h, dist, components, linesize=None, fuse=False, colorspace=2):
     rgb, yuv = frames(oracle, w, h, dist, linesize, colorspace=colorspace)
     want = oracle.waveform(rgb, yuv, w, components)

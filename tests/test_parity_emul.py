@@ -410,3 +410,12 @@ def test_vectorscope_side_reduce(emul_ctx, oracle):
 
 def test_pipeline_without_histogram(emul_ctx, oracle):
     pc.check_pipeline_without_histogram(emul_ctx, oracle, 72, 20)
+
+
+@pytest.mark.parametrize("forced", [0, 1])
+def test_plain_vectorscope_screen_content(emul_ctx, oracle, forced):
+    """The staged-plane vectorscope on screen-like content: the run-length form of its absorb mode (mixed windows), with the
+    batch's unroll (the form that carries it), the default, and one workgroup per frame."""
+    for slices, unroll in ((0, 0), (1, 4), (0, 4), (7, 1)):
+        with pc.options(emul_ctx, **{"slices": slices, "vss.unroll": unroll}):
+            pc.check_plain_screen_content(emul_ctx, oracle, [(256, 96, None), (132, 50, 132 * 4 + 16), (1024, 40, None)], forced)

@@ -1011,3 +1011,13 @@ def test_vectorscope_side_reduce(hip_ctx, oracle):
 
 def test_pipeline_without_histogram(hip_ctx, oracle):
     pc.check_pipeline_without_histogram(hip_ctx, oracle, 1920, 1080, depth=3)
+
+
+@pytest.mark.parametrize("forced", [0, 1])
+def test_plain_vectorscope_screen_content(hip_ctx, oracle, forced):
+    """The staged-plane vectorscope on screen-like content: the run-length form of its absorb mode (mixed windows), with the
+    batch's unroll (the form that carries it), the default, and one workgroup per frame."""
+    pc.check_plain_screen_content(hip_ctx, oracle, [(3840, 2160, None)], forced)
+    for slices, unroll in ((0, 0), (1, 4), (0, 4), (7, 1)):
+        with pc.options(hip_ctx, **{"slices": slices, "vss.unroll": unroll}):
+            pc.check_plain_screen_content(hip_ctx, oracle, [(640, 360, None), (509, 130, 2048)], forced)
