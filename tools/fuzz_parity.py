@@ -77,6 +77,16 @@ def run(ctx, o, cases, seed, log=print, to_dev=None, to_host=None):
                     rgb = pc.screen_frame(w, h, case, detail=rnd.choice([0.0, 0.01, 0.03, 0.3]), rects=rnd.choice([0, 3, 12, 60]), linesize=ls,
                                           grey=rnd.random() < 0.2, alpha_noise=rnd.random() < 0.3)
                     pc.check_vectorscope_rgb_frame(ctx, o, rgb, w, cs, "fuzz screen")
+            if not fuse and w >= 4:  # the staged-plane kernel's run-length form on keys (its unroll-4 form), voted / forced
+                with pc.options(ctx, **{"vss.unroll": rnd.choice([0, 4, 4]), "vss.rle": rnd.choice([0, 1]), "slices": rnd.choice([0, 1, 3]),
+                                        "vss.groups": rnd.choice([-1, 0, 2, 3])}):
+                    rgb = pc.screen_frame(w, h, case, detail=rnd.choice([0.0, 0.01, 0.03, 0.3]), rects=rnd.choice([0, 3, 12, 60]), linesize=ls,
+                                          grey=rnd.random() < 0.2, alpha_noise=rnd.random() < 0.3)
+                    yuv = o.rgb_to_yuv(rgb, w, cs)
+                    got, st = ctx.vectorscope(yuv=yuv, width=w)
+                    assert st == 0
+                    pc.assert_same(got, o.vectorscope(yuv, w), "fuzz screen, staged planes")
+                    pc.check_vectorscope(ctx, o, w, h, dist, ls, fuse=False, colorspace=cs)
         except Exception as e:  # noqa: BLE001
             log("FAIL " + tag + " -- " + repr(e)[:300])
             raise
