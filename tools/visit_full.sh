@@ -19,6 +19,10 @@ grep -E '^\{' $out/prof_headline.log | head -1 > $out/bench_headline_under_rocpr
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_trio -o t -- \
    python $GRAFT_REPO_ROOT/bench.py --steps 1000 --warmup 50 --no-cpu --no-extras --placement-candidates 1 --workload three_scope) > $out/prof_trio.log 2>&1
 for f in $(find $out/prof_trio -name "*kernel_stats.csv"); do cp $f $out/rocprof_kernel_stats_${tag}_three_scope_$fp.csv; cut -c1-60,150-330 $f | grep -E "scope_" | head -2; done
+for wl in vectorscope_rgb waveform histogram; do (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_$wl -o w -- \
+   python $GRAFT_REPO_ROOT/bench.py --steps 1000 --warmup 50 --no-cpu --no-extras --placement-candidates 1 --workload $wl) > $out/prof_$wl.log 2>&1
+  for f in $(find $out/prof_$wl -name "*kernel_stats.csv"); do cp $f $out/rocprof_kernel_stats_${tag}_${wl}_$fp.csv; cut -c1-60,150-330 $f | grep -E "scope_" | head -1; done
+  grep -E '^\{' $out/prof_$wl.log | head -1 > $out/bench_${wl}_under_rocprof_$fp.json; done
 for fr in 1 3; do (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_x$fr -o v -- \
    python $GRAFT_REPO_ROOT/bench.py --frames $fr --steps 2000 --warmup 100 --no-cpu --no-extras --placement-candidates 1) > $out/prof_x$fr.log 2>&1
   for f in $(find $out/prof_x$fr -name "*kernel_stats.csv"); do cp $f $out/rocprof_kernel_stats_${tag}_frames${fr}_$fp.csv; done; done
