@@ -116,8 +116,8 @@ int scope_ctx_fence(scope_ctx *ctx);
 int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
 /* Tunables for A/B measurements (the defaults are the measured best, profiles/):
  *   "vss.merge" 0|2|3        plain adds | absorb mode always | absorb mode by wave vote
- *   "vss.rle" 0|1            the fused-K0 vectorscope's run-length mode (flat cells as runs across lanes; the batch form of the kernel):
- *                            by wave vote (0) or on every content (1, tests)
+ *   "vss.rle" 0|1            the vectorscope kernels' run-length mode (flat cells as runs across lanes; the batch form of the kernel,
+ *                            fused K0 and staged planes): by wave vote (0) or on every content (1, tests)
  *   "vss.unroll" 0|1|2|4, "vss.fused_unroll" 0|1|2|4, "his.unroll" 0|1|2|4   16-byte loads per lane per batch (0: by launch size)
  *   "vss.fused_hash" -1|0|1|2   the fused-K0 vectorscope's LDS table: as "vss.hash" (0, 1) or rows of 136 words with the LDS
  *                              operands of two pixels worked out in one register (2); -1: the default, 2
