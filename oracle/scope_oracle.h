@@ -12,7 +12,12 @@
  * written from the reference's semantics, function by function, with each function
  * citing the reference file:line it follows, and it is cross-checked against an
  * independently written numpy restatement (oracle/scope_oracle.py) and against
- * hand-derived known answers (tests/test_oracle.py).
+ * hand-derived known answers (tests/test_oracle.py).  The only expected values the
+ * reference itself carries for this path -- the vectorscope graticule's colour targets
+ * (src/vectorscope.c:283-316) and its integer RGB2U/V macros (src/vectorscope.c:28-34) --
+ * are tolerances, not vectors (a +-6 box; 10-bit coefficients): K0 is held against them
+ * (within 2 of every target, within 3 / 2 of the macros over all 2^24 colours), which pins
+ * the matrix, the axes and the scale, not the last bit.
  *
  * All citations are relative to /root/reference (obs-color-monitor v0.9.5).
  */

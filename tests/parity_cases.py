@@ -115,6 +115,29 @@ def check_fused_screen_content(ctx, oracle, sizes, forced):
                 check_vectorscope(ctx, oracle, w, h, dist, ls, fuse=True, colorspace=2)
 
 
+def check_reference_colour_targets(ctx):
+    """The library against the vectorscope graticule's colour targets, the one table of expected chroma the reference holds
+    (src/vectorscope.c:283-316; data and rule in tests/test_oracle.py): the 100 % and 75 % colour bars through
+    scope_convert_rgb_yuv, and through the fused-K0 and the staged vectorscope -- the twelve bins that light up lie on the
+    twelve targets of the matrix in use.  No oracle call."""
+    import test_oracle as to
+
+    bars = np.repeat(np.repeat(to.colour_bars_plane().reshape(1, 12, 4), 16, axis=1), 8, axis=0).reshape(8, 12 * 16 * 4)  # 192 x 8 texels
+    bars = np.ascontiguousarray(bars)
+    w = 12 * 16
+    to.check_bars_against_the_reference_targets(
+        lambda cs: [(int(p[0]), int(p[2])) for p in ctx.convert_rgb_yuv(bars, w, cs)[0].reshape(w, 4)[::16]])
+    for cs in (1, 2):
+        tables = [ctx.vectorscope(rgb=bars, width=w, colorspace=cs, fuse_k0=True), ctx.vectorscope(yuv=ctx.convert_rgb_yuv(bars, w, cs), width=w)]
+        for vs, st in tables:
+            assert st == 0
+            rows, cols = np.nonzero(vs)
+            lit = {(int(c), 255 - int(r)) for r, c in zip(rows, cols)}
+            assert len(lit) == 12 and all(vs[255 - v, u] == 128 for (u, v) in lit)  # 16 x 8 texels per bar
+            for t in to.REF_COLOUR_TARGETS[cs]:
+                assert any(max(abs(u - t[0]), abs(v - t[1])) <= 2 for (u, v) in lit), (cs, t, sorted(lit))
+
+
 def check_plain_screen_content(ctx, oracle, sizes, forced=0):
     """The plain (staged-plane) vectorscope on the Y'CbCr planes of screen-like content: windows of cells where some lanes are
     flat and some are not take the run-length form of the absorb mode (scope_kernels.hip, keys_rle; the batch form, vss.unroll 4),

@@ -419,3 +419,8 @@ def test_plain_vectorscope_screen_content(emul_ctx, oracle, forced):
     for slices, unroll in ((0, 0), (1, 4), (0, 4), (7, 1)):
         with pc.options(emul_ctx, **{"slices": slices, "vss.unroll": unroll}):
             pc.check_plain_screen_content(emul_ctx, oracle, [(256, 96, None), (132, 50, 132 * 4 + 16), (1024, 40, None)], forced)
+
+
+def test_reference_colour_targets(emul_ctx):
+    """The kernels (compiled for the CPU) against the graticule's colour targets, the expected chroma the reference itself holds."""
+    pc.check_reference_colour_targets(emul_ctx)

@@ -501,6 +501,27 @@ def test_k0_all_colours(hip_ctx, oracle, cs):
     pc.assert_same(got, want, f"K0 exhaustive cs{cs}")
 
 
+def test_hip_k0_against_what_the_reference_holds(hip_ctx):
+    """The HIP path against the two pieces of expected chroma the reference itself carries, no oracle in between
+    (tests/test_oracle.py holds the data and the same checks for the oracle):
+      * the graticule's colour targets (src/vectorscope.c:283-316): the 100 % and 75 % colour bars through scope_convert_rgb_yuv,
+        and through the fused-K0 and the staged vectorscope -- the twelve bins that light up lie on the twelve targets;
+      * the integer macros RGB2U/V_601 / _709 (src/vectorscope.c:28-34): all 2^24 colours through the K0 kernel stay within 3 (U)
+        and 2 (V) of them."""
+    pc.check_reference_colour_targets(hip_ctx)
+    v = np.arange(1 << 24, dtype=np.uint32) | np.uint32(0xFF000000)
+    rgb = v.view(np.uint8).reshape(4096, 4096 * 4)
+    b, g, r = (rgb.reshape(-1, 4)[:, i].astype(np.int64) for i in range(3))
+
+    def cdiv(a, d):
+        return np.sign(a) * (np.abs(a) // d)
+
+    for cs, (mu, mv) in ((1, (cdiv(-150 * r - 296 * g + 448 * b, 1024) + 128, cdiv(448 * r - 374 * g - 72 * b, 1024) + 128)),
+                         (2, (cdiv(-102 * r - 346 * g + 450 * b, 1024) + 128, cdiv(450 * r - 408 * g - 40 * b, 1024) + 128))):
+        got = hip_ctx.convert_rgb_yuv(rgb, 4096, cs).reshape(-1, 4)
+        assert int(np.abs(got[:, 0].astype(np.int64) - mu).max()) <= 3 and int(np.abs(got[:, 2].astype(np.int64) - mv).max()) <= 2
+
+
 @pytest.mark.parametrize("cs", [1, 2])
 def test_fused_k0_all_colours(hip_ctx, oracle, cs):
     """The fused kernels convert on the fly (fixed-point fast path + fp32 redo near a step): all 2^24 colours through
