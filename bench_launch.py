@@ -187,7 +187,8 @@ def launcher(args, argv):
     ladder = reduce_ladder(args)
     attempts, deadline = [], args.launch_timeout
     for extra in ladder:
-        line, outcome = launch_once(argv + extra, args.gpus, deadline)
+        # the ranks' own watchdog follows the deadline of THEIR attempt (bench.py: rank_timeout = launch_timeout - 15 s)
+        line, outcome = launch_once(argv + extra + ["--launch-timeout", str(deadline)], args.gpus, deadline)
         outcome["extra_args"] = extra
         attempts.append(outcome)
         ok = line is not None and not outcome["failure"]
