@@ -806,10 +806,25 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_his_kernel(ScopeFrameSet fs
  * scalar branches); per lane there is one constant 32-bit offset, the alpha tests and the atomics.
  * WIDE needs width % 4 == 0, 8-byte aligned rows and a 16-byte aligned table; otherwise texels are
  * loaded and stored one by one. */
+#ifndef WVS_DOT4
+#define WVS_DOT4 1 /* the table address of an add by v_dot4_u32_u8, one instruction instead of two (scope_trio_kernel's gain: +4.7 %).
+		    * Here: the luma mode (fused K0, VALU-bound) +1.7 %, one channel +0.6 %, RGB 0 %; one frame -0.7 %.  The histogram's
+		    * kernels LOSE 1.3 ... 1.7 % with it and do not have it (visit t2, profiles/round4/ab_dot4_addresses.txt) */
+#endif
 template <int CH> __device__ __forceinline__ void wvs_count(u32 *tab, u32 px, u32 wbyte, u32 inc)
 {
 	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1);
 	uint8_t *t = (uint8_t *)tab + wbyte;
+	if (WVS_DOT4) { /* value * 128 + the lane's offset in one v_dot4_u32_u8 (scope_udot4) */
+		uint8_t *t0 = (uint8_t *)tab;
+		if (CH & 1)
+			atomicAdd((u32 *)(t0 + scope_udot4(px, 128u, wbyte)), inc);
+		if (CH & 2)
+			atomicAdd((u32 *)(t0 + slot1 * WVS_CH_WORDS * 4u + scope_udot4(px, 128u << 8, wbyte)), inc);
+		if (CH & 4)
+			atomicAdd((u32 *)(t0 + slot2 * WVS_CH_WORDS * 4u + scope_udot4(px, 128u << 16, wbyte)), inc);
+		return;
+	}
 	if (CH & 1)
 		atomicAdd((u32 *)(t + ((px & 0xffu) << 7)), inc);
 	if (CH & 2)

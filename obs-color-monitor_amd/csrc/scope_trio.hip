@@ -71,6 +71,9 @@
 #ifndef TRIO_FASTSLOT
 #define TRIO_FASTSLOT 1 /* 0: every slot runs the checked form (round 3's; A/B) */
 #endif
+#ifndef TRIO_DOT4
+#define TRIO_DOT4 1 /* the waveform's table addresses by v_dot4_u32_u8, one instruction per add (trio_count); 0: shift and mask (A/B) */
+#endif
 #ifndef TRIO_EXP
 #define TRIO_EXP 0 /* measurement only (wrong tables): bit 0 no waveform adds, 1 no vectorscope adds, 2 no K0, 3 no clamp pass */
 #endif
@@ -146,12 +149,54 @@ template <int CH, u32 VS> __device__ __forceinline__ void trio_count(u32 *tab, u
 {
 	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1);
 	constexpr u32 CHB = 256u * VS * 4u, SH = VS == 32 ? 7u : VS == 16 ? 6u : 5u; /* VS = words per value: 8, 16 or 32 */
+	if (TRIO_DOT4) {
+		/* value << SH + lane_base in ONE instruction: v_dot4_u32_u8 with the factor 1 << SH (32, 64 or 128) in the channel's byte
+		 * (scope_udot4); the channel's table comes in as the ds_add's immediate offset */
+		if (CH & 1)
+			scope_lds_add_at(tab, scope_udot4(px, 1u << SH, lane_base), inc);
+		if (CH & 2)
+			scope_lds_add_at(tab, scope_udot4(px, 1u << (SH + 8u), lane_base) + slot1 * CHB, inc);
+		if (CH & 4)
+			scope_lds_add_at(tab, scope_udot4(px, 1u << (SH + 16u), lane_base) + slot2 * CHB, inc);
+		return;
+	}
 	if (CH & 1)
 		scope_lds_add_at(tab, lane_base + ((px & 0xffu) << SH), inc);
 	if (CH & 2)
 		scope_lds_add_at(tab, lane_base + slot1 * CHB + (((px >> 8) & 0xffu) << SH), inc);
 	if (CH & 4)
 		scope_lds_add_at(tab, lane_base + slot2 * CHB + (((px >> 16) & 0xffu) << SH), inc);
+}
+
+/* The two texels of a lane's column pair at once: the (up to) six addresses first, then the six adds -- an address straight out of
+ * v_dot4_u32_u8 into the ds_add that uses it costs three wait states each time (the compiler pads with s_nop). */
+template <int CH, u32 VS> __device__ __forceinline__ void trio_count2(u32 *tab, u32 p0, u32 p1, u32 lane_base, u32 inc0, u32 inc1)
+{
+	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1);
+	constexpr u32 CHB = 256u * VS * 4u, SH = VS == 32 ? 7u : VS == 16 ? 6u : 5u;
+	if (!TRIO_DOT4) {
+		trio_count<CH, VS>(tab, p0, lane_base, inc0);
+		trio_count<CH, VS>(tab, p1, lane_base, inc1);
+		return;
+	}
+	u32 a0[3], a1[3];
+#pragma unroll
+	for (u32 c = 0; c < 3; c++) {
+		a0[c] = scope_udot4(p0, 1u << (SH + 8u * c), lane_base);
+		a1[c] = scope_udot4(p1, 1u << (SH + 8u * c), lane_base);
+	}
+	if (CH & 1) {
+		scope_lds_add_at(tab, a0[0], inc0);
+		scope_lds_add_at(tab, a1[0], inc1);
+	}
+	if (CH & 2) {
+		scope_lds_add_at(tab, a0[1] + slot1 * CHB, inc0);
+		scope_lds_add_at(tab, a1[1] + slot1 * CHB, inc1);
+	}
+	if (CH & 4) {
+		scope_lds_add_at(tab, a0[2] + slot2 * CHB, inc0);
+		scope_lds_add_at(tab, a1[2] + slot2 * CHB, inc1);
+	}
 }
 
 template <int CH, bool HIS, int SW>
@@ -385,8 +430,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 							/* the alpha test (src/waveform.c:247-248) as the increment: min(alpha, 1), in the low half for the even
 							 * column and in the high half for the odd one -- one SDWA instruction each, no exec mask, and the whole
 							 * slot is one basic block (adding 0 for a transparent texel changes nothing) */
-							trio_count<CH, VS>(tab, p0, lane_base, scope_min_byte3_lo(p0, 1u));
-							trio_count<CH, VS>(tab, p1, lane_base, scope_min_byte3_hi(p1, 1u));
+							trio_count2<CH, VS>(tab, p0, p1, lane_base, scope_min_byte3_lo(p0, 1u), scope_min_byte3_hi(p1, 1u));
 						} else {
 							if ((p0 >> 24) != 0) /* src/waveform.c:247-248 */
 								trio_count<CH, VS>(tab, p0, lane_base, 1u);

@@ -172,6 +172,12 @@ __device__ __forceinline__ unsigned scope_pk_mad_u16(unsigned a, unsigned b, uns
 	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c)); /* a * b + c in each half, mod 2^16 */
 	return r;
 }
+/* v_dot4_u32_u8: a.b0 * b.b0 + a.b1 * b.b1 + a.b2 * b.b2 + a.b3 * b.b3 + c.  With b = a factor in ONE byte it is "that byte of a,
+ * times the factor, plus c" in one instruction -- a table address from a texel's channel (as a shift and a mask it is two). */
+__device__ __forceinline__ unsigned scope_udot4(unsigned a, unsigned b, unsigned c)
+{
+	return __builtin_amdgcn_udot4(a, b, c, false);
+}
 /* (half H of x) << n and value << (byte B of count, its low five bits): the SDWA forms pick the half / the byte out of
  * the register, one instruction each (as a shift and a mask they are two). */
 #define SCOPE_SHL_SEL(name, sel0, sel1)                                                                                 \

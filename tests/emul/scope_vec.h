@@ -157,6 +157,12 @@ static inline unsigned scope_pk_mad_u16(unsigned a, unsigned b, unsigned c)
 	const unsigned hi = ((a >> 16) * (b >> 16) + (c >> 16)) & 0xffffu;
 	return lo | (hi << 16);
 }
+static inline unsigned scope_udot4(unsigned a, unsigned b, unsigned c)
+{
+	for (int i = 0; i < 4; i++)
+		c += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
+	return c;
+}
 static inline unsigned scope_min_byte3_lo(unsigned x, unsigned cap)
 {
 	return (x >> 24) < cap ? (x >> 24) : cap;
