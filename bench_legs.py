@@ -26,10 +26,11 @@ class Legs:
             # SURVEY 8(d)'s config-5 bytes (ONE read of the frames + the three tables).  The label "hbm" would flatter this
             # workload: its ceiling is VALU issue (profiles/round4/pmc_sq_three_scope_x64_*.txt).
             vr["bound"] = "valu issue (K0 + three waveform adds + one vectorscope add per texel); hbm is the yardstick, not the ceiling"
-            vr["ceiling_estimate"] = {"gpix_per_s": 1200, "frac_of_hbm_peak": 0.67,
-                                      "from": "the per-texel instruction floor of this structure (K0 11.5 + waveform addresses 6 + alpha 1 + "
-                                              "vectorscope 3.5 + load 1 = 23 VALU instructions) at the 73 % VALU occupancy four waves per SIMD "
-                                              "reach (measured: 29.2 instructions per texel, 947 Gpix/s); DESIGN.md 3.5"}
+            vr["ceiling_estimate"] = {"gpix_per_s": 1300, "frac_of_hbm_peak": 0.73,
+                                      "from": "the per-texel instruction count of a fast slot (K0 and its vote 11.5 + the waveform's three adds 4 + "
+                                              "the vectorscope's pair 4.5 + loop and load 1-2 = 22 VALU instructions) at the 70 % VALU occupancy four "
+                                              "waves per SIMD reach (measured: 26.2 instructions per texel over the whole kernel, 997 Gpix/s); "
+                                              "DESIGN.md 3.5"}
             vr["note"] = "algorithmic bytes = SURVEY 8(d)'s config-5 figure: one read of the frames + the three tables"
         out = {"value": round(self.n * self.w * self.h / (sus["ms_per_step"] * 1e-3) / 1e9, 3), "unit": "Gpix/s", "components": f"{comp:#04x}",
                "ms_per_step": sus["ms_per_step"], "steps": sus["steps"], "parity": ok, "roofline": vr}

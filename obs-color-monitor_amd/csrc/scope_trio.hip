@@ -29,15 +29,17 @@
  * meet on one ADDRESS.  With 16-column strips a row segment is half a cache line: slices come in pairs that split a range of
  * strips even / odd, and the two workgroups of a pair are b and b + 8 (same XCD, same L2, same moment).
  *
- * What bounds it (profiles/round4/trio_variants.txt, ab_prio_rounds.txt): 29 VALU instructions per texel (K0 11.5,
- * the waveform's three adds 7, the vectorscope's 3.5, the rest loop, read-outs, clamp passes) keep each SIMD's VALU busy 74 % of
+ * What bounds it (profiles/round4/trio_variants.txt, ab_prio_rounds.txt, ab_dot4_addresses.txt): 26 VALU instructions
+ * per texel (K0 and its vote 11.5, the waveform's three adds 4 -- their addresses come out of v_dot4_u32_u8, trio_count2 -- the
+ * vectorscope's pair 4.5, the rest loop, read-outs, clamp passes) keep each SIMD's VALU busy 68 % of
  * the kernel with the four waves a 1024-thread workgroup gives it (the LDS footprint allows one workgroup per CU), and the
  * waveform's three LDS atomics per texel are about as near their limit: with the vectorscope's adds AND K0 compiled out the
  * kernel reaches 0.59 of the HBM peak, without the waveform's adds 0.565.  Measured in round 4, each in a same-process A/B: two
  * waveform replicas (bank conflicts halved) +0 %, whole-line loads and half the barriers (32-column strips) +3 ... 5 %, pair-form
  * vectorscope adds +2 %, a slot without any exec-mask branch +0.5 %, skipping the slots a strip's rounding leaves empty +2 %,
  * contiguous read-out stores +2.4 %, the waves' issue priority going round (scope_prio_round: the arbiter's oldest-first order
- * starved waves 12-15 of every workgroup) +2.3 % on noise and +7.4 % on screen content, more or fewer loads in flight 0 %.
+ * starved waves 12-15 of every workgroup) +2.3 % on noise and +7.4 % on screen content, more or fewer loads in flight 0 %, the
+ * waveform's addresses by v_dot4_u32_u8 +1.7 ... 4.7 %.
  * Tried and dropped in round 3: deeper or shallower load queues, skipping K0 work of empty slots in front of EVERY slot.
  * Vector shape only (W % 4 == 0, 8-byte aligned rows, 16-byte aligned tables), H <= 65535 (a column's rows fit the waveform's
  * 16-bit counters).
