@@ -352,6 +352,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	(void)lane_u;
 	(void)lane_v;
 	bool absorb = false, wflat = false; /* wave-uniform */
+	const u32 wave_w = (u32)__popcll(__ballot(true)); /* 64; one on the CPU emulation (tests/emul), whose votes are a lane's own */
 	u32 wp0 = 0, wp1 = 0, wn = 0; /* the waveform's pending texel pair and how often it came (absorb mode) */
 	u32 since = 0;       /* texels the vectorscope table may have taken since its last clamp pass (uniform) */
 	const u32 round_px = (u32)D * blockDim.x * 2u; /* texels a round of D slots can add (upper bound: every lane valid) */
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 					const bool same = TRIO_PAIR ? ((pu[0] == scope_perm(0u, pu[0], 0x01000302u)) & (pv[0] == scope_perm(0u, pv[0], 0x01000302u)))
 									 : key[0] == key[1];
 					const u32 flat_lanes = (u32)__popcll(__ballot(!v || same));
-					absorb = flat_lanes >= 48;
-					wflat = flat_lanes >= 64;
+					absorb = flat_lanes * 4u >= wave_w * 3u; /* three quarters of the wave: 48 lanes */
+					wflat = flat_lanes >= wave_w;
 				}
 				if (!v || (TRIO_EXP & 2))
 					return;

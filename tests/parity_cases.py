@@ -592,7 +592,13 @@ def check_three_scopes_dev(ctx, oracle, to_dev, to_host, w, h, dists, wc=0x07, h
     times (tickets and accumulators come back to zero)."""
     import numpy as np
 
-    pairs = [frames(oracle, w, h, d, linesize, seed=300 + d, colorspace=colorspace) for d in dists]
+    def pair_of(i, d):
+        if isinstance(d, dict):  # screen-like content (screen_frame's keywords): flat areas, rectangles, sprinkled detail
+            rgb = screen_frame(w, h, 500 + i, linesize=linesize, **d)
+            return rgb, oracle.rgb_to_yuv(rgb, w, colorspace)
+        return frames(oracle, w, h, d, linesize, seed=300 + d, colorspace=colorspace)
+
+    pairs = [pair_of(i, d) for i, d in enumerate(dists)]
     n = len(pairs)
     ls = pairs[0][0].shape[1]
     hr, addr = to_dev(np.concatenate([p[0].reshape(-1) for p in pairs]))

@@ -192,6 +192,20 @@ def test_three_scopes_one_read(emul_ctx, oracle, dock):
             dev(16, 4090, [3], reps=1)                    # a tall flat strip: clamp passes inside the strip
 
 
+@pytest.mark.parametrize("strip", [0, 16, 32])
+def test_three_scopes_screen_content(emul_ctx, oracle, strip):
+    """scope_trio_kernel's absorb mode (the emulated wave's vote is its one lane's: a lane with a flat texel pair absorbs): screen-like
+    content, where a lane keeps its colour for long, meets single texels of detail and crosses into other flat areas -- colour changes
+    in the vote's slots, plain adds between them."""
+    dev = lambda *a, **k: pc.check_three_scopes_dev(emul_ctx, oracle, _np_dev, lambda hnd: hnd, *a, **k)  # noqa: E731
+    kinds = [{}, {"detail": 0.0}, {"detail": 0.3}, {"grey": True}, {"alpha_noise": True, "detail": 0.01}, {"rects": 40, "detail": 0.05}]
+    with pc.options(emul_ctx, **{"trio.strip": strip}):
+        dev(96, 260, kinds, reps=1)
+        dev(72, 130, kinds[:2], 0x05, 0x04, 72 * 4 + 8, 1, reps=1)
+        dev(32, 2100, [kinds[5], 3], reps=1)              # clamp passes with lanes holding counts
+        dev(200, 40, kinds[3:6], 0x02, 0x02, reps=2)
+
+
 @pytest.mark.parametrize("strip", [16, 32])
 def test_three_scopes_strip_widths(emul_ctx, oracle, strip):
     """scope_trio_kernel's two shapes: 16-column strips with waveform replicas (two; four for a one-channel mask) and 32-column

@@ -250,6 +250,26 @@ def test_three_scopes_strip_widths(hip_ctx, oracle, strip):
         dev(7680, 4320, [2], reps=1)
 
 
+@pytest.mark.parametrize("strip", [0, 16, 32])
+def test_three_scopes_screen_content(hip_ctx, oracle, strip):
+    """scope_trio_kernel's absorb mode at work: screen-like content -- flat areas, rectangles, sprinkled detail, greys, random alpha --
+    where most lanes of a wave hold their colour, some do not, and lanes cross into other flat areas (colour changes in the vote's
+    slots, plain adds between them); batches and one-frame calls, both strip widths, both matrices, one- and two-channel masks."""
+    to_dev, to_host = _torch_dev()
+
+    def dev(*a, **k):
+        pc.check_three_scopes_dev(hip_ctx, oracle, to_dev, to_host, *a, **k)
+
+    kinds = [{}, {"detail": 0.0}, {"detail": 0.3}, {"grey": True}, {"alpha_noise": True, "detail": 0.01}, {"rects": 200, "detail": 0.0},
+             {"rects": 300, "detail": 0.03}, {"rects": 60, "detail": 0.1}]
+    with pc.options(hip_ctx, **{"trio.strip": strip}):
+        dev(3840, 2160, kinds, reps=1)
+        dev(3840, 2160, kinds[:1], reps=1)
+        dev(3840, 2160, [kinds[6], 3, kinds[0]], 0x05, 0x04, colorspace=1, reps=1)
+        dev(1924, 1083, kinds[:3], 0x07, 0x05, 1924 * 4 + 64, reps=1)
+        dev(328, 77, kinds[4:7], 0x02, 0x02, reps=2)
+
+
 @pytest.mark.parametrize("strip", [16, 64])
 def test_waveform_strip_widths(hip_ctx, oracle, strip):
     """Both shapes a small launch can take -- 16-column strips (eight rows per wave instruction into four table
