@@ -29,7 +29,7 @@ class Legs:
             vr["ceiling_estimate"] = {"gpix_per_s": 1300, "frac_of_hbm_peak": 0.73,
                                       "from": "the per-texel instruction count of a fast slot (K0 and its vote 11.5 + the waveform's three adds 4 + "
                                               "the vectorscope's pair 4.5 + loop and load 1-2 = 22 VALU instructions) at the 70 % VALU occupancy four "
-                                              "waves per SIMD reach (measured: 26.2 instructions per texel over the whole kernel, 997-1022 Gpix/s); "
+                                              "waves per SIMD reach (measured: 26.2 instructions per texel over the whole kernel, 997-1039 Gpix/s); "
                                               "DESIGN.md 3.5"}
             vr["note"] = "algorithmic bytes = SURVEY 8(d)'s config-5 figure: one read of the frames + the three tables"
         out = {"value": round(self.n * self.w * self.h / (sus["ms_per_step"] * 1e-3) / 1e9, 3), "unit": "Gpix/s", "components": f"{comp:#04x}",
