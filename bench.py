@@ -23,7 +23,8 @@ leg of the same steps in which every launch carries its own begin/end HIP events
 figure rocprofv3 --kernel-trace --stats reports for the same command).  `roofline.frac` itself is the WHOLE STEP's, from the K
 timed steps, on the frame pool as this process first allocated it; the same launch on a pool the library placed
 (scope_frame_pool_alloc) is a leg of its own (`config.frame_pool_placement`, `roofline.frac_placed` / `frac_kernel_placed`).
-Every leg's headline number is repeated as a flat scalar at the top level and inside `roofline` (flat_summary()).
+The line on stdout is SHORT (bench_core.compact_line: under 6 KB -- the contract's fields, `config`, `roofline`, `cpu_baseline`
+and at most 40 flat scalars of the other legs, once); every leg in full is written to bench_detail.json beside this script.
 
 Besides the headline the default one-GPU run measures, briefly and in the same process (`--no-extras` skips them):
   variants       the other workloads of BASELINE.json at the same batch: vectorscope with K0 fused (config 2, variant ii),
@@ -47,7 +48,7 @@ tables are summed over RCCL through the C-ABI (scope_table_allreduce: two bins p
 torch.distributed (gloo, CPU tensors) only carries the communicator id, the barriers and the max-over-ranks time: no
 control-plane collective ever shares a GPU queue with the data path's.
 
-Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).
+Rank 0 prints ONE short JSON line (see README/DESIGN.md for the fields) and writes bench_detail.json.
 """
 import argparse
 import faulthandler
@@ -56,8 +57,8 @@ import os
 import sys
 
 import bench_core
-from bench_core import (HBM_PEAK_GBPS, H4K, KERNEL, METRIC, ROOT, UNPINNED, W4K, WORKLOAD_TEXT, Ctl, Dev, Overlap, Workload, flat_summary,  # noqa: F401
-                        kernel_fingerprint, kernel_us, log, make_comm, place_pool, pmc_traffic, roofline, spread, table_bytes_of, timed_run)
+from bench_core import (HBM_PEAK_GBPS, H4K, KERNEL, METRIC, ROOT, UNPINNED, W4K, WORKLOAD_TEXT, Ctl, Dev, Overlap, Workload, compact_line, flat_summary,  # noqa: F401
+                        kernel_fingerprint, kernel_us, log, make_comm, place_pool, pmc_traffic, roofline, spread, table_bytes_of, timed_run, write_detail)
 from bench_launch import launcher, supervisor
 from bench_legs import Legs, config1_leg, config4_leg, cpu_baseline
 
@@ -192,7 +193,7 @@ def run_rank(args):
                                    "vectorscope + waveform 0x07 + histogram 0x07 per frame", "device": info["name"]},
             "stream": res,
         }
-        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+        os.write(real_stdout, (compact_line(result, write_detail(result)) + "\n").encode())
         ctx.close()
         sys.exit(0 if res["parity"].startswith("bit-exact") else 3)
 
@@ -465,6 +466,8 @@ def run_rank(args):
                                             frames=args.config4_frames, overlap=c4_overlap,
                                             seconds=0.6 if not dev.emul else 0.0)
             result["config4"]["rccl_ranks_in_communicator"] = ctx.rccl_comm_info(c4_comm)["ranks"]
+            result["config4"]["reduce_path"] = ("C-ABI scope_table_allreduce (ncclAllReduce uint32 sum of packed u16 pairs), every step"
+                                                + (", second stream" if c4_overlap is not None else ", accumulation stream"))
             if c4_comm is not comm:
                 dev.sync()
                 ctx.rccl_comm_destroy(c4_comm)
@@ -482,15 +485,13 @@ def run_rank(args):
         result["cpu_baseline"] = cpu_baseline(np, o, "vectorscope" if wl == "three_scope" else wl, frame0[0], frame0[1],
                                               w, h, args.components, args.cpu_seconds)
 
-    # ---- the legs' headline numbers once more as FLAT scalars, at the top level and inside `roofline`: a reader (the driver's
-    # record keeps scalar fields of the objects it knows and only the NAMES of the others) then has every README row in one place
-    flat = flat_summary(result)
-    result.update(flat)
-    result["roofline"].update(flat)
-
+    # ---- ONE line on stdout, short enough for any reader (compact_line: < 6 KB; the contract's fields, config, roofline,
+    # cpu_baseline, <= 40 flat scalars of the other legs); every leg in full goes to bench_detail.json beside this script
     faulthandler.cancel_dump_traceback_later()
     if rank == 0:
-        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+        result["flat"] = flat_summary(result)
+        detail = write_detail(result)
+        os.write(real_stdout, (compact_line(result, detail) + "\n").encode())
     if comm:
         dev.sync()
         ctx.rccl_comm_destroy(comm)

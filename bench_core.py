@@ -363,6 +363,8 @@ def flat_summary(result):
             if isinstance(r, dict):
                 if "frac_kernel" in r:
                     flat[f"{kind}_{wl}_frac_kernel"] = r["frac_kernel"]
+                if "frac" in r:
+                    flat[f"{kind}_{wl}_frac"] = r["frac"]
                 flat[f"{kind}_{wl}_gpix"] = r.get("gpix_per_s")
                 ok = ok and r.get("parity") is not False
     st = result.get("stream") or {}
@@ -382,8 +384,119 @@ def flat_summary(result):
     pl = (result.get("config") or {}).get("frame_pool_placement") or {}
     if "value" in pl:
         flat["placed_pool_gpix"] = pl["value"]
+    ac = (result.get("cpu_baseline") or {}).get("all_cores") or {}
+    if "value" in ac:
+        flat["cpu_all_cores_gpix"] = ac["value"]
     flat["all_parity"] = bool(ok)
     return flat
+
+
+# the flat scalars the ONE stdout line carries (<= 40, one copy, top level); everything else is in bench_detail.json
+LINE_SCALARS = (
+    "vectorscope_rgb_gpix", "vectorscope_rgb_frac_kernel", "waveform_gpix", "waveform_frac_kernel", "waveform_y_frac_kernel",
+    "waveform_r_frac_kernel", "waveform_g_frac_kernel", "waveform_b_frac_kernel", "histogram_gpix", "histogram_frac_kernel",
+    "three_scope_gpix", "three_scope_frac_kernel",
+    "vectorscope_x1_us", "vectorscope_rgb_x1_us", "histogram_x1_us", "waveform_x1_us", "three_scope_x1_us", "vectorscope_x3_us",
+    "three_scope_x3_us",
+    "natural_three_scope_frac", "concentrated_three_scope_frac", "screen_three_scope_frac", "ramp_three_scope_frac",
+    "natural_vectorscope_frac_kernel", "natural_vectorscope_rgb_frac_kernel", "screen_vectorscope_rgb_frac_kernel",
+    "ramp_vectorscope_rgb_frac_kernel", "padded_pitch_vectorscope_frac_kernel", "padded_pitch_vectorscope_rgb_frac_kernel",
+    "alpha_holes_histogram_frac_kernel", "alpha_holes_waveform_frac_kernel",
+    "stream_fps", "stream_paced_240fps_latency_ms", "config1_cpu_ms_per_frame", "config4_gpix", "config4_ranks_in_communicator",
+    "placed_pool_gpix", "cpu_all_cores_gpix", "all_parity",
+)
+LINE_LIMIT = 6000  # bytes; the driver's record has been seen to lose a 21.7 KB line and to keep only the last ~8 KB of stdout
+DETAIL_FILE = "bench_detail.json"
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if k in d}
+
+
+def compact_launcher(lz):
+    """The launcher's object for the one line: the mode and, per attempt, what was added, how it ended and how long it took."""
+    return {"mode": _short(lz.get("mode"), 80), "deadline_s_per_attempt": lz.get("deadline_s_per_attempt"),
+            "attempts": [dict(_pick(a, ("extra_args", "exit_codes", "seconds")), failure=_short(a.get("failure"), 120))
+                         for a in lz.get("attempts", [])]}
+
+
+def compact_line(result, detail=None):
+    """The ONE line that reaches stdout: the contract's scalars first, then `config`, `roofline`, `cpu_baseline` with the
+    keys a reader recomputes from, at most 40 flat scalars of the other legs (once, at the top level), and -- at N > 1 or
+    after --strong / --force-reduce -- `config4` and `config.rccl` with what a scaling record is judged from.  No prose, no
+    nested legs: those are in the detail file this line names.  Always shorter than LINE_LIMIT bytes."""
+    out = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                         "vs_baseline", "dtype", "data"))
+    out["parity"] = _short(result.get("parity"), 48)
+    if "error" in result:
+        out["error"] = _short(result["error"], 200)
+    cfg = result.get("config") or {}
+    c = _pick(cfg, ("frames_per_step", "frame_pool", "width", "height", "input_distribution"))
+    c = dict({"workload": _short(cfg.get("workload"), 160)}, **c)
+    for k, n in (("partition", 120), ("reduce", 120), ("launch", 48), ("device", 48), ("library", 64)):
+        if cfg.get(k) is not None:
+            c[k] = _short(cfg[k], n)
+    c.update(_pick(cfg, ("compute_units", "gpu_shared_by_ranks", "kernel_sources_sha256_16")))
+    if cfg.get("options"):
+        c["options"] = cfg["options"]
+    c["rccl"] = None if not cfg.get("rccl") else _pick(cfg["rccl"], ("ranks_in_communicator", "rank", "version"))
+    if str(cfg.get("backend", "")).startswith("EMULATION"):
+        c["backend"] = "EMULATION (CPU): numbers are meaningless"
+    out["config"] = c
+    rf = result.get("roofline")
+    if rf:
+        r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "achieved_kernel", "frac_kernel", "avg_launch_ms",
+                       "launches_timed", "algorithmic_bytes_per_launch", "traffic", "frac_placed", "frac_kernel_placed"))
+        r["kernel"] = _short(r.get("kernel"), 40)
+        r["traffic_source"] = _short(rf.get("traffic_source"), 60)
+        out["roofline"] = r
+    cb = result.get("cpu_baseline")
+    if cb:
+        b = _pick(cb, ("value", "unit", "cores", "kind"))
+        ac = cb.get("all_cores") or {}
+        b.update({"host_cores": ac.get("host_cores"), "cpu": _short(ac.get("cpu"), 48), "sample": _short(cb.get("sample"), 140)})
+        out["cpu_baseline"] = b
+    c4 = result.get("config4")
+    if c4 and (result.get("n_gpus", 1) > 1 or result.get("scaling") == "strong" or "error" in c4):
+        out["config4"] = (_pick(c4, ("value", "unit", "scaling", "ms_per_step", "frames_per_step", "parity", "rccl_ranks_in_communicator", "reduce_path",
+                                     "ms_per_step_reduce_on_the_accumulation_stream", "ms_per_step_reduce_overlapped_second_stream",
+                                     "step_latency_ms_reduce_waited", "rows_of_this_rank"))
+                          if "error" not in c4 else {"error": _short(c4["error"], 160)})
+        if "partition" in c4:
+            out["config4"]["partition"] = _short(c4["partition"], 120)
+    flat = flat_summary(result)
+    for k in LINE_SCALARS:
+        if flat.get(k) is not None:
+            out[k] = flat[k]
+    if "launcher" in result:
+        out["launcher"] = compact_launcher(result["launcher"])
+    if detail:
+        out["detail"] = detail
+    line = json.dumps(out)
+    for k in reversed(LINE_SCALARS):  # never reached with today's keys; a guard, not a plan
+        if len(line.encode()) < LINE_LIMIT:
+            break
+        if out.pop(k, None) is not None:
+            line = json.dumps(out)
+    return line
+
+
+def write_detail(result, path=None):
+    """Everything the legs measured (variants, latency, distributions, stream, config 1 / 4, the prose) as one JSON file beside
+    bench.py, and its name for the line.  A directory that cannot be written costs the detail, not the line."""
+    path = path or os.environ.get("BENCH_DETAIL") or os.path.join(ROOT, DETAIL_FILE)
+    try:
+        with open(path, "w") as fh:
+            json.dump(result, fh, indent=1)
+            fh.write("\n")
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        log(f"bench.py: detail file {path} not written ({e})")
+        return None
 
 
 def code_only(src):

@@ -11,7 +11,7 @@ import subprocess
 import sys
 import time
 
-from bench_core import METRIC, ROOT, log
+from bench_core import LINE_LIMIT, METRIC, ROOT, compact_launcher, log
 
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -104,8 +104,24 @@ def failure_line(args, attempts, mode):
         "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "error": "no attempt of the N-rank run completed; see launcher.attempts (rank logs are on stderr)",
         "config": {"workload": "none completed"},
-        "launcher": {"mode": mode, "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout},
+        "launcher": compact_launcher({"mode": mode, "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout}),
     })
+
+
+def with_launcher(res, mode, attempts, args):
+    """Rank 0's (already compact) line with the launcher's object added, still under LINE_LIMIT.  A line the replicas rung
+    printed (no table sum took place) can never call itself strong scaling or carry a config-4 value."""
+    res["launcher"] = compact_launcher({"mode": mode, "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout})
+    if "--no-collective" in (attempts[-1].get("extra_args") or []) or args.no_collective:
+        res["scaling"] = "weak"
+        res.pop("config4", None)
+        res.pop("config4_gpix", None)
+    line = json.dumps(res)
+    if len(line.encode()) >= LINE_LIMIT:  # eight ranks, three attempts, long failure texts: the attempts keep their outcome only
+        for a in res["launcher"]["attempts"]:
+            a["failure"] = a["failure"] and a["failure"][:40]
+        line = json.dumps(res)
+    return line
 
 
 def supervisor(args, argv):
@@ -165,9 +181,7 @@ def supervisor(args, argv):
                          "failure": None if int(flags[0]) else (why or f"exit codes {codes}"), "rendezvous": f"127.0.0.1:{port[0]}"})
         if int(flags[0]):
             if rank == 0:
-                res = json.loads(line)
-                res["launcher"] = {"mode": mode, "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout}
-                os.write(real_stdout, (json.dumps(res) + "\n").encode())
+                os.write(real_stdout, (with_launcher(json.loads(line), mode, attempts, args) + "\n").encode())
             dist.barrier()
             dist.destroy_process_group()
             return 3 if 3 in codes else 0
@@ -199,9 +213,7 @@ def launcher(args, argv):
             except ValueError:
                 outcome["failure"] = "rank 0's line is not JSON"
                 continue
-            res["launcher"] = {"mode": "bench.py started its own ranks (subprocess per GPU, rendezvous on 127.0.0.1)",
-                               "attempts": attempts, "deadline_s_per_attempt": args.launch_timeout}
-            print(json.dumps(res), flush=True)
+            print(with_launcher(res, "bench.py started its own ranks (subprocess per GPU, rendezvous on 127.0.0.1)", attempts, args), flush=True)
             return 3 if parity_exit else 0
         deadline = max(120.0, args.launch_timeout / 2)  # the later rungs get less: the whole ladder stays bounded
     print(failure_line(args, attempts, "bench.py started its own ranks"), flush=True)

@@ -38,7 +38,19 @@ def run_bench(args, env, prefix=(), timeout=600):
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), \
         f"exactly one line on stdout, the JSON line, expected; rc={out.returncode}\n{out.stdout[-2000:]}\n{out.stderr[-4000:]}"
-    return out.returncode, json.loads(lines[0]), out.stderr
+    # the driver's record lost round 4's 21.7 KB line: the line is SHORT, whatever N is and however the run ended
+    assert len(lines[0].encode()) < 8000, f"the stdout line is {len(lines[0].encode())} bytes"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config"):
+        assert k in d, k
+    assert list(d)[:4] == ["metric", "value", "unit", "n_gpus"], "the contract's fields lead the line"
+    assert "workload" in d["config"]
+    if d["value"]:
+        assert d["roofline"]["frac"] >= 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["algorithmic_bytes_per_launch"] > 0
+        assert all(not isinstance(v, (dict, list)) or k in ("config", "roofline", "cpu_baseline", "config4", "launcher")
+                   for k, v in d.items()), "no nested legs on the line"
+    return out.returncode, d, out.stderr
 
 
 def test_gpus2_without_world_size_starts_its_own_ranks(shm_rccl):
@@ -114,6 +126,44 @@ def test_replicas_rung_says_what_it_is(shm_rccl):
     assert rc == 0, err[-3000:]
     assert d["config"]["reduce"].startswith("NONE") and "NO table sum" in d["config"]["partition"]
     assert "config4" not in d
+
+
+def test_replicas_are_never_strong(shm_rccl):
+    # the last rung of the ladder has no table sum: whatever was asked for, its line is weak scaling and carries no config-4 value
+    rc, d, err = run_bench(["--gpus", "2", *SMALL, *C4, "--no-collective"], clean_env())
+    assert rc == 0, err[-3000:]
+    assert d["scaling"] == "weak" and "config4" not in d and "config4_gpix" not in d
+    assert d["config"]["reduce"].startswith("NONE") and d["config"]["rccl"] is None
+
+
+def test_line_of_a_full_run_is_short_and_complete(tmp_path):
+    """compact_line on a REAL full result (round 4's 21.7 KB line, the one the driver's record lost): under 6 KB, headline
+    first, roofline and cpu_baseline with the keys a reader recomputes from, at most 40 flat scalars, no nested legs."""
+    sys.path.insert(0, ROOT)
+    import bench_core
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "round4", "bench_x4.json")))
+    for k in list(full):  # round 4 repeated every flat scalar at the top level: a result as bench.py builds it today has none
+        if not isinstance(full[k], (dict, list)) and k.endswith(("_gpix", "_frac", "_frac_kernel", "_us", "_fps", "_ms", "_per_frame", "_communicator")):
+            full.pop(k)
+    full["launcher"] = {"mode": "m" * 300, "deadline_s_per_attempt": 480.0,
+                        "attempts": [{"extra_args": ["--torch-reduce"], "exit_codes": [0] * 8, "seconds": 99.9, "failure": "f" * 500,
+                                      "rendezvous": "127.0.0.1:1"}] * 3}
+    full["n_gpus"] = 8
+    line = bench_core.compact_line(full, "bench_detail.json")
+    assert len(line.encode()) < bench_core.LINE_LIMIT < 8000
+    d = json.loads(line)
+    assert list(d)[:7] == ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step"]
+    assert d["roofline"]["frac"] == 0.8039 and d["roofline"]["frac_kernel"] == 0.8194 and d["roofline"]["avg_launch_ms"] == 0.32458
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 2127560704 and d["roofline"]["peak"] == 8000.0
+    assert d["cpu_baseline"]["value"] == 1.5679 and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["host_cores"] == 256
+    assert d["config"]["workload"].startswith("vectorscope 256x256") and d["config"]["kernel_sources_sha256_16"] == "57263b4608419f98"
+    assert d["config4"]["value"] == 1557.44 and d["config4"]["rccl_ranks_in_communicator"] == 1  # N > 1: the strong leg is on the line
+    flat = [k for k, v in d.items() if not isinstance(v, (dict, list)) and k in bench_core.LINE_SCALARS]
+    assert 30 <= len(flat) <= 40 and d["three_scope_frac_kernel"] == 0.594 and d["ramp_three_scope_frac"] > 0 and d["all_parity"] is True
+    assert "variants" not in d and "latency" not in d and "distributions" not in d and "stream" not in d
+    path = bench_core.write_detail(full, str(tmp_path / "bench_detail.json"))
+    assert json.load(open(path))["variants"]["waveform"]["value"] == 1436.104
 
 
 def test_nothing_works_still_one_line(shm_rccl, tmp_path):

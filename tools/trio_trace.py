@@ -2,7 +2,7 @@
 """Where scope_trio_kernel's waves spend their time: per-wave sums of 100 MHz ticks -- waiting at the strip's two barriers, the
 read-out, the clamp passes (their barriers included), the whole loop -- from the development build
 `make -C obs-color-monitor_amd/csrc trio_variant VARIANT_FLAGS=-DTRIO_TRACE VARIANT_TAG=trace` (tools/_lib_trio_trace.so).
-Run on the GPU box: python tools/trio_trace.py [frames]"""
+Run on the GPU box: python tools/trio_trace.py [frames [content,content...]]"""
 import ctypes
 import os
 import sys
@@ -23,7 +23,7 @@ torch.cuda.set_stream(stream)
 c = ocm.ScopeContext(0, lib)
 c.set_stream(stream.cuda_stream)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-for dist in ("uniform", "screen"):
+for dist in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("uniform", "screen")):
     rgb, yuv = make_frames(torch, c, n, W, H, dist, 7)
     b = c.make_device_batch(rgb, 4 * W, W, H, planes_are_rgb=True, colorspace=2)
     o_vss = torch.empty((n, 65536), dtype=torch.uint8, device="cuda")
