@@ -14,7 +14,9 @@ struct cm_source *scope_host_cm(void *source)
 const uint8_t *scope_host_vss_table(void *data, int *colorspace)
 {
 	struct vss_source *src = data;
+	pthread_mutex_lock(&src->tex_mutex);
 	const int r = src->w_tex_buf ^ 1;
+	pthread_mutex_unlock(&src->tex_mutex);
 	if (colorspace)
 		*colorspace = src->tex_cs[r];
 	return src->tex_buf[r];
@@ -23,7 +25,9 @@ const uint8_t *scope_host_vss_table(void *data, int *colorspace)
 const uint8_t *scope_host_wvs_table(void *data, uint32_t *width)
 {
 	struct wvs_source *src = data;
+	pthread_mutex_lock(&src->tex_mutex);
 	const int r = src->w_tex_buf ^ 1;
+	pthread_mutex_unlock(&src->tex_mutex);
 	if (width)
 		*width = src->tex_buf_width[r];
 	return src->tex_buf[r];
@@ -32,7 +36,9 @@ const uint8_t *scope_host_wvs_table(void *data, uint32_t *width)
 const float *scope_host_his_table(void *data, uint32_t *hi_max)
 {
 	struct his_source *src = data;
+	pthread_mutex_lock(&src->tex_mutex);
 	const int r = src->w_tex_buf ^ 1;
+	pthread_mutex_unlock(&src->tex_mutex);
 	if (hi_max)
 		for (int i = 0; i < 3; i++)
 			hi_max[i] = src->hi_max[r][i];

@@ -81,15 +81,18 @@ struct roi_source;
 /* src/common.h:48-87, minus everything that only exists to talk to libobs graphics */
 struct cm_source {
 	struct cm_surface_queue_item queue[CM_SURFACE_QUEUE_SIZE];
-	volatile int i_write_queue, i_staging_queue;
-	volatile int i_read_queue;
+	/* the ring's indices and the three flags below: every access that another thread can see happens under pipeline_mutex
+	 * (the reference marks them `volatile` and reads some of them bare, src/common.h:54-55,64-68; here the mutex is the
+	 * ordering, the consumer's wait is the condition variable's, and nothing is left to `volatile`) */
+	int i_write_queue, i_staging_queue;
+	int i_read_queue;
 
 	pthread_t pipeline_thread;
 	pthread_mutex_t pipeline_mutex;
 	pthread_cond_t pipeline_cond;
-	volatile bool pipeline_thread_running;
-	volatile bool request_exit;
-	volatile bool busy; /* the consumer is inside a callback (cm_drain waits for it) */
+	bool pipeline_thread_running; /* start / stop / drain: the thread that ticks the source (the graphics thread) */
+	bool request_exit;
+	bool busy; /* the consumer is inside a callback (cm_drain waits for it) */
 
 	cm_surface_cb_t callback;
 	void *callback_data;

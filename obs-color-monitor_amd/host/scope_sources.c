@@ -75,6 +75,7 @@ static void *vss_create(obs_data_t *settings, obs_source_t *source)
 	src->cm.flags = CM_FLAG_CONVERT_YUV; /* src/vectorscope.c:79 */
 	cm_create(&src->cm, settings, source);
 	cm_request(&src->cm, vss_surface_cb, src);
+	pthread_mutex_init(&src->tex_mutex, NULL);
 	src->zoom = 1.0f; /* src/vectorscope.c:80 */
 	vss_update(src, settings);
 	return src;
@@ -87,6 +88,7 @@ static void vss_destroy(void *data)
 	bfree(src->tex_buf[0]); /* src/vectorscope.c:119-120 */
 	bfree(src->tex_buf[1]);
 	bfree(src->pic.rgba);
+	pthread_mutex_destroy(&src->tex_mutex);
 	bfree(src);
 }
 
@@ -137,10 +139,8 @@ void vss_mouse_wheel(void *data, const struct obs_mouse_event *event, int x_delt
 
 /* src/vectorscope.c:382-471: upload, zoom transform and PSDrawBare become one GPU pass, the label quads and the bracket /
  * skin-tone lines a second one (scope_display_graticule; under a zoom they are scaled about 127.5 like the sprite, :395-408) */
-static void vss_render(void *data, gs_effect_t *effect)
+static void vss_render_locked(struct vss_source *src)
 {
-	UNUSED_PARAMETER(effect);
-	struct vss_source *src = data;
 	const int r_tex_buf = src->w_tex_buf ^ 1;
 	if (!src->tex_buf[r_tex_buf])
 		return; /* :411 */
@@ -180,6 +180,15 @@ static void vss_render(void *data, gs_effect_t *effect)
 	PROFILE_END(PROF_VSS_RENDER);
 }
 
+static void vss_render(void *data, gs_effect_t *effect)
+{
+	UNUSED_PARAMETER(effect);
+	struct vss_source *src = data;
+	pthread_mutex_lock(&src->tex_mutex); /* the table being drawn is not the worker's until this section ends (scope_sources.h) */
+	vss_render_locked(src);
+	pthread_mutex_unlock(&src->tex_mutex);
+}
+
 static uint32_t vss_get_width(void *data)
 {
 	UNUSED_PARAMETER(data);
@@ -206,7 +215,7 @@ void vss_surface_cb(void *data, struct cm_surface_data *surface_data)
 	}
 
 	src->tex_cs[src->w_tex_buf] = surface_data->colorspace;
-	src->w_tex_buf ^= 1;
+	TEX_FLIP(src);
 }
 
 static void scope_render_nothing(void *data, gs_effect_t *effect)
@@ -283,6 +292,7 @@ static void *wvs_create(obs_data_t *settings, obs_source_t *source)
 	struct wvs_source *src = bzalloc(sizeof(struct wvs_source));
 	cm_create(&src->cm, settings, source);
 	cm_request(&src->cm, wvs_surface_cb, src);
+	pthread_mutex_init(&src->tex_mutex, NULL);
 	wvs_update(src, settings);
 	return src;
 }
@@ -294,6 +304,7 @@ static void wvs_destroy(void *data)
 	bfree(src->tex_buf[0]); /* src/waveform.c:87-88 */
 	bfree(src->tex_buf[1]);
 	bfree(src->pic.rgba);
+	pthread_mutex_destroy(&src->tex_mutex);
 	bfree(src);
 }
 
@@ -333,10 +344,8 @@ static void wvs_get_defaults(obs_data_t *settings)
 }
 
 /* src/waveform.c:334-392 minus graticule: upload + DrawOverlay/Stack/Parade become one GPU pass */
-static void wvs_render(void *data, gs_effect_t *effect)
+static void wvs_render_locked(struct wvs_source *src)
 {
-	UNUSED_PARAMETER(effect);
-	struct wvs_source *src = data;
 	const int r = src->w_tex_buf ^ 1;
 	if (!src->tex_buf[r] || !src->tex_buf_width[r])
 		return;
@@ -369,11 +378,23 @@ static void wvs_render(void *data, gs_effect_t *effect)
 	PROFILE_END(PROF_WVS_RENDER);
 }
 
+static void wvs_render(void *data, gs_effect_t *effect)
+{
+	UNUSED_PARAMETER(effect);
+	struct wvs_source *src = data;
+	pthread_mutex_lock(&src->tex_mutex); /* the table being drawn is not the worker's until this section ends (scope_sources.h) */
+	wvs_render_locked(src);
+	pthread_mutex_unlock(&src->tex_mutex);
+}
+
 static uint32_t wvs_get_width(void *data)
 {
 	struct wvs_source *src = data; /* src/waveform.c:181-189 */
 	uint32_t w, h;
-	scope_display_size(src->tex_buf_width[src->w_tex_buf ^ 1], WV_SIZE, src->components, src->display, &w, &h);
+	pthread_mutex_lock(&src->tex_mutex);
+	const uint32_t tw = src->tex_buf_width[src->w_tex_buf ^ 1];
+	pthread_mutex_unlock(&src->tex_mutex);
+	scope_display_size(tw, WV_SIZE, src->components, src->display, &w, &h);
 	return w;
 }
 
@@ -381,7 +402,10 @@ static uint32_t wvs_get_height(void *data)
 {
 	struct wvs_source *src = data; /* src/waveform.c:191-199 */
 	uint32_t w, h;
-	scope_display_size(src->tex_buf_width[src->w_tex_buf ^ 1], WV_SIZE, src->components, src->display, &w, &h);
+	pthread_mutex_lock(&src->tex_mutex);
+	const uint32_t tw = src->tex_buf_width[src->w_tex_buf ^ 1];
+	pthread_mutex_unlock(&src->tex_mutex);
+	scope_display_size(tw, WV_SIZE, src->components, src->display, &w, &h);
 	return h;
 }
 
@@ -418,7 +442,7 @@ void wvs_surface_cb(void *data, struct cm_surface_data *surface_data)
 		log_failure("scope_waveform", st);
 		return;
 	}
-	src->w_tex_buf ^= 1;
+	TEX_FLIP(src);
 }
 
 const struct obs_source_info colormonitor_waveform = {
@@ -486,6 +510,7 @@ static void *his_create(obs_data_t *settings, obs_source_t *source)
 	struct his_source *src = bzalloc(sizeof(struct his_source));
 	cm_create(&src->cm, settings, source);
 	cm_request(&src->cm, his_surface_cb, src);
+	pthread_mutex_init(&src->tex_mutex, NULL);
 	his_update(src, settings);
 	return src;
 }
@@ -497,6 +522,7 @@ static void his_destroy(void *data)
 	bfree(src->tex_buf[0]); /* src/histogram.c:97-98 */
 	bfree(src->tex_buf[1]);
 	bfree(src->pic.rgba);
+	pthread_mutex_destroy(&src->tex_mutex);
 	bfree(src);
 }
 
@@ -558,10 +584,8 @@ static uint32_t his_get_height(void *data)
 }
 
 /* src/histogram.c:522-578 minus graticule */
-static void his_render(void *data, gs_effect_t *effect)
+static void his_render_locked(struct his_source *src)
 {
-	UNUSED_PARAMETER(effect);
-	struct his_source *src = data;
 	const int r = src->w_tex_buf ^ 1;
 	if (!src->tex_buf[r])
 		return;
@@ -595,6 +619,15 @@ static void his_render(void *data, gs_effect_t *effect)
 	PROFILE_END(PROF_HIS_RENDER);
 }
 
+static void his_render(void *data, gs_effect_t *effect)
+{
+	UNUSED_PARAMETER(effect);
+	struct his_source *src = data;
+	pthread_mutex_lock(&src->tex_mutex); /* the table being drawn is not the worker's until this section ends (scope_sources.h) */
+	his_render_locked(src);
+	pthread_mutex_unlock(&src->tex_mutex);
+}
+
 void his_surface_cb(void *data, struct cm_surface_data *surface_data)
 {
 	struct his_source *src = data;
@@ -619,7 +652,7 @@ void his_surface_cb(void *data, struct cm_surface_data *surface_data)
 		log_failure("scope_histogram", st);
 		return;
 	}
-	src->w_tex_buf ^= 1;
+	TEX_FLIP(src);
 }
 
 const struct obs_source_info colormonitor_histogram = {

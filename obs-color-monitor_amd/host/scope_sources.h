@@ -27,11 +27,26 @@ struct scope_picture {
 	uint32_t width, height;
 };
 
+/* The double buffer's hand-off.  The reference flips a `volatile int w_tex_buf` on the worker thread and reads `^ 1` on the render
+ * thread with no ordering at all (src/vectorscope.c:48,264,410; src/waveform.c:40-41,288,399; src/histogram.c:47,449,563): the
+ * render thread may still be reading a table when the worker, one flip later, writes into it.  Here the same two buffers and
+ * the same flip, ordered: the worker fills tex_buf[w_tex_buf] holding nothing and takes tex_mutex only to FLIP; the render side
+ * holds tex_mutex while it reads tex_buf[w_tex_buf ^ 1].  A buffer is written between two flips and read only in sections that
+ * lie before the first or behind the second, so writer and reader are never on one buffer, the worker waits for one table
+ * upload at most, and ThreadSanitizer has nothing to report (tests/emul/host_tsan.c runs the three threads flat out). */
+#define TEX_FLIP(src)                                   \
+	do {                                            \
+		pthread_mutex_lock(&(src)->tex_mutex);   \
+		(src)->w_tex_buf ^= 1;                  \
+		pthread_mutex_unlock(&(src)->tex_mutex); \
+	} while (0)
+
 struct vss_source {
 	struct cm_source cm;
 	uint8_t *tex_buf[2];
 	int tex_cs[2];
-	volatile int w_tex_buf;
+	int w_tex_buf; /* written by the worker under tex_mutex, read by the render side under it */
+	pthread_mutex_t tex_mutex;
 	int intensity;  /* src/vectorscope.c:55,129-131 */
 	int color_type; /* 0 white, 1 UV (src/vectorscope.c:36-39) */
 	float zoom;     /* 1.0 on creation (src/vectorscope.c:80); the mouse wheel changes it (:476-482) */
@@ -47,7 +62,8 @@ struct wvs_source {
 	struct cm_source cm;
 	uint8_t *tex_buf[2];
 	uint32_t tex_buf_width[2];
-	volatile int w_tex_buf;
+	int w_tex_buf;
+	pthread_mutex_t tex_mutex;
 	uint32_t components;
 	int display;   /* DISP_OVERLAY / DISP_STACK / DISP_PARADE, src/waveform.c:22-24 */
 	int intensity; /* src/waveform.c:104-106 */
@@ -59,7 +75,8 @@ struct his_source {
 	struct cm_source cm;
 	uint8_t *tex_buf[2];
 	uint32_t hi_max[2][3];
-	volatile int w_tex_buf;
+	int w_tex_buf;
+	pthread_mutex_t tex_mutex;
 	uint32_t components;
 	int level_fixed_value;
 	int level_ratio_value;
