@@ -273,6 +273,16 @@ __device__ __forceinline__ void scope_prio_round(u32 wave, u32 round)
 	}
 }
 
+/* The lanes of ONE wave hand data to each other through the LDS (bin_rle's scratch row): a wave's LDS operations are performed
+ * in order by the hardware; this tells the COMPILER not to move or forward the plain stores and loads across the point.  No
+ * instructions on gfx9. */
+__device__ __forceinline__ void scope_wave_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 /* Slice s of S of `total` cells. */
 __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
 {
@@ -321,14 +331,20 @@ __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
  * 16-bin output group is two aligned uint4.  The table lies at byte VSS3_BASE of the LDS block, behind the waveform's;
  * the origin (row 16, column 8) and the base are ONE constant, carried by the ds instruction's immediate offset, so
  * the address arithmetic is HASH 2's: the raw word v * 116 + (u >> 1) fits 16 bits (vss_add_pair). */
-#define VSS3_PITCH 116u
+#ifndef VSS3_PITCH
+#define VSS3_PITCH 116u /* even (the read-out's 8-byte loads); < 128 (the table must fit behind the waveform's 48 KiB) */
+#endif
 #define VSS3_ROWS 225u
 #define VSS3_V0 16u
 #define VSS3_U0 8u
 #define VSS3_BASE 49152u
 #define VSS3_BIAS (VSS3_BASE - 4u * (VSS3_V0 * VSS3_PITCH + (VSS3_U0 >> 1)))
+static_assert(VSS3_PITCH % 2u == 0u && VSS3_PITCH >= 116u && VSS3_BASE + ((VSS3_ROWS * VSS3_PITCH + 3u) & ~3u) * 4u <= 160u * 1024u,
+	      "HASH 3: an even pitch that holds u = 8 .. 239 and leaves the table inside the CU's 160 KiB");
+static_assert(VSS3_BASE >= 4u * (VSS3_V0 * VSS3_PITCH + (VSS3_U0 >> 1)) && VSS3_BIAS < 65536u && 240u * VSS3_PITCH + 119u < 65536u,
+	      "HASH 3: the bias is a ds instruction's offset field, the raw word index a 16-bit half");
 template <int HASH> struct VssTable {
-	static constexpr u32 words = HASH == 3 ? VSS3_ROWS * VSS3_PITCH : HASH == 2 ? 256u * VSS_PITCH2 : VSS_WORDS;
+	static constexpr u32 words = HASH == 3 ? ((VSS3_ROWS * VSS3_PITCH + 3u) & ~3u) : HASH == 2 ? 256u * VSS_PITCH2 : VSS_WORDS; /* whole uint4s */
 	static constexpr u32 pitch = HASH == 3 ? VSS3_PITCH : HASH == 2 ? VSS_PITCH2 : 128u;
 	static constexpr u32 bias = HASH == 3 ? VSS3_BIAS : 0u; /* bytes added to 4 * (v * pitch + (u >> 1)) */
 };

@@ -149,7 +149,14 @@ __device__ __forceinline__ u32 scope_slice_begin_cells(u32 total, u32 s, u32 S)
 #ifndef SCOPE_STREAM_MAIN
 #define SCOPE_STREAM_MAIN 1 /* 0: every batch through the checked form (A/B) */
 #endif
-template <int VECW, int U, bool NT, bool CONTIG, bool MAIN = CONTIG, bool ROUNDS = false, typename Pro, typename Hook, typename F>
+/* ROWS (padded planes, linesize > ncols * cell size: what a D3D11 staging surface can look like, src/vectorscope.c:225,236): the
+ * streams are whole ROWS -- [c0, c1) is a range of rows, lane group g walks its share of them -- and a row is a multiple of
+ * a lane group's cells (scope_rows_mode), so every lane of a wave is in the same column phase: whether a load's successor lies
+ * in the next row is a WAVE-UNIFORM question, the column cursor lives in a scalar register, and the per-lane address costs
+ * one add of a scalar increment (the pitch padding folded in when the cursor wraps), as in the CONTIG form.  The general
+ * form below keeps the column per lane: eleven operations per load, 9 % of the fused vectorscope kernel on a padded 4K plane. */
+template <int VECW, int U, bool NT, bool CONTIG, bool MAIN = CONTIG, bool ROUNDS = false, bool ROWS = false, typename Pro, typename Hook,
+	  typename F>
 __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize, u32 xbyte0, u32 ncols, u32 c0, u32 c1,
 					     u32 glog2, Pro &&after_first_issue, Hook &&before_batch, F &&fn)
 {
@@ -163,9 +170,19 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	const u32 g = lane >> (6u - glog2);     /* my group = my stream */
 	const u32 tg = blockDim.x >> glog2;     /* lanes of the workgroup on one stream */
 	const u32 len = c1 - c0;
-	const u32 s0 = c0 + (u32)(((u64)len * g) >> glog2);
-	const u32 s1 = c0 + (u32)(((u64)len * (g + 1)) >> glog2);
-	const u32 longest = (len + (1u << glog2) - 1u) >> glog2;
+	u32 s0, s1, longest, shortest;
+	if (ROWS && !CONTIG) {
+		const u32 r0 = c0 / ncols, rl = len / ncols; /* c0 and c1 are row boundaries */
+		s0 = (r0 + (u32)(((u64)rl * g) >> glog2)) * ncols;
+		s1 = (r0 + (u32)(((u64)rl * (g + 1)) >> glog2)) * ncols;
+		longest = ((rl + (1u << glog2) - 1u) >> glog2) * ncols;
+		shortest = (rl >> glog2) * ncols;
+	} else {
+		s0 = c0 + (u32)(((u64)len * g) >> glog2);
+		s1 = c0 + (u32)(((u64)len * (g + 1)) >> glog2);
+		longest = (len + (1u << glog2) - 1u) >> glog2;
+		shortest = len >> glog2;
+	}
 	const u32 step = (u32)U * tg;
 	const u32 batches = (longest + step - 1u) / step;
 	/* priority rounds (scope_prio_round): the histogram's kernels only -- RGB +0.8 ... 1.6 %, the fused Y'CbCr form +5 %; the
@@ -198,7 +215,12 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	 * cell's offset is its index times the cell size: no column bookkeeping, three operations per load instead of
 	 * eleven.  Same-process A/B: histogram +1 %, fused-K0 vectorscope +4 %, plain vectorscope +0.6 % on noise and
 	 * +3.7 % on screen content (once its per-pixel arithmetic had been trimmed; before that it lost 3 % there). */
-	const u32 end_off = (s1 - row0 * ncols) * cell_bytes;
+	const u32 end_off = ROWS && !CONTIG ? (s1 / ncols - row0) * linesize : (s1 - row0 * ncols) * cell_bytes;
+	/* ROWS: the wave's column cursor (the lane's column is col_s + its place in the lane group) and what a wrap adds */
+	u32 col_s = ROWS ? (wave_u * lg) % ncols : 0u;
+	const u32 d_off_wrap = d_off + wrap_off;
+	(void)col_s;
+	(void)d_off_wrap;
 	vec_t va[U], vb[U];
 	bool oka[U], okb[U];
 
@@ -210,6 +232,13 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 				ok[k] = off < end_off;                                                 \
 				v[k] = scope_load_base<NT, vec_t>(base, ok[k] ? off : safe_off);       \
 				off += tg * cell_bytes;                                                \
+			} else if (ROWS) {                                                             \
+				ok[k] = off < end_off;                                                 \
+				v[k] = scope_load_base<NT, vec_t>(base, ok[k] ? off : safe_off);       \
+				col_s += dr;                                                           \
+				const bool wrap_ = col_s >= ncols;                                     \
+				col_s = wrap_ ? col_s - ncols : col_s;                                 \
+				off += wrap_ ? d_off_wrap : d_off;                                     \
 			} else {                                                                       \
 				ok[k] = (c + (u32)k * tg) < s1;                                        \
 				v[k] = scope_load_base<NT, vec_t>(base, ok[k] ? off : safe_off);       \
@@ -235,7 +264,7 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 	SCOPE_ISSUE(va, oka);
 	after_first_issue();
 	u32 b = 0;
-	if (CONTIG && MAIN && SCOPE_STREAM_MAIN) {
+	if ((CONTIG || ROWS) && MAIN && SCOPE_STREAM_MAIN) {
 		/* The first `full` batches are inside the stream for every lane of every group (the shortest group has
 		 * len >> glog2 cells): no range test, no address select and no predication there -- two VALU instructions per
 		 * load and an exec-mask branch per load less (what the fused-K0 kernels are short of); the rest of the stream,
@@ -245,7 +274,7 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 		 * +0.3 %; the plain RGB histogram -2 .. -5 % (its callers pass MAIN = false).  (A form in which the vectorscope's
 		 * main loop knew only the plain adds and left for the general loop when the vote said absorb -- to get the vote's
 		 * 1.4 % back -- gained nothing on noise and lost 6 % on flat and 13 % on screen content: both bodies in one loop.) */
-		const u32 full = (len >> glog2) / step;
+		const u32 full = shortest / step;
 		bool yes[U];
 #pragma unroll
 		for (int k = 0; k < U; k++)
@@ -255,7 +284,14 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 		_Pragma("unroll") for (int k = 0; k < U; k++)                                      \
 		{                                                                                  \
 			v[k] = scope_load_base<NT, vec_t>(base, off);                              \
-			off += tg * cell_bytes;                                                    \
+			if (CONTIG) {                                                              \
+				off += tg * cell_bytes;                                            \
+			} else {                                                                   \
+				col_s += dr;                                                       \
+				const bool wrap_ = col_s >= ncols;                                 \
+				col_s = wrap_ ? col_s - ncols : col_s;                             \
+				off += wrap_ ? d_off_wrap : d_off;                                 \
+			}                                                                          \
 		}                                                                                  \
 		c += step;                                                                         \
 	} while (0)
@@ -278,8 +314,21 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 		if (b + 1 < batches)
 			SCOPE_BIN(vb, okb);
 	}
+	if (PRIO)
+		__builtin_amdgcn_s_setprio(0); /* the epilogues (flush, reduction, tickets) and whatever shares the SIMD run at the usual priority */
 #undef SCOPE_ISSUE
 #undef SCOPE_BIN
+}
+
+#ifndef SCOPE_ROWS
+#define SCOPE_ROWS 1 /* 0: padded planes through the general form (A/B) */
+#endif
+/* Does a padded plane's slice run the ROWS form of scope_stream?  A row must be whole lane groups (every lane of a wave in one
+ * column phase) and a lane group's share at least sixteen rows (streams are whole rows: a share of 8.4 rows -- one 4K frame
+ * over 256 workgroups -- would be 8 rows here and 9 there). */
+__device__ __forceinline__ bool scope_rows_mode(u32 linesize, u32 ncols, u32 cell_bytes, u32 rows, u32 slices, u32 glog2)
+{
+	return SCOPE_ROWS && linesize != ncols * cell_bytes && ncols % (64u >> glog2) == 0u && rows >= ((16u * slices) << glog2);
 }
 
 #ifndef VSS_RLE
@@ -308,8 +357,9 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 	if (ncols == 0)
 		return;
 	const u32 total = rows * ncols;
-	const u32 c0 = scope_slice_begin_cells(total, slice, slices);
-	const u32 c1 = scope_slice_begin_cells(total, slice + 1, slices);
+	const bool rows_mode = VECW == 4 && scope_rows_mode(linesize, ncols, 16u, rows, slices, glog2); /* uniform */
+	const u32 c0 = rows_mode ? scope_slice_begin(rows, slice, slices) * ncols : scope_slice_begin_cells(total, slice, slices);
+	const u32 c1 = rows_mode ? scope_slice_begin(rows, slice + 1, slices) * ncols : scope_slice_begin_cells(total, slice + 1, slices);
 	auto epoch = [&](u32 px) {
 		/* uniform across the workgroup: everybody takes the same branch */
 		if (since_clamp + px > VSS_EPOCH_PIXELS) {
@@ -380,7 +430,10 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 						slot[1] = p2;
 						slot[2] = p3;
 					}
-					/* a wave's LDS operations are performed in order: the reads below see the writes above */
+					/* a wave's LDS operations are performed in order, so the reads below see the writes above; the fence and
+					 * the wave barrier (no instructions on gfx9) say so to the compiler, which may otherwise move or forward the
+					 * plain stores and loads of lanes that only MAY alias */
+					scope_wave_fence();
 					for (u32 base = 0; base < n3; base += wave_w) {
 						const u32 idx = base + lane_w;
 						u32 key[1] = {idx < n3 ? rle_scr[idx] : 0u};
@@ -388,6 +441,7 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 						if (idx < n3)
 							vss_add<HASH>(tab, key[0], 1);
 					}
+					scope_wave_fence(); /* ... and the next cell's stores stay behind these reads */
 				}
 			}
 		};
@@ -459,6 +513,8 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		};
 		if (linesize == ncols * 16u)
 			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_pairs);
+		else if (rows_mode)
+			scope_stream<4, U, NT, false, true, false, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_pairs);
 		else
 			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_pairs);
 	} else if (VECW == 4) {
@@ -543,6 +599,8 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		};
 		if (linesize == ncols * 16u) /* uniform: planes whose rows carry no padding */
 			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_cells);
+		else if (rows_mode)
+			scope_stream<4, U, NT, false, true, false, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_cells);
 		else
 			scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_cells);
 	} else {
@@ -670,8 +728,9 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 	if (ncols == 0)
 		return;
 	const u32 total = rows * ncols;
-	const u32 c0 = scope_slice_begin_cells(total, slice, slices);
-	const u32 c1 = scope_slice_begin_cells(total, slice + 1, slices);
+	const bool rows_mode = VECW == 4 && scope_rows_mode(linesize, ncols, 16u, rows, slices, 0); /* uniform */
+	const u32 c0 = rows_mode ? scope_slice_begin(rows, slice, slices) * ncols : scope_slice_begin_cells(total, slice, slices);
+	const u32 c1 = rows_mode ? scope_slice_begin(rows, slice + 1, slices) * ncols : scope_slice_begin_cells(total, slice + 1, slices);
 	const u32 rep = threadIdx.x & 31u;
 	const bool need_uv = (chmask & 5u) != 0, need_y = (chmask & 2u) != 0;
 	auto nothing = [](u32) {};
@@ -690,6 +749,8 @@ __device__ __forceinline__ void his_region(u32 *tab, const uint8_t *plane, u32 l
 		};
 		if (linesize == ncols * 16u) /* uniform: rows without padding */
 			scope_stream<4, U, NT, true, FUSE, true>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
+		else if (rows_mode)
+			scope_stream<4, U, NT, false, FUSE, true, true>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
 		else
 			scope_stream<4, U, NT, false, false, true>(plane, linesize, xbyte0, ncols, c0, c1, 0, prologue, nothing, bin_cells);
 	} else {
@@ -1015,6 +1076,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 			WVS_BIN(vb, okb);
 			WVS_ISSUE(vb, okb);
 		}
+		if (WVS_PRIO && SW == 16)
+			__builtin_amdgcn_s_setprio(0); /* the flush and the next unit's start at the usual priority */
 		if (DEEP) { /* va, vb hold slots 0, 1 of the next unit; these are its slots 2 .. */
 #pragma unroll
 			for (int e = 0; e < NX; e++)

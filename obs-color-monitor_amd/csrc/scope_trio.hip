@@ -555,6 +555,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		TRIO_T(tb3);
 		TRIO_T_ADD(t_barrier, tb2, tb3);
 	}
+	if (TRIO_PRIO)
+		__builtin_amdgcn_s_setprio(0); /* the slice's epilogue (partial table, histogram atomics, ticket) at the usual priority */
 #ifdef TRIO_TRACE
 	if (lane == 0) {
 		unsigned long long *d = &scope_trio_dbg[((size_t)(blockIdx.x & 255u) * 16u + wave) * 4u];
@@ -582,9 +584,18 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 				const u32 k16 = g & 15u;
 				if (row - VSS3_V0 < VSS3_ROWS && k16 != 15u) {
 					const u32 w0 = (row - VSS3_V0) * VSS3_PITCH + (k16 << 3);
-					hi = *(const uint4 *)&vt[w0];
-					if (k16 != 0u)
-						lo = *(const uint4 *)&vt[w0 - 4u];
+					if (VSS3_PITCH % 4u == 0u) {
+						hi = *(const uint4 *)&vt[w0];
+						if (k16 != 0u)
+							lo = *(const uint4 *)&vt[w0 - 4u];
+					} else { /* a pitch that is only even: 8-byte loads (once per slice) */
+						const uint2 h0 = *(const uint2 *)&vt[w0], h1 = *(const uint2 *)&vt[w0 + 2u];
+						hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+						if (k16 != 0u) {
+							const uint2 l0 = *(const uint2 *)&vt[w0 - 4u], l1 = *(const uint2 *)&vt[w0 - 2u];
+							lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+						}
+					}
 				}
 			} else {
 				const u32 w0 = TRIO_HASH == 2 ? row * VSS_PITCH2 + ((g & 15u) << 3) : (row << 7) + (((g & 15u) << 3) ^ ((row & 15u) << 3));
@@ -704,8 +715,33 @@ hipError_t scope_trio_init(void)
 	return e;
 }
 
+/* The compact vectorscope table (HASH 3) holds the bins U in [8, 239], V in [16, 240] and nothing else: a chroma outside that
+ * rectangle would be counted in the waveform's table or in a neighbouring row without any fault.  Today's two matrices stay
+ * inside (tests/test_oracle.py::test_k0_chroma_range, test_dock_kernel_all_colours); this is the launch-time guard for
+ * a third one, a full-range option or other coefficients: the matrix rows are linear, so their extremes over all colours lie
+ * at the eight corners of the RGB cube, evaluated here in the kernel's own fixed point with the guard band on either side
+ * (a result the kernel recomputes in fp32 moves by one step at most). */
+static bool trio_chroma_fits(const ScopeK0 &k)
+{
+	for (int corner = 0; corner < 8; corner++) {
+		const long long r = (corner & 1) ? 255 : 0, g = (corner & 2) ? 255 : 0, b = (corner & 4) ? 255 : 0;
+		const long long su = k.fu[0] * r + k.fu[1] * g + k.fu[2] * b + (long long)(uint32_t)k.fu[3];
+		const long long sv = k.fv[0] * r + k.fv[1] * g + k.fv[2] * b + (long long)(uint32_t)k.fv[3];
+		for (long long d = -2 * SCOPE_K0_FX_GUARD; d <= 0; d += 2 * SCOPE_K0_FX_GUARD) {
+			const long long u = (su + d) >> SCOPE_K0_FX_SHIFT, v = (sv + d) >> SCOPE_K0_FX_SHIFT;
+			if (u < (long long)VSS3_U0 || u > 239 || v < (long long)VSS3_V0 || v >= (long long)(VSS3_V0 + VSS3_ROWS))
+				return false;
+		}
+	}
+	return true;
+}
+
 bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const ScopeTuning &tn)
 {
+	/* both matrices the library knows (scope_k0_matrix: 1 -> 601, anything else -> 709), once */
+	static const bool chroma_ok = !TRIO_COMPACT || (trio_chroma_fits(scope_k0_matrix(1)) && trio_chroma_fits(scope_k0_matrix(2)));
+	if (!chroma_ok)
+		return false; /* the two-pass path then (scope_api.hip): its tables hold every bin */
 	/* the vector shape, a column's rows within the waveform's 16-bit counters, 32-bit offsets */
 	return scope_wvs_vector_shape(fs, wvs_dst, tn) && fs.height >= 1 && fs.height <= 65535u &&
 	       (u64)fs.height * fs.linesize < (1ull << 31);
@@ -732,7 +768,10 @@ uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu, uint32_t st
 	s0 = min(min(s0, strips), 256u);
 	const u32 per = (strips + s0 - 1u) / s0;
 	u32 s = (strips + per - 1u) / per;
-	if (s > 1u && (s & 1u))
+	/* only 16-column slices pair up; an odd count of 32-column slices is fine, and rounding it up could exceed the strips there are
+	 * (three strips -> four slices, one of them empty: legal for the kernel -- it writes an empty partial and takes its ticket --
+	 * but 150 KiB of LDS zeroed for nothing) */
+	if (strip_width == 16u && s > 1u && (s & 1u))
 		s++;
 	return min(s, 256u);
 }
@@ -743,6 +782,8 @@ hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t 
 {
 	if ((chmask & 7u) == 0 || slices == 0 || slices > 256u || (slices > 1 && !vss_mask) || (strip_width != 16u && strip_width != 32u))
 		return hipErrorInvalidValue;
+	if (TRIO_COMPACT && !trio_chroma_fits(scope_k0_matrix(colorspace)))
+		return hipErrorInvalidValue; /* never a silent write outside the compact table */
 	ScopeWvsHis h = {NULL, NULL, NULL, 0};
 	if (his)
 		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};

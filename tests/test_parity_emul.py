@@ -71,6 +71,22 @@ def test_vectorscope_fused_k0_long_streams(emul_ctx, oracle, merge, hash_):
         pc.check_vectorscope(emul_ctx, oracle, 509, 130, 2, 2048, fuse=True, colorspace=1)  # tails + pitch
 
 
+@pytest.mark.parametrize("groups,w,h,slices", [(0, 256, 80, 1), (0, 256, 80, 4), (3, 64, 300, 2), (2, 128, 200, 3), (1, 384, 70, 2),
+                                               (0, 256, 530, 1), (3, 64, 2100, 1)])  # the last two: eight batches of the unchecked main loop
+def test_padded_planes_walk_whole_rows(emul_ctx, oracle, groups, w, h, slices):
+    """scope_stream's ROWS form: a padded DEVICE plane (linesize > 4 W, src/vectorscope.c:225,236; host planes are packed on
+    their way to the GPU) whose rows are whole lane groups is walked in whole rows with a wave-uniform column cursor -- the plain
+    and the fused vectorscope (unchecked main loop and checked tail, lane groups whose shares differ by a row, several slices)
+    and the histogram's kernels.  The widths here are multiples of 64 >> groups cells and every lane group has sixteen rows or
+    more, so this form runs (seen with a probe build); the geometry tests (odd widths, few rows) keep the general form covered."""
+    ls = 4 * w + 64
+    for unroll in (0, 4):
+        with pc.options(emul_ctx, **{"slices": slices, "vss.groups": groups, "vss.unroll": unroll, "vss.fused_unroll": unroll}):
+            pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, w, h, ls, n=2)
+    with pc.options(emul_ctx, **{"slices": slices, "vss.groups": groups, "vss.merge": 0}):
+        pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, w, h, ls, n=1, offset=16)
+
+
 @pytest.mark.parametrize("comp", pc.COMPONENTS)
 def test_waveform_components(emul_ctx, oracle, comp):
     pc.check_waveform(emul_ctx, oracle, 70, 9, 5, comp)
