@@ -140,6 +140,10 @@ __device__ __forceinline__ u32 scope_slice_begin_cells(u32 total, u32 s, u32 S)
 	return c & ~((u32)SCOPE_SLICE_ALIGN - 1u);
 }
 
+#ifndef WVS_PACE
+#define WVS_PACE 0 /* experiment (visit b5): s_sleep of this many 64-clock units behind every slot pair of a ONE-channel unit -- do the
+		    * one-channel modes run 5 % under the RGB form because their waves ask for memory in tighter bursts? */
+#endif
 #ifndef WVS_PRIO
 #define WVS_PRIO 1 /* the same inside scope_wvs_kernel's units, narrow-strip form only (see there); 0: A/B */
 #endif
@@ -1075,6 +1079,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 			WVS_ISSUE(va, oka);
 			WVS_BIN(vb, okb);
 			WVS_ISSUE(vb, okb);
+			if (WVS_PACE && nch == 1)
+				__builtin_amdgcn_s_sleep(WVS_PACE);
 		}
 		if (WVS_PRIO && SW == 16)
 			__builtin_amdgcn_s_setprio(0); /* the flush and the next unit's start at the usual priority */

@@ -178,6 +178,7 @@ static inline int __ffsll(long long v)
 #define __builtin_amdgcn_s_setprio(x) ((void)0) /* issue priority: nothing to emulate */
 #define __builtin_amdgcn_fence(order, scope) ((void)0) /* one-lane waves run to completion between yields: nothing to order */
 #define __builtin_amdgcn_wave_barrier() ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 static inline void __threadfence()
 {
 	__sync_synchronize();

@@ -87,7 +87,47 @@ def test_bench_shapes_64x4k_vectorscope(hip_ctx, oracle, pool64):
     _all_frames(got, lambda f: want[2][f], "vectorscope x64, SCOPE_OUT_PACKED16")
 
 
-@pytest.mark.parametrize("comp", [0x07, 0x20, 0x04])
+def test_bench_shapes_64x4k_padded_pitch(hip_ctx, oracle, pool64):
+    """bench.py's padded-pitch leg at its real size (linesize = 4 W + 256, src/vectorscope.c:225,236): the
+    same 64 frames behind a pitch, so the tables must be the ones of the packed planes -- the staged and the fused vectorscope
+    (scope_stream's ROWS form: 2160 rows in 32 lane-group shares of 67 and 68) and the histogram, all 64 tables each; then one
+    frame per call and the ring of three, which keep the general form (8.4 rows per workgroup are no whole-row shares)."""
+    import torch
+
+    from obs_color_monitor_amd.synth import pad_pitch
+
+    ls = 4 * W + 256
+    out = torch.empty((N, 65536), dtype=torch.uint8, device="cuda")
+    want = [oracle.vectorscope(pool64["yuv709"][f], W).reshape(-1) for f in range(N)]
+    for key, is_rgb in (("d_yuv", False), ("d_rgb", True)):
+        padded = pad_pitch(torch, pool64[key] if is_rgb else pool64[key][2], W)
+        padded[:, :, 4 * W:] = 0x5A  # whatever lies in the padding is nobody's texel
+        b = hip_ctx.make_device_batch(padded, ls, W, H, planes_are_rgb=is_rgb, colorspace=2)
+        out.fill_(0xEE)
+        hip_ctx.vectorscope_batch_dev(b, out, sync=False)
+        hip_ctx.sync()
+        _all_frames(out.cpu().numpy(), lambda f: want[f], f"vectorscope x64, pitch {ls}, {'SCOPE_FUSE_K0' if is_rgb else 'staged planes'}")
+        for nf in (1, 3):
+            b = hip_ctx.make_device_batch(padded[:nf], ls, W, H, planes_are_rgb=is_rgb, colorspace=2)
+            out[:nf].fill_(0xEE)
+            hip_ctx.vectorscope_batch_dev(b, out[:nf], sync=False)
+            hip_ctx.sync()
+            got = out[:nf].cpu().numpy()
+            assert all(np.array_equal(got[f], want[f]) for f in range(nf)), f"vectorscope x{nf}, pitch {ls}, rgb {is_rgb}"
+        if is_rgb:
+            his = torch.empty((N, 1024), dtype=torch.int32, device="cuda")
+            b = hip_ctx.make_device_batch(padded, ls, W, H, planes_are_rgb=True, colorspace=2)
+            for comp in (0x07, 0x20):
+                his.fill_(-1)
+                hip_ctx.histogram_counts_batch_dev(b, comp, his, sync=False)
+                hip_ctx.sync()
+                got = his.cpu().numpy().view(np.uint32)
+                _all_frames(got, lambda f: oracle.histogram_counts(pool64["rgb"][f], pool64["yuv709"][f], W, comp).reshape(-1),
+                            f"histogram {comp:#04x} x64, pitch {ls}")
+        del padded
+
+
+@pytest.mark.parametrize("comp", [0x07, 0x20, 0x04, 0x02, 0x01])
 def test_bench_shapes_64x4k_waveform(hip_ctx, oracle, pool64, comp):
     """bench.py's waveform variants: RGB planes in every mode (the luma mode derives Y' through the fused K0), and the
     staged Y'CbCr planes for the luma mode as the reference's K2 reads them."""
