@@ -326,13 +326,19 @@ __device__ __forceinline__ u32 scope_slice_begin(u32 total, u32 s, u32 S)
  * produce.  Over all 2^24 colours and both matrices U lies in [15, 239] and V in [16, 240] (data/common.effect:23-43 are
  * limited-range chroma rows; tests/test_oracle.py::test_k0_chroma_range enumerates them, test_dock_kernel_all_colours
  * runs every colour through the kernel), so the table holds rows v = 16 .. 240 and the columns u = 8 .. 239:
- * word (v - 16) * 116 + ((u - 8) >> 1), 225 rows of 116 words = 104 400 bytes instead of 131 072.  The pitch is 4 words
- * more than a multiple of 16: eight consecutive rows start on eight different multiples of four words, and every
- * 16-bin output group is two aligned uint4.  The table lies at byte VSS3_BASE of the LDS block, behind the waveform's;
- * the origin (row 16, column 8) and the base are ONE constant, carried by the ds instruction's immediate offset, so
- * the address arithmetic is HASH 2's: the raw word v * 116 + (u >> 1) fits 16 bits (vss_add_pair). */
+ * word (v - 16) * PITCH + ((u - 8) >> 1), 225 rows of PITCH >= 116 words.  PITCH = 122 (109 800 bytes instead of 131 072): 122 = 26
+ * mod 32, so consecutive rows start 26 banks apart and sixteen of them start on sixteen different banks -- a chroma cluster of
+ * a few rows by a few words (what a wave sees of any coherent picture) is spread over the banks.  Round 4 ran 116 (= 20 mod 32:
+ * rows eight apart share their banks); on the ramp content, whose chroma lies on ONE line through the CbCr plane, the clusters of a
+ * wave's four image rows then met in the same banks: a model of the table's bank traffic over sampled wave instructions
+ * (profiles/round5/vss3_pitch_model.txt) put 122 at 0.77 of 116's conflict cost there and level elsewhere, and the same-process
+ * A/B agreed: ramp 3084 -> 3394 GB/s (+10 %), noise / natural / screen +-0.1 %, concentrated -0.5 % (visit b5,
+ * profiles/round5/ab_trio_pitch_depth.txt).  An even pitch keeps the read-out's 8-byte loads aligned; the table lies at byte
+ * VSS3_BASE of the LDS block, behind the waveform's; the origin (row 16, column 8) and the base are ONE constant, carried by the
+ * ds instruction's immediate offset, so the address arithmetic is HASH 2's: the raw word v * PITCH + (u >> 1) fits 16 bits
+ * (vss_add_pair). */
 #ifndef VSS3_PITCH
-#define VSS3_PITCH 116u /* even (the read-out's 8-byte loads); < 128 (the table must fit behind the waveform's 48 KiB) */
+#define VSS3_PITCH 122u /* even (the read-out's 8-byte loads); < 128 (the table must fit behind the waveform's 48 KiB) */
 #endif
 #define VSS3_ROWS 225u
 #define VSS3_V0 16u

@@ -12,7 +12,7 @@
  * The dock's three scopes from ONE read, for ANY number of frames: scope_trio_kernel.
  *
  * BOTH tables are resident in the LDS: the vectorscope's (16-bit counters; the compact HASH 3 form of scope_device.h: only
- * the chroma K0 can produce, 104 400 bytes) and a waveform table of ONE strip of columns (48 KiB; the map is described at
+ * the chroma K0 can produce, 109 800 bytes) and a waveform table of ONE strip of columns (48 KiB; the map is described at
  * TRIO_COMPACT below).  A workgroup owns strips of one frame and streams them like any other kernel here: every texel is
  * loaded once (8 bytes = a column pair per lane, TRIO_D loads per lane in flight, buffer addressing), counted in the waveform
  * table (alpha test, src/waveform.c:247-248), sent through the fixed-point K0 and counted in the vectorscope table.  Per
@@ -88,10 +88,10 @@
  * met in a bank whenever their values agreed mod 4 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.64,
  * profiles/round3/pmc_sq_three_scope_x64_f1.txt), and four rows of flat content met on one ADDRESS.
  * K0 is fused here, and its chroma rows are limited-range: U in [15, 239], V in [16, 240] for every colour and both matrices
- * (scope_device.h, HASH 3).  The vectorscope table shrinks to that rectangle -- 225 rows of 116 words, 104 400 bytes -- and the
- * 26 KiB that frees buy a SECOND waveform replica (four for a one-channel mask):
+ * (scope_device.h, HASH 3).  The vectorscope table shrinks to that rectangle -- 225 rows of 122 words (round 4: 116), 109 800 bytes -- and the
+ * 21 KiB that frees buy a SECOND waveform replica (four for a one-channel mask):
  *     bytes      0 ..  49 151   waveform: [channel][256 values][REP replicas][8 column pairs] words of two 16-bit counters
- *     bytes 49 152 .. 153 551   vectorscope, HASH 3
+ *     bytes 49 152 .. 158 951   vectorscope, HASH 3
  * A lane's replica is its row within the half wave mod REP, so the bank is (value mod (4 / REP)) * 8 REP + replica * 8 + pair:
  * with two replicas only the rows r and r + 2 can meet, two-way at most -- which costs a ds_add nothing
  * (profiles/round1/lds_atomic_microbench.txt: "same bank, distinct address x 2" = the conflict-free 4.5 clk) -- and flat content

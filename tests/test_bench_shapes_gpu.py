@@ -104,12 +104,14 @@ def test_bench_shapes_64x4k_padded_pitch(hip_ctx, oracle, pool64):
         padded[:, :, 4 * W:] = 0x5A  # whatever lies in the padding is nobody's texel
         b = hip_ctx.make_device_batch(padded, ls, W, H, planes_are_rgb=is_rgb, colorspace=2)
         out.fill_(0xEE)
+        torch.cuda.synchronize()  # the planes were made on torch's stream, the library launches on its context's
         hip_ctx.vectorscope_batch_dev(b, out, sync=False)
         hip_ctx.sync()
         _all_frames(out.cpu().numpy(), lambda f: want[f], f"vectorscope x64, pitch {ls}, {'SCOPE_FUSE_K0' if is_rgb else 'staged planes'}")
         for nf in (1, 3):
             b = hip_ctx.make_device_batch(padded[:nf], ls, W, H, planes_are_rgb=is_rgb, colorspace=2)
             out[:nf].fill_(0xEE)
+            torch.cuda.synchronize()
             hip_ctx.vectorscope_batch_dev(b, out[:nf], sync=False)
             hip_ctx.sync()
             got = out[:nf].cpu().numpy()
@@ -119,6 +121,7 @@ def test_bench_shapes_64x4k_padded_pitch(hip_ctx, oracle, pool64):
             b = hip_ctx.make_device_batch(padded, ls, W, H, planes_are_rgb=True, colorspace=2)
             for comp in (0x07, 0x20):
                 his.fill_(-1)
+                torch.cuda.synchronize()
                 hip_ctx.histogram_counts_batch_dev(b, comp, his, sync=False)
                 hip_ctx.sync()
                 got = his.cpu().numpy().view(np.uint32)
