@@ -140,10 +140,6 @@ __device__ __forceinline__ u32 scope_slice_begin_cells(u32 total, u32 s, u32 S)
 	return c & ~((u32)SCOPE_SLICE_ALIGN - 1u);
 }
 
-#ifndef WVS_PACE
-#define WVS_PACE 0 /* experiment (visit b5): s_sleep of this many 64-clock units behind every slot pair of a ONE-channel unit -- do the
-		    * one-channel modes run 5 % under the RGB form because their waves ask for memory in tighter bursts? */
-#endif
 #ifndef WVS_PRIO
 #define WVS_PRIO 1 /* the same inside scope_wvs_kernel's units, narrow-strip form only (see there); 0: A/B */
 #endif
@@ -417,7 +413,8 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 				scope_k0_cell<1, true>(key0, k0, true, false); /* wave votes inside: every lane goes through */
 				/* keys have bytes 0 and 3 zero: bit 31 marks a flat cell, bit 30 + the lane a cell that continues nothing */
 				const u32 tag = flat ? (key0[0] | 0x80000000u) : (0x40000000u | lane_id);
-				const bool cont = flat && tag == scope_lane_below(tag, 0u) && (lane_id & (run_lanes - 1u)) != 0u;
+				const u32 below = scope_lane_below(tag, 0u); /* every lane takes part in the DPP move (its contract), flat or not */
+				const bool cont = flat && tag == below && (lane_id & (run_lanes - 1u)) != 0u;
 				const u64 breaks = ~__ballot(cont); /* every lane that continues nothing (and every lane there is none of) */
 				if (flat && !cont) { /* the head of a run: the next break above this lane ends it */
 					const u64 above = ((breaks >> 1) | (1ull << 63)) >> lane_id;
@@ -573,7 +570,8 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 							       const u32 i0 = idx[k][0];
 							       const bool flat = ok[k] && ((i0 == idx[k][1]) & (i0 == idx[k][2]) & (i0 == idx[k][3]));
 							       const u32 tag = flat ? (i0 | 0x80000000u) : (0x40000000u | rk_lane);
-							       const bool cont = flat && tag == scope_lane_below(tag, 0u) && (rk_lane & (rk_run - 1u)) != 0u;
+							       const u32 below = scope_lane_below(tag, 0u); /* every lane takes part (the DPP move's contract) */
+							       const bool cont = flat && tag == below && (rk_lane & (rk_run - 1u)) != 0u;
 							       const u64 breaks = ~__ballot(cont);
 							       if (flat && !cont) {
 								       const u64 above = ((breaks >> 1) | (1ull << 63)) >> rk_lane;
@@ -1079,8 +1077,6 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 			WVS_ISSUE(va, oka);
 			WVS_BIN(vb, okb);
 			WVS_ISSUE(vb, okb);
-			if (WVS_PACE && nch == 1)
-				__builtin_amdgcn_s_sleep(WVS_PACE);
 		}
 		if (WVS_PRIO && SW == 16)
 			__builtin_amdgcn_s_setprio(0); /* the flush and the next unit's start at the usual priority */

@@ -111,6 +111,11 @@ const char *hipGetErrorString(hipError_t e);
 /* ---- device vocabulary -------------------------------------------------------------------- */
 namespace emul {
 void block_barrier();
+/* SCOPE_EMUL_WAVE64=1: the 64 threads of a wave in lock step between cross-lane operations (emul_runtime.cpp) */
+bool wave64();
+/* the rendezvous of a wave's live lanes: every lane leaves `v`; returns the 64 slots and which of them are lanes that took part */
+const uint64_t *wave_gather(uint64_t v, uint64_t *mask, unsigned site);
+enum { SITE_BALLOT = 1, SITE_READLANE, SITE_BELOW, SITE_SUM, SITE_BARRIER };
 /* runs fn(blockIdx) for every thread of every block */
 void run_grid(dim3 grid, dim3 block, void (*thread_fn)(void *), void *ctx);
 } // namespace emul
@@ -153,17 +158,32 @@ static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t x)
 {
 	return x;
 }
-static inline uint32_t __builtin_amdgcn_readlane(uint32_t x, uint32_t)
+static inline uint32_t __builtin_amdgcn_readlane(uint32_t x, uint32_t lane)
 {
+	if (emul::wave64()) {
+		uint64_t m;
+		const uint64_t *v = emul::wave_gather(x, &m, emul::SITE_READLANE);
+		return (uint32_t)v[lane & 63u]; /* (an inactive lane's register is whatever it was; the kernels never ask for one) */
+	}
 	return x; /* the only active lane is the caller */
-}
-static inline int __all(int p)
-{
-	return p != 0;
 }
 static inline uint64_t __ballot(int p)
 {
+	if (emul::wave64()) {
+		uint64_t m, r = 0;
+		const uint64_t *v = emul::wave_gather(p != 0, &m, emul::SITE_BALLOT);
+		for (unsigned l = 0; l < 64; l++)
+			if (((m >> l) & 1u) && v[l])
+				r |= 1ull << l;
+		return r;
+	}
 	return p ? (1ull << (threadIdx.x & 63u)) : 0ull;
+}
+static inline int __all(int p)
+{
+	if (emul::wave64())
+		return __ballot(!p) == 0;
+	return p != 0;
 }
 static inline int __ffsll(long long v)
 {
@@ -177,7 +197,13 @@ static inline int __ffsll(long long v)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0) /* issue priority: nothing to emulate */
 #define __builtin_amdgcn_fence(order, scope) ((void)0) /* one-lane waves run to completion between yields: nothing to order */
-#define __builtin_amdgcn_wave_barrier() ((void)0)
+static inline void __builtin_amdgcn_wave_barrier()
+{
+	if (emul::wave64()) { /* lock step: what the lanes stored before this point is there for every lane behind it */
+		uint64_t m;
+		(void)emul::wave_gather(0, &m, emul::SITE_BARRIER);
+	}
+}
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 static inline void __threadfence()
 {

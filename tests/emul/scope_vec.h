@@ -102,13 +102,22 @@ template <unsigned TT> static inline unsigned scope_bitop3(unsigned a, unsigned 
 	return out;
 }
 
-/* the emulated wave has one lane = one DPP row of its own: there is no lane below, and no bit of a ballot belongs to one */
-static inline unsigned scope_lane_below(unsigned, unsigned fill)
+/* one-lane waves: a lane is a DPP row of its own -- there is no lane below, and no bit of a ballot belongs to one.
+ * SCOPE_EMUL_WAVE64: row_shr:1 within rows of 16 lanes (bound_ctrl off: the first lane of a row keeps `fill`), v_mbcnt. */
+static inline unsigned scope_lane_below(unsigned x, unsigned fill)
 {
+	if (emul::wave64()) {
+		uint64_t m;
+		const unsigned lane = threadIdx.x & 63u;
+		const uint64_t *v = emul::wave_gather(x, &m, emul::SITE_BELOW);
+		return (lane & 15u) == 0u || !((m >> (lane - 1u)) & 1u) ? fill : (unsigned)v[lane - 1u];
+	}
 	return fill;
 }
-static inline unsigned scope_lanes_below(unsigned long long)
+static inline unsigned scope_lanes_below(unsigned long long mask)
 {
+	if (emul::wave64())
+		return (unsigned)__builtin_popcountll(mask & ((1ull << (threadIdx.x & 63u)) - 1ull));
 	return 0;
 }
 /* the emulated wave has one lane = one DPP row of its own */
@@ -195,5 +204,14 @@ static inline int scope_pin_vgpr(int uniform)
 
 static inline unsigned scope_wave_sum(unsigned x)
 {
+	if (emul::wave64()) {
+		uint64_t m;
+		unsigned sum = 0;
+		const uint64_t *v = emul::wave_gather(x, &m, emul::SITE_SUM);
+		for (unsigned l = 0; l < 64; l++)
+			if ((m >> l) & 1u)
+				sum += (unsigned)v[l];
+		return sum;
+	}
 	return x;
 }
