@@ -4,6 +4,9 @@
 # without its run-length mode on the SAME frames (noise, natural, concentrated, padded pitch); the waveform kernel's one-channel
 # forms against its RGB form under the SQ counters; the one-frame vectorscope launch's per-workgroup time stamps.
 #   bash tools/visit_a5.sh <tag>      (from the repo root; results under gpurun_out/<tag>/)
+# Variant libraries this visit compared (not kept in the tree; from obs-color-monitor_amd/csrc at round 4's kernel sources):
+#   for e in 1 2 4 8 3; do make trio_variant VARIANT_FLAGS=-DTRIO_EXP=$e VARIANT_TAG=exp$e; done
+#   make variant VARIANT_FLAGS=-DVSS_RLE=0 VARIANT_OUT=../../tools/_lib_vss_norle.so;  make trace;  make trio_variant VARIANT_FLAGS=-DTRIO_TRACE VARIANT_TAG=trace
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 tag=${1:-a5}
 out=gpurun_out/$tag; mkdir -p $out

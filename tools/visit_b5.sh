@@ -3,6 +3,10 @@
 # form on the SAME frames; the three-scope kernel with another vectorscope table pitch and deeper load queues; the waveform's
 # one-channel mode paced (s_sleep) -- is it the burstiness of its loads?; the one-frame launch's per-workgroup time stamps.
 #   bash tools/visit_b5.sh <tag>
+# Variant libraries this visit compared (not kept in the tree; from obs-color-monitor_amd/csrc):
+#   make variant VARIANT_FLAGS=-DSCOPE_ROWS=0 VARIANT_OUT=../../tools/_lib_norows.so
+#   make trio_variant VARIANT_FLAGS=-DVSS3_PITCH=116u VARIANT_TAG=head   (the default was 116 then; p122: -DVSS3_PITCH=122u; d9 / d12: -DTRIO_D=9 / 12)
+#   _lib_pace1 / _lib_pace3: scope_kernels.hip with an s_sleep(1 / 3) behind every slot pair of a one-channel waveform unit (the macro is gone again)
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 tag=${1:-b5}
 out=gpurun_out/$tag; mkdir -p $out

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 5, fourth visit: the three-scope kernel's lazy absorb form against round 4's eager one -- parity first (the GPU suite's
 # three-scope tests, a fuzz seed), then the same-process A/B on every content, then the SQ counters on screen content.
+# The eager library: round 4's absorb form = the tree's; the library under test was the tree with profiles/round5/dropped_lazy_absorb.diff applied
+# (this script ran with the lazy form as libscope_hip.so and `make trio_variant VARIANT_FLAGS=-DTRIO_LAZY=0 VARIANT_TAG=eager` beside it).
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 tag=${1:-d5}
 out=gpurun_out/$tag; mkdir -p $out
