@@ -351,7 +351,13 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	u32 lane_u = 0xffffffffu, lane_v = 0xffffffffu; /* pair form: the lane's colour (vss_absorb_pair) */
 	(void)lane_u;
 	(void)lane_v;
-	bool absorb = false, wflat = false; /* wave-uniform */
+#ifndef TRIO_SCALAR_VERDICT
+#define TRIO_SCALAR_VERDICT 1 /* 0: the vote's verdict as a bool (round 4; A/B) */
+#endif
+	/* wave-uniform, and kept in a scalar register (readfirstlane): a bool carried round the loop becomes a lane mask and every
+	 * `if (absorb)` an exec-mask dance of six scalar instructions and two branches per slot (as in vss_region) */
+	u32 absorb = 0;
+	bool wflat = false;
 	const u32 wave_w = (u32)__popcll(__ballot(true)); /* 64; one on the CPU emulation (tests/emul), whose votes are a lane's own */
 	u32 wp0 = 0, wp1 = 0, wn = 0; /* the waveform's pending texel pair and how often it came (absorb mode) */
 	u32 since = 0;       /* texels the vectorscope table may have taken since its last clamp pass (uniform) */
@@ -454,13 +460,14 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 					const bool same = TRIO_PAIR ? ((pu[0] == scope_perm(0u, pu[0], 0x01000302u)) & (pv[0] == scope_perm(0u, pv[0], 0x01000302u)))
 									 : key[0] == key[1];
 					const u32 flat_lanes = (u32)__popcll(__ballot(!v || same));
-					absorb = flat_lanes * 4u >= wave_w * 3u; /* three quarters of the wave: 48 lanes */
+					absorb = TRIO_SCALAR_VERDICT ? (u32)__builtin_amdgcn_readfirstlane((int)(flat_lanes * 4u >= wave_w * 3u))
+								     : (u32)(flat_lanes * 4u >= wave_w * 3u); /* three quarters of the wave: 48 lanes */
 					wflat = flat_lanes >= wave_w;
 				}
 				if (!v || (TRIO_EXP & 2))
 					return;
 				if (TRIO_PAIR) {
-					if (absorb)
+					if (TRIO_SCALAR_VERDICT ? __builtin_amdgcn_readfirstlane((int)absorb) != 0 : absorb != 0)
 						vss_absorb_pair<TRIO_HASH>(tab, st, lane_u, lane_v, pu[0], pv[0]);
 					else
 						vss_add_pair<TRIO_HASH>(tab, pu[0], pv[0]);
