@@ -91,7 +91,8 @@ def test_bench_shapes_64x4k_padded_pitch(hip_ctx, oracle, pool64):
     """bench.py's padded-pitch leg at its real size (linesize = 4 W + 256, src/vectorscope.c:225,236): the
     same 64 frames behind a pitch, so the tables must be the ones of the packed planes -- the staged and the fused vectorscope
     (scope_stream's ROWS form: 2160 rows in 32 lane-group shares of 67 and 68) and the histogram, all 64 tables each; then one
-    frame per call and the ring of three, which keep the general form (8.4 rows per workgroup are no whole-row shares)."""
+    frame per call and the ring of three, which keep the general form (8.4 rows per workgroup are no whole-row shares), and
+    launches of 16 and 24 frames (other slice counts of the ROWS form)."""
     import torch
 
     from obs_color_monitor_amd.synth import pad_pitch
@@ -108,7 +109,7 @@ def test_bench_shapes_64x4k_padded_pitch(hip_ctx, oracle, pool64):
         hip_ctx.vectorscope_batch_dev(b, out, sync=False)
         hip_ctx.sync()
         _all_frames(out.cpu().numpy(), lambda f: want[f], f"vectorscope x64, pitch {ls}, {'SCOPE_FUSE_K0' if is_rgb else 'staged planes'}")
-        for nf in (1, 3):
+        for nf in (1, 3, 16, 24):  # 16 / 24 frames: 16 / 10 slices per frame, lane-group shares of 16-17 / 27 rows (ROWS form)
             b = hip_ctx.make_device_batch(padded[:nf], ls, W, H, planes_are_rgb=is_rgb, colorspace=2)
             out[:nf].fill_(0xEE)
             torch.cuda.synchronize()
