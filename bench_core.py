@@ -6,6 +6,7 @@ Nothing here is the product; nothing here calls the oracle except Workload.check
 import hashlib
 import json
 import os
+import tempfile
 import sys
 import time
 
@@ -491,11 +492,20 @@ def compact_line(result, detail=None):
 def write_detail(result, path=None):
     """Everything the legs measured (variants, latency, distributions, stream, config 1 / 4, the prose) as one JSON file beside
     bench.py, and its name for the line.  A directory that cannot be written costs the detail, not the line."""
-    path = path or os.environ.get("BENCH_DETAIL") or os.path.join(ROOT, DETAIL_FILE)
+    path = path or os.environ.get("BENCH_DETAIL")
+    if not path:
+        # an EMULATION run (tests, experiments on the CPU) never takes the name a real run's line points at
+        emul = "EMULATION" in str((result.get("config") or {}).get("backend", ""))
+        path = os.path.join(tempfile.gettempdir(), f"bench_detail_emul_{os.getpid()}.json") if emul else os.path.join(ROOT, DETAIL_FILE)
     try:
-        with open(path, "w") as fh:
+        # written beside and moved into place: a reader (or a second run with the same name) never sees half a file; the file
+        # carries the line's own value / ms_per_step / fingerprint at its top level, so a line and a detail file that are not of
+        # one run can be told apart
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as fh:
             json.dump(result, fh, indent=1)
             fh.write("\n")
+        os.replace(tmp, path)
         return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
     except OSError as e:
         log(f"bench.py: detail file {path} not written ({e})")

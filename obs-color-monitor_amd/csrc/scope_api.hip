@@ -549,7 +549,7 @@ int run_dock(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t 
 							    ctx->stream, tm_));
 		} else {
 			TIMED_LAUNCH(ctx, scope_launch_trio(fs, slices, sw, cw, colorspace, wvs_dst, his_dst ? &sink : NULL,
-							    slices > 1 ? ctx->partial : vss_dst, ctx->pmask, ctx->stream, tm_));
+							    slices > 1 ? ctx->partial : vss_dst, ctx->pmask, ctx->stream, tm_, (uint32_t)ctx->tn.vss_rle));
 		}
 		if (partials)
 			HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, vss_dst, nf, slices, mask_block, 0, ctx->stream));

@@ -69,7 +69,8 @@ struct ScopeTuning {
 	int wvs_strip;       /* 0: 16-column strips for launches that would otherwise need row bands, 64 elsewhere; 64 / 16: always */
 	int nt_loads;        /* 1: non-temporal pixel loads */
 	int trio_strip;      /* scope_trio_kernel's strip width: 0 = 32 columns for batches, 16 for small launches; 16 / 32: always */
-	int vss_rle;         /* the fused-K0 vectorscope under vss_merge 3: 0 = run-length mode by wave vote, 1 = always (tests) */
+	int vss_rle;         /* the fused-K0 vectorscope under vss_merge 3, and scope_trio_kernel's vectorscope half: 0 = run-length mode by wave
+			      * vote, 1 = always (tests) */
 };
 
 /* Optional last argument of the accumulation launchers: two HIP events that receive the kernel's own begin and end time
@@ -153,7 +154,7 @@ uint32_t scope_trio_strip_width(const ScopeFrameSet &fs, uint32_t num_cu, const 
 uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu, uint32_t strip_width);
 hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t strip_width, uint32_t chmask, int colorspace,
 			     uint8_t *wvs_dst, const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st,
-			     const ScopeTiming *tm = NULL);
+			     const ScopeTiming *tm = NULL, uint32_t rle_force = 0 /* the vectorscope's run-length form on every slot (tests) */);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
  * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */

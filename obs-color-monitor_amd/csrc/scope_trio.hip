@@ -79,6 +79,33 @@
 #ifndef TRIO_EXP
 #define TRIO_EXP 0 /* measurement only (wrong tables): bit 0 no waveform adds, 1 no vectorscope adds, 2 no K0, 3 no clamp pass */
 #endif
+#ifndef TRIO_RLE
+#define TRIO_RLE 1 /* round 6: the vectorscope's run-length form (trio_rle_pair below) where the vote finds flat content; 0: the per-lane
+		    * absorb mode alone (rounds 3-5; A/B) */
+#endif
+#ifndef TRIO_RLE_HI
+#define TRIO_RLE_HI 64u /* only with TRIO_ABSORB 1: flat lanes of 64 at the vote from which the per-lane absorb mode runs instead of the
+			 * run-length form (64 = where the WHOLE wave is flat; 65 = never) */
+#endif
+#ifndef TRIO_ABSORB
+#define TRIO_ABSORB 1 /* the per-lane absorb mode: 1 = on one state register (trio_absorb_pair; with TRIO_RLE only where the vote finds the
+		       * whole wave flat, TRIO_RLE_HI), 4 = rounds 3-5's four-register form (A/B), 0 = none (the run-length form takes all
+		       * flat content; A/B) */
+#endif
+#define TRIO_MODE_ABSORB 1u
+#define TRIO_MODE_RLE 2u
+#define TRIO_MODE_RLE_WHOLE 6u /* TRIO_MODE_RLE | 4: with the whole-wave question */
+#ifndef TRIO_RLE_LO
+#define TRIO_RLE_LO 48u /* flat lanes of 64 at the vote from which a wave leaves the plain adds (three quarters: rounds 3-5's absorb threshold) */
+#endif
+#ifndef TRIO_RLE_WHOLE
+#define TRIO_RLE_WHOLE (!TRIO_ABSORB) /* the run-length form's whole-wave shortcut (trio_rle_pair): what stands in for the absorb mode where
+					* that is compiled out (A/B: flat frames 13 % behind the absorb mode, visit d6) */
+#endif
+#ifndef TRIO_RLE_FASTONLY
+#define TRIO_RLE_FASTONLY 0 /* 1: only the branch-free slot form carries the run-length form (the checked slots -- two of 36 per 4K strip -- keep
+			      * the absorb mode): less code (A/B) */
+#endif
 #ifndef TRIO_COMPACT
 #define TRIO_COMPACT 1 /* round 4: the LDS map below.  0: round 3's map (A/B: `make trio_variant VARIANT_FLAGS=-DTRIO_COMPACT=0`) */
 #endif
@@ -201,9 +228,116 @@ template <int CH, u32 VS> __device__ __forceinline__ void trio_count2(u32 *tab, 
 	}
 }
 
+/* ---- the per-lane absorb mode on ONE state register (round 6) -----------------------------------------------------------------
+ * Rounds 3-5 carried the mode's state in four registers (colour key, count, the colour as U | U << 16 and V | V << 16), and the
+ * compiler copied all four at every join of a slot's paths: four v_mov per slot on the path NOISE takes, twelve once the
+ * run-length form added a third way through the slot (visit a6: -6 % on noise).  Here the state is S = count | U << 16 | V << 24
+ * (a lane's count stays below 65 281, an epoch's texels); what the compare needs is two byte permutes away.  The mode runs only
+ * where the vote found the WHOLE wave flat (flat frames, the inside of large areas: a lane's colour then rarely changes and a
+ * slot costs six instructions and no LDS operation); everything between that and noise is the run-length form's. */
+template <int HASH> __device__ __forceinline__ void trio_absorb_flush(u32 *tab, u32 &S)
+{
+	/* every lane of the wave (uniform control flow); one colour throughout the wave: one lane adds the wave's total */
+	const u32 n = S & 0xffffu;
+	const u64 pending = __ballot(n != 0);
+	if (pending == 0)
+		return;
+	const u32 leader = (u32)(__ffsll((long long)pending) - 1);
+	const u32 colour = __builtin_amdgcn_readlane(S >> 16, leader);
+	if (__all(n == 0 || (S >> 16) == colour)) {
+		const u32 total = scope_wave_sum(n);
+		if ((threadIdx.x & 63u) == leader)
+			vss_add<HASH>(tab, colour << 8, total); /* key = U << 8 | V << 16 */
+	} else if (n) {
+		vss_add<HASH>(tab, (S >> 16) << 8, n);
+	}
+	S &= 0xffff0000u;
+}
+template <int HASH> __device__ __forceinline__ void trio_absorb_pair(u32 *tab, u32 &S, u32 pu, u32 pv)
+{
+	constexpr u32 pitch = VssTable<HASH>::pitch, bias = VssTable<HASH>::bias;
+	/* x = 0 in the half whose texel has the lane's colour (S = 0, no colour yet: no pair has U = V = 0) */
+	u32 x = scope_bitop3<0xf6>(pu ^ scope_perm(0u, S, 0x0c020c02u), pv, scope_perm(0u, S, 0x0c030c03u));
+	if (x == 0u) {
+		S += 2u;
+		return;
+	}
+	bool e0 = (x & 0xffffu) == 0u, e1 = (x >> 16) == 0u;
+	if (!(e0 | e1)) { /* the colour changed: the old count goes to the table, texel 0's colour is the lane's */
+		if (S & 0xffffu)
+			vss_add<HASH>(tab, (S >> 16) << 8, S & 0xffffu);
+		S = scope_perm(pv, pu, 0x04000c0cu);
+		x = scope_bitop3<0xf6>(pu ^ scope_perm(0u, S, 0x0c020c02u), pv, scope_perm(0u, S, 0x0c030c03u));
+		e0 = true;
+		e1 = (x >> 16) == 0u;
+	}
+	S += (u32)e0 + (u32)e1;
+	if (!(e0 & e1)) {
+		const u32 w = scope_pk_mad_u16(pv, pitch | (pitch << 16), scope_pk_lshr_u16(pu, 1)), q = pu << 4;
+		if (!e0)
+			scope_lds_add_at(tab, scope_shl_word0(2u, w) + bias, scope_shl_by_byte0(q, 1u));
+		if (!e1)
+			scope_lds_add_at(tab, scope_shl_word1(2u, w) + bias, scope_shl_by_byte2(q, 1u));
+	}
+}
+
+/* ---- the vectorscope's run-length form (round 6) --------------------------------------------------------------------
+ * Screen capture -- flat rectangles with a little single-texel detail -- was this kernel's worst content: 38 VALU instructions per
+ * texel against 26 on noise (profiles/round5/pmc_sq_three_scope_x64_screen_*.txt).  The per-lane absorb mode keeps (colour, count)
+ * per LANE, and a lane's consecutive slots lie sixteen image rows apart: when a row of the picture crosses a rectangle's edge all
+ * sixteen lanes of the row segment change colour in the same slot and hand the same old colour in (16- to 64-way same-address
+ * atomics), and every wave holds a lane that meets detail in almost every slot, so the wave runs the register path, the colour
+ * change AND the table path.  What is coherent is the row segment ACROSS lanes: the sixteen lanes of a DPP row hold 32 adjacent
+ * texels (32-column strips; with 16-column strips two segments of eight lanes, rows H / 8 apart -- equal keys merge all the same:
+ * the form needs equal bins, not neighbours).  So, with no per-lane state (scope_vss_kernel's keys_rle after K0):
+ *   - a pair is FLAT when its two texels have one chroma; a flat pair whose key equals the key of the flat pair in the lane below
+ *     (one DPP move and a compare; the first lane of a DPP row has no lane below) adds nothing;
+ *   - the HEAD of a run adds 2 x the run's length, read off the ballot of the continuing lanes (a 64-bit shift and a find-first-bit:
+ *     the next lane that continues nothing ends the run; a run ends with its DPP row);
+ *   - a pair that is not flat adds its two texels as the plain form does.
+ * Heads and rough pairs share ONE address computation (vss_add_pair's) and the first ds_add; only the second texel of a rough pair
+ * is a second, exec-masked add.  19 VALU instructions per slot whatever the content (plain adds: 7), one LDS atomic per run.
+ * Every texel is counted once in the bin K0 gave it: exact.  `v`: the lane holds a real texel pair (lanes that do not break every
+ * run and add nothing); every lane of the wave must be active. */
+template <int HASH, bool ALLV> __device__ __forceinline__ void trio_rle_pair(u32 *tab, u32 pu, u32 pv, bool v, u32 lane, u32 wave_w, bool whole)
+{
+	constexpr u32 pitch = VssTable<HASH>::pitch, bias = VssTable<HASH>::bias;
+	/* the pair's two colours as 16-bit halves (U | V << 8 each): flat <=> the halves agree, and a flat pair's word is its tag --
+	 * never zero (U >= 15) and never a lane's own tag, whose halves differ (0x4000 and the lane) */
+	const u32 c = pu | (pv << 8);
+	if (ALLV && TRIO_RLE_WHOLE && whole) {
+		/* The whole wave ONE colour (a flat frame, the inside of a rectangle, letterbox bars)?  Then its first lane adds the wave's
+		 * 2 x 64 texels and nobody else does anything: the question is one readfirstlane and one compare, the bin's address is
+		 * worked out on the scalar side.  (What the per-lane absorb mode of rounds 3-5 was for -- without its four state registers,
+		 * whose copies at every join of the slot cost the path NOISE takes four to twelve v_mov per slot.)  Asked only where the
+		 * last vote found EVERY lane of the wave flat (`whole`, wave-uniform): in front of every slot the question's chain of
+		 * scalar and vector steps cost screen content 8 % (visit c6), where it is almost never answered with yes. */
+		const u32 c0 = scope_first_lane(c);
+		if (((c0 ^ (c0 >> 16)) & 0xffffu) == 0u && __all(c == c0)) {
+			if (scope_lanes_below(__ballot(true)) == 0u)
+				vss_add<HASH>(tab, (c0 & 0xffffu) << 8, 2u * wave_w); /* key = U << 8 | V << 16 */
+			return;
+		}
+	}
+	const bool same = v & ((c & 0xffffu) == (c >> 16));
+	const u32 tag = same ? c : (0x40000000u | lane);
+	const bool cont = tag == scope_lane_below0(tag); /* the first lane of a DPP row reads zero: it continues nothing */
+	const u64 breaks = ~__ballot(cont); /* the lanes that continue nothing, and the lanes there are none of */
+	if (v && !cont) {
+		/* bit i of `above`: lane + 1 + i continues nothing.  A run ends within its sixteen lanes (the next DPP row's first lane, or
+		 * the sentinel behind lane 63), so the low half always holds a bit */
+		const u64 above = ((breaks >> 1) | (1ull << 63)) >> lane;
+		const u32 n0 = same ? 2u * (u32)__builtin_ctz((u32)above) + 2u : 1u;
+		const u32 w = scope_pk_mad_u16(pv, pitch | (pitch << 16), scope_pk_lshr_u16(pu, 1)), q = pu << 4;
+		scope_lds_add_at(tab, scope_shl_word0(2u, w) + bias, scope_shl_by_byte0(q, n0));
+		if (!same)
+			scope_lds_add_at(tab, scope_shl_word1(2u, w) + bias, scope_shl_by_byte2(q, 1u));
+	}
+}
+
 template <int CH, bool HIS, int SW>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet fs, u32 strips, u32 slices, ScopeK0 k0_arg,
-								uint8_t *wvs_dst, ScopeWvsHis his, uint8_t *vss_dst, uint8_t *vss_mask)
+								uint8_t *wvs_dst, ScopeWvsHis his, uint8_t *vss_dst, uint8_t *vss_mask, u32 rle_force)
 {
 	const ScopeK0 k0 = scope_k0_pinned(k0_arg, true, false);
 	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1), nch = slot2 + ((CH >> 2) & 1);
@@ -348,15 +482,18 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 	__syncthreads();
 
 	VssLane st = {0xffffffffu, 0};
-	u32 lane_u = 0xffffffffu, lane_v = 0xffffffffu; /* pair form: the lane's colour (vss_absorb_pair) */
+	u32 lane_u = 0xffffffffu, lane_v = 0xffffffffu; /* TRIO_ABSORB 4: the lane's colour (vss_absorb_pair) */
+	u32 S = 0; /* TRIO_ABSORB 1: the absorb mode's state in one register (trio_absorb_pair) */
 	(void)lane_u;
 	(void)lane_v;
+	(void)S;
 #ifndef TRIO_SCALAR_VERDICT
 #define TRIO_SCALAR_VERDICT 1 /* 0: the vote's verdict as a bool (round 4; A/B) */
 #endif
 	/* wave-uniform, and kept in a scalar register (readfirstlane): a bool carried round the loop becomes a lane mask and every
 	 * `if (absorb)` an exec-mask dance of six scalar instructions and two branches per slot (as in vss_region) */
 	u32 absorb = 0;
+	u32 mode = rle_force ? TRIO_MODE_RLE : 0u; /* the pair form's mode (wave-uniform): the vote's, or the run-length form forced (tests) */
 	bool wflat = false;
 	const u32 wave_w = (u32)__popcll(__ballot(true)); /* 64; one on the CPU emulation (tests/emul), whose votes are a lane's own */
 	u32 wp0 = 0, wp1 = 0, wn = 0; /* the waveform's pending texel pair and how often it came (absorb mode) */
@@ -389,7 +526,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 			 * not 59 (a pass reads the whole 128 KiB table: 5 % of the kernel when taken once per strip) */
 			if (since + round_px > VSS_EPOCH_PIXELS && !(TRIO_EXP & 8)) { /* uniform across the workgroup */
 				TRIO_T(tc0);
-				vss_flush_lane<TRIO_HASH>(tab, st); /* pending texels belong to the epoch that ends here */
+				if (TRIO_PAIR && TRIO_ABSORB == 1)
+					trio_absorb_flush<TRIO_HASH>(tab, S); /* pending texels belong to the epoch that ends here */
+				else
+					vss_flush_lane<TRIO_HASH>(tab, st);
 				__syncthreads();
 				vss_clamp_pass(vt, TRIO_VSS_WORDS);
 				__syncthreads();
@@ -460,35 +600,62 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 					const bool same = TRIO_PAIR ? ((pu[0] == scope_perm(0u, pu[0], 0x01000302u)) & (pv[0] == scope_perm(0u, pv[0], 0x01000302u)))
 									 : key[0] == key[1];
 					const u32 flat_lanes = (u32)__popcll(__ballot(!v || same));
-					absorb = TRIO_SCALAR_VERDICT ? (u32)__builtin_amdgcn_readfirstlane((int)(flat_lanes * 4u >= wave_w * 3u))
-								     : (u32)(flat_lanes * 4u >= wave_w * 3u); /* three quarters of the wave: 48 lanes */
+					absorb = TRIO_SCALAR_VERDICT ? (u32)__builtin_amdgcn_readfirstlane((int)(flat_lanes * 64u >= wave_w * TRIO_RLE_LO))
+								     : (u32)(flat_lanes * 64u >= wave_w * TRIO_RLE_LO); /* three quarters of the wave: 48 lanes */
 					wflat = flat_lanes >= wave_w;
-				}
-				if (!v || (TRIO_EXP & 2))
-					return;
-				if (TRIO_PAIR) {
-					if (TRIO_SCALAR_VERDICT ? __builtin_amdgcn_readfirstlane((int)absorb) != 0 : absorb != 0)
-						vss_absorb_pair<TRIO_HASH>(tab, st, lane_u, lane_v, pu[0], pv[0]);
-					else
-						vss_add_pair<TRIO_HASH>(tab, pu[0], pv[0]);
-				} else if (absorb) {
-					bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
-					if (!(e0 | e1)) {
-						if (st.count)
-							vss_add<TRIO_HASH>(tab, st.colour, st.count);
-						st.colour = key[0];
-						st.count = 0;
-						e0 = true;
-						e1 = key[1] == key[0];
+					/* ONE mode word for the pair form (noise asks ONE question per slot): 0 plain adds; TRIO_MODE_ABSORB the per-lane
+					 * absorb mode -- where the WHOLE wave is flat (TRIO_RLE_HI; a one-lane wave of the CPU emulation always is); from
+					 * three quarters of the wave up to that the run-length form, with its whole-wave question behind an all-flat vote */
+					if (TRIO_PAIR) {
+						const bool flat_enough = flat_lanes * 64u >= wave_w * TRIO_RLE_LO;
+						const bool to_absorb = TRIO_ABSORB && (!TRIO_RLE || flat_lanes * 64u >= TRIO_RLE_HI * wave_w);
+						mode = (u32)__builtin_amdgcn_readfirstlane((int)((TRIO_RLE && rle_force != 0) ? TRIO_MODE_RLE
+												 : !flat_enough	      ? 0u
+												 : to_absorb	      ? TRIO_MODE_ABSORB
+												 : !TRIO_RLE	      ? 0u
+												 : wflat	      ? TRIO_MODE_RLE_WHOLE
+														      : TRIO_MODE_RLE));
 					}
-					st.count += (u32)e0 + (u32)e1;
-					if (!e0)
+				}
+				/* ONE structured exit from here on (no early return): with several ways out the compiler copied the absorb mode's
+				 * state registers at every join -- sixteen v_mov per slot on the path noise takes, 6 % of the kernel (visit a6) */
+				if (TRIO_PAIR) {
+					const u32 m = (u32)__builtin_amdgcn_readfirstlane((int)mode);
+					if (__builtin_expect(m != 0u, 0)) { /* unlikely: laid out behind the loop */
+						if (TRIO_EXP & 2) {
+						} else if (TRIO_RLE && (m & TRIO_MODE_RLE) && (FAST || !TRIO_RLE_FASTONLY)) {
+							trio_rle_pair<TRIO_HASH, FAST>(tab, pu[0], pv[0], v, lane, wave_w, m == TRIO_MODE_RLE_WHOLE); /* every lane goes through */
+						} else if (v) {
+							if (TRIO_ABSORB == 1)
+								trio_absorb_pair<TRIO_HASH>(tab, S, pu[0], pv[0]);
+							else if (TRIO_ABSORB)
+								vss_absorb_pair<TRIO_HASH>(tab, st, lane_u, lane_v, pu[0], pv[0]);
+							else
+								vss_add_pair<TRIO_HASH>(tab, pu[0], pv[0]); /* (a checked slot under TRIO_RLE_FASTONLY) */
+						}
+					} else if (v && !(TRIO_EXP & 2)) {
+						vss_add_pair<TRIO_HASH>(tab, pu[0], pv[0]);
+					}
+				} else if (v && !(TRIO_EXP & 2)) {
+					if (absorb) { /* the key forms (TRIO_COMPACT 0; A/B) */
+						bool e0 = key[0] == st.colour, e1 = key[1] == st.colour;
+						if (!(e0 | e1)) {
+							if (st.count)
+								vss_add<TRIO_HASH>(tab, st.colour, st.count);
+							st.colour = key[0];
+							st.count = 0;
+							e0 = true;
+							e1 = key[1] == key[0];
+						}
+						st.count += (u32)e0 + (u32)e1;
+						if (!e0)
+							vss_add<TRIO_HASH>(tab, key[0], 1);
+						if (!e1)
+							vss_add<TRIO_HASH>(tab, key[1], 1);
+					} else {
 						vss_add<TRIO_HASH>(tab, key[0], 1);
-					if (!e1)
 						vss_add<TRIO_HASH>(tab, key[1], 1);
-				} else {
-					vss_add<TRIO_HASH>(tab, key[0], 1);
-					vss_add<TRIO_HASH>(tab, key[1], 1);
+					}
 				}
 			};
 #pragma unroll
@@ -510,7 +677,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		}
 		const bool last_strip = s_b + 1u == nst;
 		if (last_strip)
-			vss_flush_lane<TRIO_HASH>(tab, st); /* the lanes' pending texels, before the table is read out */
+			(TRIO_PAIR && TRIO_ABSORB == 1) ? trio_absorb_flush<TRIO_HASH>(tab, S) : vss_flush_lane<TRIO_HASH>(tab, st); /* the lanes' pending texels, before the table is read out */
 		TRIO_T(tb0);
 		__syncthreads();
 		TRIO_T(tb1);
@@ -669,6 +836,7 @@ struct TrioArgs {
 	uint8_t *wvs_dst;
 	ScopeWvsHis his;
 	uint8_t *vss_dst, *vss_mask;
+	u32 rle_force;
 	hipStream_t st;
 	const ScopeTiming *tm;
 };
@@ -680,7 +848,7 @@ template <int CH, bool HIS, int SW> hipError_t trio_variant(const TrioArgs *a)
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_trio_kernel<CH, HIS, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	SCOPE_LAUNCH((scope_trio_kernel<CH, HIS, SW>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), lds, a->st, a->tm, *a->fs,
-		     a->strips, a->slices, a->k0, a->wvs_dst, a->his, a->vss_dst, a->vss_mask);
+		     a->strips, a->slices, a->k0, a->wvs_dst, a->his, a->vss_dst, a->vss_mask, a->rle_force);
 	return hipGetLastError();
 }
 template <bool HIS, int SW> hipError_t trio_pick_ch(u32 chmask, const TrioArgs *a)
@@ -785,7 +953,7 @@ uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu, uint32_t st
 
 hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t strip_width, uint32_t chmask, int colorspace,
 			     uint8_t *wvs_dst, const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st,
-			     const ScopeTiming *tm)
+			     const ScopeTiming *tm, uint32_t rle_force)
 {
 	if ((chmask & 7u) == 0 || slices == 0 || slices > 256u || (slices > 1 && !vss_mask) || (strip_width != 16u && strip_width != 32u))
 		return hipErrorInvalidValue;
@@ -795,6 +963,6 @@ hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t 
 	if (his)
 		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
 	const TrioArgs a = {&fs, (fs.width + strip_width - 1u) / strip_width, slices, scope_k0_matrix(colorspace), wvs_dst, h, vss_dst,
-			    slices > 1 ? vss_mask : NULL, st, tm};
+			    slices > 1 ? vss_mask : NULL, rle_force, st, tm};
 	return his ? trio_pick_sw<true>(strip_width, chmask, &a) : trio_pick_sw<false>(strip_width, chmask, &a);
 }

@@ -246,6 +246,17 @@ __device__ __forceinline__ unsigned scope_lane_below(unsigned x, unsigned fill)
 {
 	return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x111, 0xf, 0xf, false);
 }
+/* The same with zero for the first lane of a row, in the form the compiler can fold into the instruction that uses the value
+ * (bound_ctrl on: no `old` operand to initialise). */
+__device__ __forceinline__ unsigned scope_lane_below0(unsigned x)
+{
+	return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+}
+/* The value of the wave's first active lane, for a value that is not wave-uniform yet (v_readfirstlane_b32). */
+__device__ __forceinline__ unsigned scope_first_lane(unsigned x)
+{
+	return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+}
 /* How many bits of `mask` belong to lanes below this one (v_mbcnt_lo / v_mbcnt_hi). */
 __device__ __forceinline__ unsigned scope_lanes_below(unsigned long long mask)
 {

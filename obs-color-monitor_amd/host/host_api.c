@@ -5,21 +5,26 @@
  * (src/vectorscope.c:410-412, src/waveform.c:399, src/histogram.c:563).
  */
 #include "scope_sources.h"
+#include <string.h>
 
 struct cm_source *scope_host_cm(void *source)
 {
 	return (struct cm_source *)source; /* every source starts with its struct cm_source */
 }
 
+/* The pointer forms hand out tex_buf[r] itself: legal only while the source is QUIET (after cm_drain with nothing staged since, or
+ * with its threads stopped) -- two flips later the worker writes that buffer again and ensure_tex_buf_size may free it.  The
+ * metadata is read under the same lock as the index.  A host that reads while frames flow takes the *_copy forms below. */
 const uint8_t *scope_host_vss_table(void *data, int *colorspace)
 {
 	struct vss_source *src = data;
 	pthread_mutex_lock(&src->tex_mutex);
 	const int r = src->w_tex_buf ^ 1;
-	pthread_mutex_unlock(&src->tex_mutex);
+	const uint8_t *t = src->tex_buf[r];
 	if (colorspace)
 		*colorspace = src->tex_cs[r];
-	return src->tex_buf[r];
+	pthread_mutex_unlock(&src->tex_mutex);
+	return t;
 }
 
 const uint8_t *scope_host_wvs_table(void *data, uint32_t *width)
@@ -27,10 +32,11 @@ const uint8_t *scope_host_wvs_table(void *data, uint32_t *width)
 	struct wvs_source *src = data;
 	pthread_mutex_lock(&src->tex_mutex);
 	const int r = src->w_tex_buf ^ 1;
-	pthread_mutex_unlock(&src->tex_mutex);
+	const uint8_t *t = src->tex_buf[r];
 	if (width)
 		*width = src->tex_buf_width[r];
-	return src->tex_buf[r];
+	pthread_mutex_unlock(&src->tex_mutex);
+	return t;
 }
 
 const float *scope_host_his_table(void *data, uint32_t *hi_max)
@@ -38,11 +44,66 @@ const float *scope_host_his_table(void *data, uint32_t *hi_max)
 	struct his_source *src = data;
 	pthread_mutex_lock(&src->tex_mutex);
 	const int r = src->w_tex_buf ^ 1;
-	pthread_mutex_unlock(&src->tex_mutex);
+	const float *t = (const float *)src->tex_buf[r];
 	if (hi_max)
 		for (int i = 0; i < 3; i++)
 			hi_max[i] = src->hi_max[r][i];
-	return (const float *)src->tex_buf[r];
+	pthread_mutex_unlock(&src->tex_mutex);
+	return t;
+}
+
+/* The same tables COPIED OUT under the source's tex_mutex -- the section the render side holds while it reads tex_buf[w_tex_buf ^ 1]
+ * (scope_sources.h: the worker flips only under it, so the buffer cannot be rewritten or freed while the copy runs).  Safe with
+ * frames in flight.  Return the bytes copied; 0 when there is no table yet or `cap` is too small (nothing written then, *width
+ * still says what is needed). */
+size_t scope_host_vss_copy(void *data, uint8_t *out, size_t cap, int *colorspace)
+{
+	struct vss_source *src = data;
+	size_t n = 0;
+	pthread_mutex_lock(&src->tex_mutex);
+	const int r = src->w_tex_buf ^ 1;
+	if (colorspace)
+		*colorspace = src->tex_cs[r];
+	if (src->tex_buf[r] && out && cap >= (size_t)VS_SIZE * VS_SIZE) {
+		n = (size_t)VS_SIZE * VS_SIZE;
+		memcpy(out, src->tex_buf[r], n);
+	}
+	pthread_mutex_unlock(&src->tex_mutex);
+	return n;
+}
+
+size_t scope_host_wvs_copy(void *data, uint8_t *out, size_t cap, uint32_t *width)
+{
+	struct wvs_source *src = data;
+	size_t n = 0;
+	pthread_mutex_lock(&src->tex_mutex);
+	const int r = src->w_tex_buf ^ 1;
+	const size_t need = (size_t)WV_SIZE * src->tex_buf_width[r] * 4;
+	if (width)
+		*width = src->tex_buf_width[r];
+	if (src->tex_buf[r] && out && need && cap >= need) {
+		n = need;
+		memcpy(out, src->tex_buf[r], n);
+	}
+	pthread_mutex_unlock(&src->tex_mutex);
+	return n;
+}
+
+size_t scope_host_his_copy(void *data, float *out, size_t cap, uint32_t *hi_max)
+{
+	struct his_source *src = data;
+	size_t n = 0;
+	pthread_mutex_lock(&src->tex_mutex);
+	const int r = src->w_tex_buf ^ 1;
+	if (hi_max)
+		for (int i = 0; i < 3; i++)
+			hi_max[i] = src->hi_max[r][i];
+	if (src->tex_buf[r] && out && cap >= (size_t)HI_SIZE * 4 * sizeof(float)) {
+		n = (size_t)HI_SIZE * 4 * sizeof(float);
+		memcpy(out, src->tex_buf[r], n);
+	}
+	pthread_mutex_unlock(&src->tex_mutex);
+	return n;
 }
 
 /* The level settings his_update left behind (src/histogram.c:131-156): what the next K3b pass and the graticule use. */

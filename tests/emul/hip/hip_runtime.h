@@ -115,7 +115,7 @@ void block_barrier();
 bool wave64();
 /* the rendezvous of a wave's live lanes: every lane leaves `v`; returns the 64 slots and which of them are lanes that took part */
 const uint64_t *wave_gather(uint64_t v, uint64_t *mask, unsigned site);
-enum { SITE_BALLOT = 1, SITE_READLANE, SITE_BELOW, SITE_SUM, SITE_BARRIER };
+enum { SITE_BALLOT = 1, SITE_READLANE, SITE_BELOW, SITE_SUM, SITE_BARRIER, SITE_READFIRST };
 /* runs fn(blockIdx) for every thread of every block */
 void run_grid(dim3 grid, dim3 block, void (*thread_fn)(void *), void *ctx);
 } // namespace emul

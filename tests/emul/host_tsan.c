@@ -31,6 +31,9 @@ struct cm_source *scope_host_cm(void *source);
 const uint8_t *scope_host_vss_table(void *data, int *colorspace);
 const uint8_t *scope_host_wvs_table(void *data, uint32_t *width);
 const float *scope_host_his_table(void *data, uint32_t *hi_max);
+size_t scope_host_vss_copy(void *data, uint8_t *out, size_t cap, int *colorspace);
+size_t scope_host_wvs_copy(void *data, uint8_t *out, size_t cap, uint32_t *width);
+size_t scope_host_his_copy(void *data, float *out, size_t cap, uint32_t *hi_max);
 uint64_t scope_host_frames_processed(void *source);
 uint64_t scope_host_frames_dropped(void *source);
 
@@ -61,6 +64,14 @@ static void *render_thread(void *unused)
 			info[i]->video_render(src[i], NULL);
 			renders += info[i]->get_width(src[i]) + info[i]->get_height(src[i]) != 0;
 		}
+		/* a host reading the finished tables WHILE frames flow: the copy-out accessors (host_api.c), under the worker's flips */
+		static uint8_t vss_copy[65536], wvs_copy[(size_t)W * 256 * 4];
+		static float his_copy[1024];
+		uint32_t width = 0, hi[3];
+		int cs = 0;
+		renders += scope_host_vss_copy(src[0], vss_copy, sizeof vss_copy, &cs) > sizeof vss_copy;
+		renders += scope_host_wvs_copy(src[1], wvs_copy, sizeof wvs_copy, &width) > sizeof wvs_copy;
+		renders += scope_host_his_copy(src[2], his_copy, sizeof his_copy, hi) > sizeof his_copy;
 		nap(100); /* thousands of renders per second are plenty (and the emulated display passes are not free) */
 	}
 	return (void *)renders;

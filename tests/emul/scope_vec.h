@@ -114,6 +114,21 @@ static inline unsigned scope_lane_below(unsigned x, unsigned fill)
 	}
 	return fill;
 }
+/* the value of the wave's first live lane, for a value that is NOT wave-uniform yet (the emulation's __builtin_amdgcn_readfirstlane is
+ * the identity: the kernels use that one on uniform values only) */
+static inline unsigned scope_first_lane(unsigned x)
+{
+	if (emul::wave64()) {
+		uint64_t m;
+		const uint64_t *v = emul::wave_gather(x, &m, emul::SITE_READFIRST);
+		return (unsigned)v[__builtin_ctzll(m)];
+	}
+	return x;
+}
+static inline unsigned scope_lane_below0(unsigned x)
+{
+	return scope_lane_below(x, 0u);
+}
 static inline unsigned scope_lanes_below(unsigned long long mask)
 {
 	if (emul::wave64())

@@ -57,6 +57,11 @@ class Host:
         L.scope_host_wvs_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.scope_host_his_table.restype = C.POINTER(C.c_float)
         L.scope_host_his_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        for name, meta in (("scope_host_vss_copy", C.POINTER(C.c_int)), ("scope_host_wvs_copy", C.POINTER(C.c_uint32)),
+                           ("scope_host_his_copy", C.POINTER(C.c_uint32))):
+            fn = getattr(L, name)
+            fn.restype = C.c_size_t
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, meta]
         L.scope_host_picture.restype = C.POINTER(C.c_uint8)
         L.scope_host_picture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.scope_host_frames_processed.restype = C.c_uint64
@@ -98,14 +103,20 @@ class Host:
         self.L.cm_drain(self.L.scope_host_cm(obj))
 
     def vss_table(self, obj):
+        """The copy-out accessor (host_api.c): taken under the source's tex_mutex, legal with frames in flight."""
         cs = C.c_int()
-        p = self.L.scope_host_vss_table(obj, C.byref(cs))
-        return (np.ctypeslib.as_array(p, (256, 256)).copy() if p else None), cs.value
+        out = np.empty((256, 256), np.uint8)
+        n = self.L.scope_host_vss_copy(obj, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(cs))
+        return (out if n else None), cs.value
 
     def wvs_table(self, obj):
         w = C.c_uint32()
-        p = self.L.scope_host_wvs_table(obj, C.byref(w))
-        return np.ctypeslib.as_array(p, (256, w.value, 4)).copy() if p else None
+        self.L.scope_host_wvs_copy(obj, None, 0, C.byref(w))  # the width first
+        if not w.value:
+            return None
+        out = np.empty((256, w.value, 4), np.uint8)
+        n = self.L.scope_host_wvs_copy(obj, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(w))
+        return out if n == out.nbytes else None
 
     def picture(self, obj, kind):
         w, h = C.c_uint32(), C.c_uint32()
@@ -114,8 +125,9 @@ class Host:
 
     def his_table(self, obj):
         hi = (C.c_uint32 * 3)()
-        p = self.L.scope_host_his_table(obj, hi)
-        return (np.ctypeslib.as_array(p, (256, 4)).copy() if p else None), list(hi)
+        out = np.empty((256, 4), np.float32)
+        n = self.L.scope_host_his_copy(obj, out.ctypes.data_as(C.c_void_p), out.nbytes, hi)
+        return (out if n else None), list(hi)
 
 
 def check_source_surface(host):

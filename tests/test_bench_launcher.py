@@ -7,6 +7,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -25,10 +26,13 @@ def shm_rccl(emul_lib):
     return os.path.join(d, "libshm_rccl_emul.so")
 
 
+DETAIL_DIR = tempfile.mkdtemp(prefix="bench_detail_")  # never the repository's bench_detail.json: that file belongs to real runs
+
+
 def clean_env(**extra):
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SELF_LAUNCHED", "SCOPE_RCCL_LIBRARY")}
-    env.update(OMP_NUM_THREADS="1", **extra)
+    env.update(OMP_NUM_THREADS="1", BENCH_DETAIL=os.path.join(DETAIL_DIR, f"detail_{os.getpid()}_{len(os.listdir(DETAIL_DIR))}.json"), **extra)
     return env
 
 

@@ -208,18 +208,24 @@ def test_three_scopes_one_read(emul_ctx, oracle, dock):
             dev(16, 4090, [3], reps=1)                    # a tall flat strip: clamp passes inside the strip
 
 
+@pytest.mark.parametrize("forced", [0, 1])
 @pytest.mark.parametrize("strip", [0, 16, 32])
-def test_three_scopes_screen_content(emul_ctx, oracle, strip):
+def test_three_scopes_screen_content(emul_ctx, oracle, strip, forced):
     """scope_trio_kernel's absorb mode (the emulated wave's vote is its one lane's: a lane with a flat texel pair absorbs): screen-like
     content, where a lane keeps its colour for long, meets single texels of detail and crosses into other flat areas -- colour changes
-    in the vote's slots, plain adds between them."""
+    in the vote's slots, plain adds between them.  forced 1: the vectorscope half's run-length form (trio_rle_pair, round 6) on every
+    slot of any content (vss.rle = 1); by vote it runs where a wave is flat in most lanes but not in all -- never in a one-lane wave,
+    under the 64-lane model (tests/test_wave64_emul.py) on the screen-like frames here."""
     dev = lambda *a, **k: pc.check_three_scopes_dev(emul_ctx, oracle, _np_dev, lambda hnd: hnd, *a, **k)  # noqa: E731
     kinds = [{}, {"detail": 0.0}, {"detail": 0.3}, {"grey": True}, {"alpha_noise": True, "detail": 0.01}, {"rects": 40, "detail": 0.05}]
-    with pc.options(emul_ctx, **{"trio.strip": strip}):
+    with pc.options(emul_ctx, **{"trio.strip": strip, "vss.rle": forced}):
         dev(96, 260, kinds, reps=1)
         dev(72, 130, kinds[:2], 0x05, 0x04, 72 * 4 + 8, 1, reps=1)
         dev(32, 2100, [kinds[5], 3], reps=1)              # clamp passes with lanes holding counts
         dev(200, 40, kinds[3:6], 0x02, 0x02, reps=2)
+        if forced:
+            dev(100, 37, [1, 2, 5], 0x07, 0x03, 100 * 4 + 24, 1, reps=1)  # noise, a tight cluster, alpha holes: every pair rough or a short run; a ragged last strip
+            dev(36, 3, [3, 4], reps=1)                    # three rows: most lanes of a wave hold no texel and break every run
 
 
 @pytest.mark.parametrize("strip", [16, 32])

@@ -250,11 +250,14 @@ def test_three_scopes_strip_widths(hip_ctx, oracle, strip):
         dev(7680, 4320, [2], reps=1)
 
 
+@pytest.mark.parametrize("forced", [0, 1])
 @pytest.mark.parametrize("strip", [0, 16, 32])
-def test_three_scopes_screen_content(hip_ctx, oracle, strip):
-    """scope_trio_kernel's absorb mode at work: screen-like content -- flat areas, rectangles, sprinkled detail, greys, random alpha --
-    where most lanes of a wave hold their colour, some do not, and lanes cross into other flat areas (colour changes in the vote's
-    slots, plain adds between them); batches and one-frame calls, both strip widths, both matrices, one- and two-channel masks."""
+def test_three_scopes_screen_content(hip_ctx, oracle, strip, forced):
+    """scope_trio_kernel's flat-content modes at work: screen-like content -- flat areas, rectangles, sprinkled detail, greys, random
+    alpha -- where most lanes of a wave hold flat texel pairs and some do not: the run-length form (trio_rle_pair, round 6: runs of
+    equal pairs across the lanes of a DPP row, one add per run) where the vote finds such a wave, the per-lane absorb mode where the
+    whole wave is flat, plain adds elsewhere; batches and one-frame calls, both strip widths, both matrices, one- and two-channel
+    masks.  forced 1: the run-length form on every slot of any content (vss.rle = 1)."""
     to_dev, to_host = _torch_dev()
 
     def dev(*a, **k):
@@ -262,12 +265,15 @@ def test_three_scopes_screen_content(hip_ctx, oracle, strip):
 
     kinds = [{}, {"detail": 0.0}, {"detail": 0.3}, {"grey": True}, {"alpha_noise": True, "detail": 0.01}, {"rects": 200, "detail": 0.0},
              {"rects": 300, "detail": 0.03}, {"rects": 60, "detail": 0.1}]
-    with pc.options(hip_ctx, **{"trio.strip": strip}):
+    with pc.options(hip_ctx, **{"trio.strip": strip, "vss.rle": forced}):
         dev(3840, 2160, kinds, reps=1)
         dev(3840, 2160, kinds[:1], reps=1)
         dev(3840, 2160, [kinds[6], 3, kinds[0]], 0x05, 0x04, colorspace=1, reps=1)
         dev(1924, 1083, kinds[:3], 0x07, 0x05, 1924 * 4 + 64, reps=1)
         dev(328, 77, kinds[4:7], 0x02, 0x02, reps=2)
+        if forced:
+            dev(3840, 2160, [1, 2, 5, 4], reps=1)        # noise, a tight cluster, alpha holes, bars: rough pairs and short runs
+            dev(100, 37, [1, 2, 5], 0x07, 0x03, 100 * 4 + 24, 1, reps=1)  # a ragged last strip, lanes without texels
 
 
 @pytest.mark.parametrize("strip", [16, 64])
