@@ -277,6 +277,19 @@ def kernel_us(ctx, fn, warm=12, reps=24):
     return round(ms / max(nl, 1) * 1e3, 2)
 
 
+def steps_ms(dev, ctl, step, steps, warmup):
+    """ms per step of exactly `steps` steps between synchronizes, after `warmup` untimed ones (one round of an interleaved comparison)."""
+    for j in range(max(warmup, 2)):
+        step(j)
+    dev.sync()
+    ctl.barrier()
+    t0 = time.perf_counter()
+    for j in range(steps):
+        step(j)
+    dev.sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def place_pool(torch, dev, ctx, frames, candidates, keep_alive):
     """WHERE a frame pool lies in HBM decides a few per cent of every streaming kernel's rate, and the first pools a
     process allocates are regularly the slow ones (profiles/round2/placement_probe_g8.txt; profiles/HISTORY.md section 5).  The
@@ -454,7 +467,8 @@ def compact_line(result, detail=None):
     rf = result.get("roofline")
     if rf:
         r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "achieved_kernel", "frac_kernel", "avg_launch_ms",
-                       "launches_timed", "algorithmic_bytes_per_launch", "traffic", "frac_placed", "frac_kernel_placed"))
+                       "launches_timed", "algorithmic_bytes_per_launch", "traffic", "frac_placed", "frac_kernel_placed",
+                        "frac_first_pool_same_rounds", "frac_kernel_first_pool_same_rounds"))
         r["kernel"] = _short(r.get("kernel"), 40)
         r["traffic_source"] = _short(rf.get("traffic_source"), 60)
         out["roofline"] = r

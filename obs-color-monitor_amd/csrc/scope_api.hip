@@ -14,11 +14,21 @@
 #include <math.h>
 #include <stdio.h>
 #include <mutex>
+#include <vector>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
 
 #define SCOPE_PROFILE_SLOTS 512u
+
+/* a frame pool scope_frame_pool_alloc mapped itself: one physical allocation (`handle`) at `va` inside an address reservation */
+struct ScopePoolRec {
+	void *va;
+	size_t size;
+	void *reserve_base;
+	size_t reserve_size;
+	unsigned long long handle; /* hipMemGenericAllocationHandle_t */
+};
 
 struct scope_ctx {
 	int device;
@@ -47,6 +57,7 @@ struct scope_ctx {
 	 * pipeline threads and its render thread (the reference runs one "color-monitor" thread per stand-alone
 	 * source, src/common.c:375-403).  Recursive: scope_surface_begin() keeps it until scope_surface_end(). */
 	std::recursive_mutex mu;
+	std::vector<ScopePoolRec> pools; /* pools scope_frame_pool_alloc mapped; a pool still there when the context goes is unmapped with it */
 	/* scope_surface_begin .. scope_surface_end: host planes uploaded once and reused by every scope call that is
 	 * handed the same plane (the ROI / dock fan-out) */
 	struct {
@@ -794,6 +805,12 @@ void scope_ctx_destroy(scope_ctx *ctx)
 		return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	for (const ScopePoolRec &rec : ctx->pools) { /* pools the host did not give back */
+		(void)hipMemUnmap(rec.va, rec.size);
+		(void)hipMemRelease((hipMemGenericAllocationHandle_t)(uintptr_t)rec.handle);
+		(void)hipMemAddressFree(rec.reserve_base, rec.reserve_size);
+	}
+	ctx->pools.clear();
 	if (ctx->partial)
 		(void)hipFree(ctx->partial);
 	if (ctx->stage_in)
@@ -1418,7 +1435,169 @@ int scope_table_unpack_clamp_u16x2_u8(scope_ctx *ctx, const uint32_t *in, uint8_
 	return SCOPE_OK;
 }
 
-/* ---- frame pools: WHERE in HBM a long-lived pool lies decides a few per cent of every streaming kernel's rate ---------- */
+/* ---- frame pools: WHICH ADDRESS RANGE a long-lived pool is mapped at decides a few per cent of every streaming kernel's rate ------
+ * Round 6's probe (tools/placement_vmm_probe.hip, profiles/round6/placement_vmm_probe_c6.txt): on a box whose pools spread over 8 %
+ * the rate FOLLOWS THE VIRTUAL ADDRESS RANGE, not the physical memory -- two hipMemCreate handles that swap their addresses swap
+ * their rates (0.856 <-> 0.809 of peak), the same handle reads 0.807 / 0.856 / 0.808 at three ranges, an offset of 2 or 64 MiB
+ * inside a range changes nothing, the latency of dependent loads is the same on fast and slow ranges at every stride (it is not
+ * the size of the page-table fragments), and one 24 GiB mapping reads the same in every 2 GiB window.  So the search needs ONE
+ * physical allocation: it is mapped at up to `candidates` ranges of one address reservation in turn, each read a few times by
+ * the vectorscope accumulation kernel (three interleaved rounds, the kernel's own begin / end stamps, the fastest launch of a
+ * round counts, the median round decides), and stays at the best.  Nothing is copied, and candidates x bytes of HBM are never held.
+ * Where the driver has no virtual-memory calls (the CPU emulation; older stacks) the round-3 form runs instead: `candidates`
+ * plain allocations held at once, each probed, the fastest kept. */
+namespace {
+
+struct PoolProbe {
+	ScopeFrameSet fs;
+	uint64_t frame_bytes, probe_bytes;
+	uint32_t slices, mask_block;
+};
+
+int pool_probe_setup(scope_ctx *ctx, uint64_t bytes, PoolProbe *pp)
+{
+	memset(&pp->fs, 0, sizeof pp->fs);
+	pp->fs.linesize = 4096;
+	pp->fs.width = 1024;
+	pp->fs.n_frames = bytes >= ((uint64_t)SCOPE_MAX_FRAMES << 20) ? SCOPE_MAX_FRAMES : (uint32_t)((bytes >> 20) ? (bytes >> 20) : 1);
+	pp->frame_bytes = (bytes / pp->fs.n_frames) & ~(uint64_t)4095;
+	if (pp->frame_bytes >= (1ull << 31))
+		pp->frame_bytes = (1ull << 31) - 4096; /* 32-bit offsets inside a slice's span: a huge pool is probed on its first 128 GiB */
+	pp->fs.height = (uint32_t)(pp->frame_bytes / 4096);
+	pp->probe_bytes = (uint64_t)pp->fs.n_frames * pp->fs.height * 4096;
+	pp->slices = pick_slices(ctx, pp->fs.n_frames, 1);
+	pp->mask_block = ctx->tn.vss_sparse ? scope_vss_mask_block(ctx->tn) : 0u;
+	if (!pp->probe_bytes)
+		return SCOPE_OK;
+	int rc = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)pp->fs.n_frames * pp->slices * SCOPE_VSS_BINS);
+	if (rc == SCOPE_OK && pp->mask_block)
+		rc = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)pp->fs.n_frames * pp->slices * pp->mask_block);
+	return rc;
+}
+
+/* GB/s of the vectorscope accumulation kernel over the pool at `base` taken as frames: `launches` launches, the fastest counts */
+int pool_probe(scope_ctx *ctx, PoolProbe *pp, const void *base, hipEvent_t ev[2], int warm, int launches, float *gbps)
+{
+	for (uint32_t f = 0; f < pp->fs.n_frames; f++)
+		pp->fs.plane[f] = (const uint8_t *)base + (size_t)f * pp->frame_bytes;
+	const ScopeTiming tm = {ev[0], ev[1]};
+	float best_ms = 0.0f;
+	for (int rep = 0; rep < warm + launches; rep++) {
+		if (scope_launch_vss(pp->fs, pp->slices, 0, 2, ctx->partial, (pp->slices > 1 && pp->mask_block) ? ctx->pmask : NULL, ctx->tn,
+				     ctx->stream, &tm) != hipSuccess ||
+		    hipEventSynchronize(ev[1]) != hipSuccess)
+			return fail(ctx, SCOPE_EIO, "frame pool probe", hipGetLastError());
+		float ms = 0.0f;
+		(void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+		if (rep >= warm && ms > 0.0f && (best_ms == 0.0f || ms < best_ms))
+			best_ms = ms;
+	}
+	*gbps = best_ms > 0.0f ? (float)((double)pp->probe_bytes / ((double)best_ms * 1e-3) / 1e9) : 0.0f;
+	return SCOPE_OK;
+}
+
+float median3(float a, float b, float c)
+{
+	return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b));
+}
+
+#ifndef SCOPE_POOL_VMM
+#define SCOPE_POOL_VMM 1 /* 0: the round-3 form only (A/B) */
+#endif
+
+/* ONE physical allocation tried at up to `candidates` address ranges.  SCOPE_OK with *pool set; SCOPE_EAGAIN (nothing allocated) when
+ * the driver refuses a virtual-memory call: the caller falls back to plain allocations. */
+int pool_alloc_vmm(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **pool, float *rate /* [candidates] */, uint32_t *best_out)
+{
+	if (!SCOPE_POOL_VMM)
+		return SCOPE_EAGAIN;
+	hipMemAllocationProp prop;
+	memset(&prop, 0, sizeof prop);
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = ctx->device;
+	size_t gran = 0;
+	if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess) {
+		(void)hipGetLastError();
+		return SCOPE_EAGAIN;
+	}
+	const size_t two_mib = (size_t)2 << 20, gib = (size_t)1 << 30;
+	if (gran < two_mib)
+		gran = two_mib;
+	const size_t size = ((size_t)bytes + gran - 1) / gran * gran;
+	const size_t slot = (size + gib - 1) / gib * gib + gib; /* ranges a whole GiB and more apart */
+	hipMemGenericAllocationHandle_t h;
+	if (hipMemCreate(&h, size, &prop, 0) != hipSuccess) {
+		(void)hipGetLastError();
+		return SCOPE_EAGAIN;
+	}
+	void *base = NULL;
+	if (hipMemAddressReserve(&base, slot * candidates, two_mib, NULL, 0) != hipSuccess) {
+		(void)hipGetLastError();
+		(void)hipMemRelease(h);
+		return SCOPE_EAGAIN;
+	}
+	hipMemAccessDesc acc;
+	memset(&acc, 0, sizeof acc);
+	acc.location.type = hipMemLocationTypeDevice;
+	acc.location.id = ctx->device;
+	acc.flags = hipMemAccessFlagsProtReadWrite;
+	auto map_at = [&](uint32_t i) {
+		uint8_t *va = (uint8_t *)base + (size_t)i * slot;
+		if (hipMemMap(va, size, 0, h, 0) != hipSuccess)
+			return false;
+		if (hipMemSetAccess(va, size, &acc, 1) != hipSuccess) {
+			(void)hipMemUnmap(va, size);
+			return false;
+		}
+		return true;
+	};
+	PoolProbe pp;
+	hipEvent_t ev[2] = {NULL, NULL};
+	int rc = pool_probe_setup(ctx, bytes, &pp);
+	if (rc == SCOPE_OK && (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))
+		rc = fail(ctx, SCOPE_EIO, "hipEventCreate", hipGetLastError());
+	float r[3][SCOPE_POOL_MAX_CANDIDATES] = {{0}};
+	bool vmm_ok = true;
+	for (int round = 0; round < 3 && rc == SCOPE_OK && vmm_ok && pp.probe_bytes; round++)
+		for (uint32_t i = 0; i < candidates && rc == SCOPE_OK && vmm_ok; i++) {
+			vmm_ok = map_at(i);
+			if (!vmm_ok)
+				break;
+			if (round == 0 && i == 0) /* what the physical memory holds is anybody's: a known content, once (it travels with the handle) */
+				rc = hipMemsetAsync((uint8_t *)base, 0x5a, size, ctx->stream) == hipSuccess ? SCOPE_OK : fail(ctx, SCOPE_EIO, "hipMemsetAsync", hipGetLastError());
+			if (rc == SCOPE_OK)
+				rc = pool_probe(ctx, &pp, (uint8_t *)base + (size_t)i * slot, ev, round == 0 ? 2 : 1, 4, &r[round][i]);
+			(void)hipStreamSynchronize(ctx->stream);
+			vmm_ok = hipMemUnmap((uint8_t *)base + (size_t)i * slot, size) == hipSuccess && vmm_ok;
+		}
+	uint32_t best = 0;
+	for (uint32_t i = 0; i < candidates; i++) {
+		rate[i] = median3(r[0][i], r[1][i], r[2][i]);
+		if (rate[i] > rate[best])
+			best = i;
+	}
+	if (rc == SCOPE_OK && vmm_ok)
+		vmm_ok = map_at(best);
+	if (ev[0])
+		(void)hipEventDestroy(ev[0]);
+	if (ev[1])
+		(void)hipEventDestroy(ev[1]);
+	if (rc != SCOPE_OK || !vmm_ok) {
+		(void)hipGetLastError();
+		(void)hipMemAddressFree(base, slot * candidates);
+		(void)hipMemRelease(h);
+		return rc != SCOPE_OK ? rc : SCOPE_EAGAIN;
+	}
+	ScopePoolRec rec = {(uint8_t *)base + (size_t)best * slot, size, base, slot * candidates, (unsigned long long)(uintptr_t)h};
+	ctx->pools.push_back(rec);
+	*pool = rec.va;
+	*best_out = best;
+	return SCOPE_OK;
+}
+
+} // namespace
+
 int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **pool, float *read_gbps,
 			   uint32_t *tried)
 {
@@ -1434,69 +1613,53 @@ int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, 
 		candidates = 1;
 	if (candidates > SCOPE_POOL_MAX_CANDIDATES)
 		candidates = SCOPE_POOL_MAX_CANDIDATES;
-	/* All candidates are held at once (freeing one and allocating again hands out the same virtual range over OTHER
-	 * physical memory, fast or slow: profiles/round2/placement2_r2f.txt).  Each is read a few times by the kernel the pool
-	 * is for -- the vectorscope accumulation itself, the pool taken as up to 64 "frames" of 4 KiB rows (any bytes are
-	 * pixels) -- timed by the kernel's own begin / end stamps; the fastest stays.  (A plain streaming-read kernel was tried
-	 * as the yardstick first: its ranking of four candidates did not predict the accumulation kernel's, profiles/round3.) */
-	void *cand[SCOPE_POOL_MAX_CANDIDATES] = {NULL};
 	float rate[SCOPE_POOL_MAX_CANDIDATES] = {0};
-	hipEvent_t ev[2] = {NULL, NULL};
-	int rc = SCOPE_OK;
 	uint32_t n = 0, best = 0;
-	if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)
-		rc = fail(ctx, SCOPE_EIO, "hipEventCreate", hipGetLastError());
-	ScopeFrameSet fs;
-	memset(&fs, 0, sizeof fs);
-	fs.linesize = 4096;
-	fs.width = 1024;
-	fs.n_frames = bytes >= ((uint64_t)SCOPE_MAX_FRAMES << 20) ? SCOPE_MAX_FRAMES : (uint32_t)((bytes >> 20) ? (bytes >> 20) : 1);
-	uint64_t frame_bytes = (bytes / fs.n_frames) & ~(uint64_t)4095;
-	if (frame_bytes >= (1ull << 31))
-		frame_bytes = (1ull << 31) - 4096; /* 32-bit offsets inside a slice's span: a huge pool is probed on its first 128 GiB */
-	fs.height = (uint32_t)(frame_bytes / 4096);
-	const uint64_t probe_bytes = (uint64_t)fs.n_frames * fs.height * 4096;
-	uint32_t slices = pick_slices(ctx, fs.n_frames, 1);
-	const uint32_t mask_block = ctx->tn.vss_sparse ? scope_vss_mask_block(ctx->tn) : 0u;
-	if (rc == SCOPE_OK && candidates > 1 && probe_bytes) {
-		rc = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)fs.n_frames * slices * SCOPE_VSS_BINS);
-		if (rc == SCOPE_OK && mask_block)
-			rc = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)fs.n_frames * slices * mask_block);
+	int rc = SCOPE_OK;
+	if (candidates > 1) {
+		rc = pool_alloc_vmm(ctx, bytes, candidates, pool, rate, &best);
+		if (rc == SCOPE_OK)
+			n = candidates;
+		else if (rc != SCOPE_EAGAIN)
+			return rc;
 	}
-	for (; rc == SCOPE_OK && n < candidates; n++) {
-		const hipError_t e = hipMalloc(&cand[n], (size_t)bytes);
-		if (e != hipSuccess) {
-			cand[n] = NULL;
-			(void)hipGetLastError(); /* the launchers end with hipGetLastError(): a stale out-of-memory must not fail the next one */
-			if (n == 0)
-				rc = fail(ctx, SCOPE_ENOMEM, "hipMalloc (frame pool)", e);
-			break; /* fewer candidates than asked for: the best of those there are */
-		}
-		if (candidates == 1 || probe_bytes == 0)
-			continue; /* nothing to compare */
-		for (uint32_t f = 0; f < fs.n_frames; f++)
-			fs.plane[f] = (const uint8_t *)cand[n] + (size_t)f * frame_bytes;
-		const ScopeTiming tm = {ev[0], ev[1]};
-		float best_ms = 0.0f;
-		for (int rep = 0; rep < 8 && rc == SCOPE_OK; rep++) { /* three to warm up, the fastest of five counts */
-			if (scope_launch_vss(fs, slices, 0, 2, ctx->partial, (slices > 1 && mask_block) ? ctx->pmask : NULL, ctx->tn, ctx->stream,
-					     &tm) != hipSuccess ||
-			    hipEventSynchronize(ev[1]) != hipSuccess) {
-				rc = fail(ctx, SCOPE_EIO, "frame pool probe", hipGetLastError());
-				break;
+	if (!*pool) {
+		/* plain allocations, all held at once (freeing one and allocating again hands out the same virtual range again), each
+		 * probed; the fastest stays */
+		void *cand[SCOPE_POOL_MAX_CANDIDATES] = {NULL};
+		hipEvent_t ev[2] = {NULL, NULL};
+		PoolProbe pp;
+		rc = candidates > 1 ? pool_probe_setup(ctx, bytes, &pp) : SCOPE_OK;
+		if (rc == SCOPE_OK && candidates > 1 && (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))
+			rc = fail(ctx, SCOPE_EIO, "hipEventCreate", hipGetLastError());
+		for (; rc == SCOPE_OK && n < candidates; n++) {
+			const hipError_t e = hipMalloc(&cand[n], (size_t)bytes);
+			if (e != hipSuccess) {
+				cand[n] = NULL;
+				(void)hipGetLastError(); /* the launchers end with hipGetLastError(): a stale out-of-memory must not fail the next one */
+				if (n == 0)
+					rc = fail(ctx, SCOPE_ENOMEM, "hipMalloc (frame pool)", e);
+				break; /* fewer candidates than asked for: the best of those there are */
 			}
-			float ms = 0.0f;
-			(void)hipEventElapsedTime(&ms, ev[0], ev[1]);
-			if (rep >= 3 && ms > 0.0f && (best_ms == 0.0f || ms < best_ms))
-				best_ms = ms;
+			if (candidates == 1 || pp.probe_bytes == 0)
+				continue; /* nothing to compare */
+			rc = pool_probe(ctx, &pp, cand[n], ev, 3, 5, &rate[n]);
+			if (rate[n] > rate[best])
+				best = n;
 		}
-		rate[n] = best_ms > 0.0f ? (float)((double)probe_bytes / ((double)best_ms * 1e-3) / 1e9) : 0.0f;
-		if (rate[n] > rate[best])
-			best = n;
+		if (rc == SCOPE_OK) {
+			*pool = cand[best];
+			cand[best] = NULL;
+		}
+		for (uint32_t i = 0; i < SCOPE_POOL_MAX_CANDIDATES; i++)
+			if (cand[i])
+				(void)hipFree(cand[i]);
+		if (ev[0])
+			(void)hipEventDestroy(ev[0]);
+		if (ev[1])
+			(void)hipEventDestroy(ev[1]);
 	}
 	if (rc == SCOPE_OK) {
-		*pool = cand[best];
-		cand[best] = NULL;
 		if (tried)
 			*tried = n;
 		if (read_gbps) {
@@ -1507,13 +1670,6 @@ int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, 
 					read_gbps[k++] = rate[i];
 		}
 	}
-	for (uint32_t i = 0; i < SCOPE_POOL_MAX_CANDIDATES; i++)
-		if (cand[i])
-			(void)hipFree(cand[i]);
-	if (ev[0])
-		(void)hipEventDestroy(ev[0]);
-	if (ev[1])
-		(void)hipEventDestroy(ev[1]);
 	return rc;
 }
 
@@ -1522,7 +1678,21 @@ int scope_frame_pool_free(scope_ctx *ctx, void *pool)
 	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
-	if (pool && hipFree(pool) != hipSuccess)
+	if (!pool)
+		return SCOPE_OK;
+	for (size_t i = 0; i < ctx->pools.size(); i++)
+		if (ctx->pools[i].va == pool) {
+			const ScopePoolRec rec = ctx->pools[i];
+			ctx->pools.erase(ctx->pools.begin() + (long)i);
+			(void)hipStreamSynchronize(ctx->stream);
+			const bool ok = hipMemUnmap(rec.va, rec.size) == hipSuccess;
+			const bool ok2 = hipMemRelease((hipMemGenericAllocationHandle_t)(uintptr_t)rec.handle) == hipSuccess;
+			const bool ok3 = hipMemAddressFree(rec.reserve_base, rec.reserve_size) == hipSuccess;
+			if (!(ok && ok2 && ok3))
+				return fail(ctx, SCOPE_EIO, "frame pool: unmap / release / address free", hipGetLastError());
+			return SCOPE_OK;
+		}
+	if (hipFree(pool) != hipSuccess)
 		return fail(ctx, SCOPE_EIO, "hipFree (frame pool)", hipGetLastError());
 	return SCOPE_OK;
 }

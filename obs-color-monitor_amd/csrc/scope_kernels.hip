@@ -338,6 +338,9 @@ __device__ __forceinline__ bool scope_rows_mode(u32 linesize, u32 ncols, u32 cel
  * one frame per call, the ring of three) is dominated by its start-up, and carrying the mode's code cost it 2.5-4 % on noise and
  * natural content for +4 % (one frame) / +14 % (three) on screen content (visit c4/c5, profiles/round4/ab_fused_vectorscope.txt). */
 #define VSS_RLE_IN(U) (VSS_RLE && (U) == 4)
+#ifndef VSS_RLE_LEAN
+#define VSS_RLE_LEAN 1 /* 0: round 4's instruction sequence of the run-length modes (A/B) */
+#endif
 #ifndef VSS_RLE_KEYS
 #define VSS_RLE_KEYS 1 /* 0: the plain (staged-plane) vectorscope without the run-length form of its absorb mode (A/B) */
 #endif
@@ -404,28 +407,44 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		 * lane wide, with that lane's ballot bit at its thread's position -- gets 0 and 1 */
 		const u32 lane_w = scope_lanes_below(~0ull), wave_w = (u32)__popcll(__ballot(1));
 		u32 *rle_scr = tab + VssTable<HASH>::words + (threadIdx.x >> 6) * VSS_RLE_SCRATCH_WORDS_PER_WAVE;
+		const u32 lane_tag = 0x40000000u | lane_id; /* no key looks like it (keys: bytes 0 and 3 zero, U >= 15: never zero either) */
 		auto bin_rle = [&](const scope_v4(&q)[U], const bool(&ok)[U]) {
 #pragma unroll
 			for (int k = 0; k < U; k++) {
 				const u32 p0 = q[k][0], p1 = q[k][1], p2 = q[k][2], p3 = q[k][3];
-				const bool flat = ok[k] && (scope_bitop3<0xf6>(p0 ^ p1, p0, p2) | (p0 ^ p3)) << 8 == 0u;
+				/* flat: the four texels agree in B, G, R (bits that differ between p0 and any of the others, alpha masked off) */
+				const bool flat = ok[k] && scope_bitop3<0xa8>(scope_bitop3<0x7e>(p0, p1, p2), p0 ^ p3, 0x00ffffffu) == 0u;
 				u32 key0[1] = {p0};
 				scope_k0_cell<1, true>(key0, k0, true, false); /* wave votes inside: every lane goes through */
-				/* keys have bytes 0 and 3 zero: bit 31 marks a flat cell, bit 30 + the lane a cell that continues nothing */
-				const u32 tag = flat ? (key0[0] | 0x80000000u) : (0x40000000u | lane_id);
-				const u32 below = scope_lane_below(tag, 0u); /* every lane takes part in the DPP move (its contract), flat or not */
-				const bool cont = flat && tag == below && (lane_id & (run_lanes - 1u)) != 0u;
+				/* a flat cell's tag is its key, any other cell's the lane's own: equal tags <=> flat cells of one bin.  Round 6 (the
+				 * three-scope kernel's run-length form carried back, `VSS_RLE_LEAN`): the tag is one select, the lane below comes with
+				 * zero for the first lane of a DPP row (bound_ctrl: no register to prepare; a run may cross the lane groups of a row --
+				 * equal bins merge whatever their places in the picture), the run's length is a 32-bit count of trailing zeros (a run
+				 * ends within its sixteen lanes), and heads and rough cells add their texel 0 through ONE address computation. */
+				const u32 tag = flat ? key0[0] : lane_tag;
+				const u32 below = VSS_RLE_LEAN ? scope_lane_below0(tag) : scope_lane_below(tag, 0u); /* every lane takes part (the DPP move's contract) */
+				const bool cont = tag == below && (VSS_RLE_LEAN || (flat && (lane_id & (run_lanes - 1u)) != 0u)); /* (round 4: runs inside a lane group) */
 				const u64 breaks = ~__ballot(cont); /* every lane that continues nothing (and every lane there is none of) */
-				if (flat && !cont) { /* the head of a run: the next break above this lane ends it */
+				const bool nf = ok[k] && !flat;
+				const u64 rough = __ballot(nf);
+				if (VSS_RLE_LEAN) {
+					if (ok[k] && !cont) { /* the head of a run, or a rough cell's texel 0 */
+						u32 n = 1u;
+						if (flat) {
+							const u64 above = ((breaks >> 1) | (1ull << 63)) >> lane_id; /* bit i: lane + 1 + i continues nothing */
+							n = 4u * (u32)__builtin_ctz((u32)above) + 4u;
+						}
+						vss_add<HASH>(tab, key0[0], n);
+					}
+				} else if (flat && !cont) { /* the head of a run: the next break above this lane ends it */
 					const u64 above = ((breaks >> 1) | (1ull << 63)) >> lane_id;
 					vss_add<HASH>(tab, key0[0], 4u * (u32)__ffsll((long long)above));
 				}
-				const bool nf = ok[k] && !flat;
-				const u64 rough = __ballot(nf);
 				if (rough != 0) { /* wave-uniform */
 					const u32 n3 = 3u * (u32)__popcll(rough);
 					if (nf) {
-						vss_add<HASH>(tab, key0[0], 1);
+						if (!VSS_RLE_LEAN)
+							vss_add<HASH>(tab, key0[0], 1);
 						u32 *slot = rle_scr + 3u * scope_lanes_below(rough);
 						slot[0] = p1;
 						slot[1] = p2;
@@ -569,6 +588,26 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 						       for (int k = 0; k < U; k++) {
 							       const u32 i0 = idx[k][0];
 							       const bool flat = ok[k] && ((i0 == idx[k][1]) & (i0 == idx[k][2]) & (i0 == idx[k][3]));
+							       if (VSS_RLE_LEAN) { /* round 6: the lean sequence of bin_rle above */
+								       const u32 tag = flat ? i0 : (0x40000000u | rk_lane); /* staged planes: a key may be zero -- so may a
+													      * DPP row's first lane's fill, hence the lane test below */
+								       const bool cont = tag == scope_lane_below0(tag) && (rk_lane & 15u) != 0u;
+								       const u64 breaks = ~__ballot(cont);
+								       if (ok[k] && !cont) {
+									       u32 n = 1u;
+									       if (flat) {
+										       const u64 above = ((breaks >> 1) | (1ull << 63)) >> rk_lane;
+										       n = 4u * (u32)__builtin_ctz((u32)above) + 4u;
+									       }
+									       vss_add<HASH>(tab, i0, n);
+									       if (!flat) {
+										       vss_add<HASH>(tab, idx[k][1], 1);
+										       vss_add<HASH>(tab, idx[k][2], 1);
+										       vss_add<HASH>(tab, idx[k][3], 1);
+									       }
+								       }
+								       continue;
+							       }
 							       const u32 tag = flat ? (i0 | 0x80000000u) : (0x40000000u | rk_lane);
 							       const u32 below = scope_lane_below(tag, 0u); /* every lane takes part (the DPP move's contract) */
 							       const bool cont = flat && tag == below && (rk_lane & (rk_run - 1u)) != 0u;
