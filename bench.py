@@ -108,12 +108,22 @@ def parse_args(argv=None):
                     help="let ranks share a GPU when there are fewer GPUs than ranks (the table sum then needs SCOPE_RCCL_LIBRARY "
                          "= tools/libshm_rccl_hip.so or --torch-reduce over gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--option", action="append", default=[], help="key=value passed to scope_ctx_set_option")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the per-rank plan of this command line (rows, launches, wire bytes, reduce path, streams) as one JSON line "
+                         "and exit: no device, no torch, no library")
     ap.add_argument("--lib", default=None, help="another build of libscope_hip.so (A/B of kernel variants; the line names it)")
     return ap.parse_args(argv)
 
 
 def main():
     args = parse_args()
+    if args.dry_run:
+        import json
+
+        from bench_launch import dry_run_plan
+
+        print(json.dumps(dry_run_plan(args)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launcher(args, sys.argv[1:]))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("BENCH_WORKER") and not os.environ.get("BENCH_SELF_LAUNCHED"):

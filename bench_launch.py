@@ -218,3 +218,65 @@ def launcher(args, argv):
         deadline = max(120.0, args.launch_timeout / 2)  # the later rungs get less: the whole ladder stays bounded
     print(failure_line(args, attempts, "bench.py started its own ranks"), flush=True)
     return 5
+
+
+def dry_run_plan(args, num_cu=256):
+    """`bench.py --gpus N --dry-run`: what an N-rank run WOULD do, rank by rank -- rows, launches, wire bytes, reduce path, streams,
+    the launcher's ladder -- computed from the same rules the run uses (row_tiles.tile_rows, the C-ABI's slices-per-frame rule,
+    the in-launch fold's bound) without touching a device, torch or the library.  The first real 8-GPU run can be held against
+    it field by field (`config.partition`, `config4.rows_of_this_rank`, `config.reduce`, `rccl.ranks_in_communicator`)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("row_tiles", os.path.join(os.path.dirname(os.path.abspath(__file__)), "obs-color-monitor_amd", "row_tiles.py"))
+    rt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rt)
+    n = args.gpus
+    if args.geometry:
+        w, h = (int(x) for x in args.geometry.lower().split("x"))
+    else:
+        w, h = (3840, 2160) if args.size == "4k" else (7680, 4320)
+    frames = args.frames or (64 if w * h <= 3840 * 2160 else 16)
+    table_bytes = {"vectorscope": 65536, "vectorscope_rgb": 65536, "histogram": 4096, "waveform": 256 * w * 4, "three_scope": 65536 + 4096 + 256 * w * 4}
+
+    def launch_shape(nf, units=1):
+        slices = max(1, min(256, num_cu // max(1, nf * units)))  # scope_api.hip: pick_slices
+        fold = 2 <= slices <= 4  # scope_device.h: VSS_FOLD_MAX
+        return {"workgroups": nf * slices, "slices_per_frame": slices, "threads_per_workgroup": 1024,
+                "partial_tables": "none (one slice per frame)" if slices == 1 else
+                                  ("sparse, added up INSIDE the launch by the frame's last-arriving workgroup" if fold else
+                                   "sparse + scope_sat_reduce_sparse_kernel")}
+
+    c4w, c4h = (int(x) for x in args.config4_geometry.lower().split("x"))
+    wl = args.workload
+    sums = wl in ("vectorscope", "vectorscope_rgb", "histogram") and n > 1 and not args.no_collective
+    wire_words = frames * (32768 if wl.startswith("vectorscope") else 1024)
+    ranks = []
+    for r in range(n):
+        r0, r1 = rt.tile_rows(c4h, r, n)
+        ranks.append({
+            "rank": r, "device": f"cuda:{r}" if not args.oversubscribe else "cuda:(rank mod GPUs)",
+            "headline": {"frames": frames, "tile": f"{w}x{h} (rows [{h * r}, {h * (r + 1)}) of a frame {n} times as tall: weak)",
+                         "bytes_read_per_step": frames * w * h * 4, **launch_shape(frames)},
+            "config4": {"rows": [r0, r1], "tile": f"{c4w}x{r1 - r0}", "frames": args.config4_frames,
+                        "bytes_read_per_step": args.config4_frames * c4w * (r1 - r0) * 4, **launch_shape(args.config4_frames)},
+        })
+    plan = {
+        "dry_run": True, "metric": METRIC, "n_gpus": n, "workload": wl, "scaling": "strong" if args.strong else "weak",
+        "value_is": "pixels all ranks reduced in exactly K steps / the slowest rank's time between barrier + synchronize (MAX over ranks)",
+        "steps": args.steps, "warmup": args.warmup,
+        "launch": {"how": "bench.py starts one subprocess per GPU itself (or supervises the ranks torch.distributed.run started)",
+                   "rendezvous": "127.0.0.1, gloo control plane on CPU tensors", "env": {"HSA_ENABLE_IPC_MODE_LEGACY": "0"},
+                   "deadline_s_per_attempt": args.launch_timeout,
+                   "ladder": ["C-ABI: scope_table_allreduce (RCCL, dlopen)"] + [" ".join(x) for x in reduce_ladder(args)[1:]]},
+        "table_sum": ({"what": f"in-place ncclAllReduce(sum, uint32) of {wire_words} words = {wire_words * 4} bytes per step per rank"
+                               + (" (two clamped bins per word, SCOPE_OUT_PACKED16 straight out of the accumulation), then unpack + clamp" if wl.startswith("vectorscope") else ""),
+                       "ranks_in_communicator_expected": n,
+                       "stream": "the accumulation's own stream" if args.serial_reduce else
+                                 "a second hipStream + scope context: the sum of step i runs under the accumulation of step i + 1 (two wire buffers, events both ways)",
+                       "config4_wire_bytes_per_step": args.config4_frames * 32768 * 4}
+                      if sums else {"what": "none" + (" (the waveform shards by column strip: no collective)" if wl == "waveform" else " (replicas)" if n > 1 else " (one rank)")}),
+        "table_bytes_out_per_frame": table_bytes.get(wl),
+        "ranks": ranks,
+    }
+    return plan

@@ -133,6 +133,8 @@ int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
  *                            and 16 (two replicas; four for a one-channel mask) for launches of a few frames (0), or fixed
  *   "fold" 0|1   the slices of a histogram frame meet inside the launch (atomics + last arrival) | partial tables + a second kernel
  *   "vss.sparse" 0|1   vectorscope partial tables hold only the 16-bin groups that are not empty
+ *   "vss.fold" 0|1     launches of 2 .. 4 workgroups per frame (the 64-frame batches) add a frame's partial vectorscope tables up inside
+ *                      the launch (the workgroup that arrives last) | in a second kernel
  *   "nt" 0|1     streaming (non-temporal) loads
  *   "slices"     workgroups per frame (0 = automatic) */
 int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value);

@@ -414,10 +414,15 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 				st = grow(ctx, &ctx->pmask, &ctx->pmask_bytes, (size_t)nf * slices * mask_block);
 			if (st)
 				return st;
+			/* a few slices per frame (the 64-frame batches: four): they meet inside the launch, no reduction kernel */
+			const ScopeVssFoldSink sink = {dst, ctx->tickets + SCOPE_MAX_FRAMES, packed ? 1 : 0};
+			const bool folded = mask_block && scope_vss_can_fold(slices, ctx->pmask, ctx->tn);
 			TIMED_LAUNCH(ctx, scope_launch_vss(fs, slices, fuse, colorspace, ctx->partial, mask_block ? ctx->pmask : NULL,
-							   ctx->tn, ctx->stream, tm_));
+							   ctx->tn, ctx->stream, tm_, folded ? &sink : NULL));
 			/* one partial per frame and a packed result: the "reduction" of one table is just the repacking */
-			if (mask_block)
+			if (folded)
+				;
+			else if (mask_block)
 				HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, dst, nf, slices, mask_block, packed,
 									    ctx->stream));
 			else
@@ -548,6 +553,7 @@ int run_dock(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t 
 		const uint32_t sw = scope_trio_strip_width(fs, (uint32_t)ctx->num_cu, ctx->tn);
 		const uint32_t slices = old_form ? scope_wvs_strips(width, 1) : scope_trio_slices(fs, (uint32_t)ctx->num_cu, sw);
 		const bool partials = slices > 1 || old_form; /* scope_dock_kernel always writes a sparse partial per strip */
+		bool folded = false; /* scope_trio_kernel with 2 .. 4 slices per frame: they meet inside the launch */
 		if (partials) {
 			st = grow(ctx, &ctx->partial, &ctx->partial_bytes, (size_t)nf * slices * SCOPE_VSS_BINS);
 			if (!st)
@@ -559,10 +565,13 @@ int run_dock(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t 
 			TIMED_LAUNCH(ctx, scope_launch_dock(fs, cw, colorspace, wvs_dst, his_dst ? &sink : NULL, ctx->partial, ctx->pmask,
 							    ctx->stream, tm_));
 		} else {
+			folded = slices > 1 && scope_vss_can_fold(slices, ctx->pmask, ctx->tn);
+			const ScopeVssFoldSink vsink = {vss_dst, ctx->tickets + SCOPE_MAX_FRAMES, 0};
 			TIMED_LAUNCH(ctx, scope_launch_trio(fs, slices, sw, cw, colorspace, wvs_dst, his_dst ? &sink : NULL,
-							    slices > 1 ? ctx->partial : vss_dst, ctx->pmask, ctx->stream, tm_, (uint32_t)ctx->tn.vss_rle));
+							    slices > 1 ? ctx->partial : vss_dst, ctx->pmask, ctx->stream, tm_, (uint32_t)ctx->tn.vss_rle,
+							    folded ? &vsink : NULL));
 		}
-		if (partials)
+		if (partials && !folded)
 			HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, vss_dst, nf, slices, mask_block, 0, ctx->stream));
 		launched = true;
 	}
@@ -765,8 +774,9 @@ int scope_ctx_create(int device, scope_ctx **out)
 		ok = hipEventCreateWithFlags(&ctx->acc_done[k], hipEventDisableTiming) == hipSuccess &&
 		     hipEventCreateWithFlags(&ctx->side_done[k], hipEventDisableTiming) == hipSuccess;
 	const size_t acc_bytes = (size_t)SCOPE_MAX_FRAMES * SCOPE_HIS_WORDS * sizeof(uint32_t);
-	ok = ok && hipMalloc((void **)&ctx->tickets, SCOPE_MAX_FRAMES * sizeof(uint32_t)) == hipSuccess &&
-	     hipMemsetAsync(ctx->tickets, 0, SCOPE_MAX_FRAMES * sizeof(uint32_t), ctx->stream) == hipSuccess &&
+	/* two sets of arrival tickets: the histogram's in-launch combine, and (behind it) the vectorscope's fold */
+	ok = ok && hipMalloc((void **)&ctx->tickets, 2 * SCOPE_MAX_FRAMES * sizeof(uint32_t)) == hipSuccess &&
+	     hipMemsetAsync(ctx->tickets, 0, 2 * SCOPE_MAX_FRAMES * sizeof(uint32_t), ctx->stream) == hipSuccess &&
 	     hipMalloc((void **)&ctx->his_acc, acc_bytes) == hipSuccess &&
 	     hipMemsetAsync(ctx->his_acc, 0, acc_bytes, ctx->stream) == hipSuccess &&
 	     hipStreamSynchronize(ctx->stream) == hipSuccess;
@@ -791,6 +801,7 @@ int scope_ctx_create(int device, scope_ctx **out)
 	ctx->tn.wvs_per_cu = 1;
 	ctx->tn.fold = 1;
 	ctx->tn.vss_sparse = 1;
+	ctx->tn.vss_fold = 1;
 	ctx->tn.nt_loads = 1;
 	ctx->tn.trio_strip = 0;
 	ctx->tn.vss_rle = 0;
@@ -934,6 +945,8 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.fold = value != 0;
 	else if (!strcmp(key, "vss.sparse"))
 		ctx->tn.vss_sparse = value != 0;
+	else if (!strcmp(key, "vss.fold"))
+		ctx->tn.vss_fold = value != 0;
 	else if (!strcmp(key, "wvs.per_cu"))
 		ctx->tn.wvs_per_cu = value;
 	else if (!strcmp(key, "wvs.persist"))

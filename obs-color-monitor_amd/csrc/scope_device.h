@@ -551,6 +551,132 @@ __device__ __forceinline__ void vss_clamp_pass(u32 *tab, u32 words = VSS_WORDS)
 	}
 }
 
+/* ------------------------------------------------------------------------------------------
+ * The vectorscope's tables leave a workgroup here (scope_vss_kernel, scope_trio_kernel).
+ *
+ *   slices == 1 (pmask NULL): the final clamped table, dst[frame].
+ *   otherwise a SPARSE partial -- only the 16-bin groups that hold a count, flagged in one mask byte per thread -- laid out for
+ *   scope_sat_reduce_sparse_kernel: group g of slice s is cell ((frame * 256 + g / 16) * slices + s) * 16 + g % 16.
+ *   ... and with fold.out set (round 6; launches of a few slices per frame: the 64-frame batches have four) the slices of a frame
+ *   meet INSIDE the launch: partials and masks are stored write-through (sc1), every storing wave drains, the workgroup takes the
+ *   frame's arrival ticket, and the workgroup that arrives last adds the other slices' flagged groups (sc1 loads, all of a
+ *   thread's in flight at once) to its own -- which it still holds in registers -- saturates, and writes the final table; the
+ *   ticket goes back to zero.  The hand-off is MI355X_MICROARCH.md's "16 B sc1 stores AND sc1 loads" form: no release or acquire
+ *   fence, no dependence on which XCDs the slices run on.  It takes scope_sat_reduce_sparse_kernel<1> (6.8 us + a launch boundary
+ *   per 318 us step of the headline) out of the call.  1024 threads per workgroup, at most VSS_FOLD_MAX slices.
+ * group(g, lo, hi): the eight table words (16 bins) of output group g, which is layout business of the caller. */
+#define VSS_FOLD_MAX 4u
+struct VssFold {
+	uint8_t *out;   /* final tables: uint8[frames][65536], or uint32[frames][32768] (packed16); NULL: no fold */
+	u32 *tickets;   /* [SCOPE_MAX_FRAMES], zero between launches */
+	u32 packed16;
+};
+
+template <typename Group>
+__device__ __forceinline__ void vss_write_out(Group &&group, u32 frame, u32 slice, u32 slices, uint8_t *dst, uint8_t *pmask, const VssFold &fold,
+					      u32 *lds_flag)
+{
+	const u32 unit = frame * slices + slice;
+	uint4 *out = (uint4 *)(dst + (size_t)unit * SCOPE_VSS_BINS);
+	const u32 cell0 = (frame * 256u * slices + slice) * 16u; /* this slice's first cell (16 bytes each) of the frame's block of partials */
+	const u32 mask_at = ((frame * (blockDim.x >> 4) + (threadIdx.x >> 4)) * slices + slice) * 16u + (threadIdx.x & 15u);
+	const bool folding = fold.out != NULL && pmask != NULL; /* uniform */
+	const scope_buf pbuf = scope_buf_make(dst, folding ? SCOPE_MAX_FRAMES * VSS_FOLD_MAX * SCOPE_VSS_BINS : 0u);
+	const scope_buf mbuf = scope_buf_make(pmask, folding ? SCOPE_MAX_FRAMES * VSS_FOLD_MAX * 1024u : 0u);
+	scope_u4 mine[4]; /* folding: this thread's four clamped groups */
+	u32 wrote = 0;
+	/* thread t takes the groups t + k * blockDim.x: four with 1024 threads (whose clamped values the fold keeps, hence the unrolled
+	 * first four), eight with 512 (the most a mask byte covers), more only for the dense tables of smaller workgroups */
+	auto emit = [&](u32 g, u32 k) {
+		uint4 lo, hi;
+		group(g, lo, hi);
+		const scope_u4 t = {vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y), vss_clamp_pair(hi.z, hi.w)};
+		if (!pmask) {
+			out[g] = make_uint4(t.x, t.y, t.z, t.w);
+		} else if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0) {
+			const u32 cell = cell0 + (g >> 4) * slices * 16u + (g & 15u);
+			if (folding) {
+				scope_buf_store16_sc1(pbuf, cell * 16u, t);
+			} else {
+				/* streaming store: a partial is read once, by other CUs; leaving it dirty in this XCD's L2 only moves the
+				 * write-back to the end of the kernel */
+				const scope_v4 tv = {t.x, t.y, t.z, t.w};
+				__builtin_nontemporal_store(tv, (scope_v4 *)dst + cell);
+			}
+			wrote |= 1u << k;
+		}
+		return t;
+	};
+#pragma unroll
+	for (u32 k = 0; k < 4u; k++) {
+		const u32 g = threadIdx.x + k * blockDim.x;
+		mine[k] = scope_u4{0u, 0u, 0u, 0u};
+		if (g < SCOPE_VSS_BINS / 16)
+			mine[k] = emit(g, k);
+	}
+	for (u32 k = 4u, g = threadIdx.x + 4u * blockDim.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++)
+		(void)emit(g, k);
+	/* the masks likewise: byte t of slice s is ((frame * blockDim / 16 + t / 16) * slices + s) * 16 + t % 16 */
+	if (pmask && !folding)
+		pmask[mask_at] = (uint8_t)wrote;
+	if (!folding)
+		return;
+	scope_buf_store1_sc1(mbuf, mask_at, wrote);
+	if (!scope_last_arrival(&fold.tickets[frame], slices, lds_flag)) /* every wave drains its stores, barrier, one agent-scope ticket */
+		return;
+	/* the frame's last arrival: the other slices' partials are in memory.  Every load of this thread is issued before the first
+	 * is used (a group nobody flagged re-reads cell 0 of the partials and is dropped). */
+	u32 mb[VSS_FOLD_MAX];
+#pragma unroll
+	for (u32 s = 0; s < VSS_FOLD_MAX; s++)
+		mb[s] = (s < slices && s != slice) ? scope_buf_load1_sc1(mbuf, mask_at + (s - slice) * 16u) : 0u;
+	scope_u4 q[4][VSS_FOLD_MAX];
+#pragma unroll
+	for (u32 kk = 0; kk < 4u; kk++) {
+		const u32 g = threadIdx.x + kk * 1024u;
+#pragma unroll
+		for (u32 s = 0; s < VSS_FOLD_MAX; s++) {
+			const bool on = ((mb[s] >> kk) & 1u) != 0u;
+			q[kk][s] = scope_buf_load16_sc1(pbuf, on ? ((frame * 256u * slices + s) * 16u + (g >> 4) * slices * 16u + (g & 15u)) * 16u : 0u);
+			if (!on)
+				q[kk][s] = scope_u4{0u, 0u, 0u, 0u};
+		}
+	}
+#pragma unroll
+	for (u32 kk = 0; kk < 4u; kk++) {
+		const u32 g = threadIdx.x + kk * 1024u;
+		/* sixteen bytes <= 255 each from up to four tables: sums in 16-bit lanes (even bytes, odd bytes), then the clamp */
+		u32 ev[4] = {mine[kk].x & 0x00ff00ffu, mine[kk].y & 0x00ff00ffu, mine[kk].z & 0x00ff00ffu, mine[kk].w & 0x00ff00ffu};
+		u32 od[4] = {(mine[kk].x >> 8) & 0x00ff00ffu, (mine[kk].y >> 8) & 0x00ff00ffu, (mine[kk].z >> 8) & 0x00ff00ffu, (mine[kk].w >> 8) & 0x00ff00ffu};
+#pragma unroll
+		for (u32 s = 0; s < VSS_FOLD_MAX; s++) {
+			ev[0] += q[kk][s].x & 0x00ff00ffu, od[0] += (q[kk][s].x >> 8) & 0x00ff00ffu;
+			ev[1] += q[kk][s].y & 0x00ff00ffu, od[1] += (q[kk][s].y >> 8) & 0x00ff00ffu;
+			ev[2] += q[kk][s].z & 0x00ff00ffu, od[2] += (q[kk][s].z >> 8) & 0x00ff00ffu;
+			ev[3] += q[kk][s].w & 0x00ff00ffu, od[3] += (q[kk][s].w >> 8) & 0x00ff00ffu;
+		}
+		u32 b[16];
+#pragma unroll
+		for (u32 j = 0; j < 4; j++) {
+			b[4 * j + 0] = min(ev[j] & 0xffffu, 255u);
+			b[4 * j + 1] = min(od[j] & 0xffffu, 255u);
+			b[4 * j + 2] = min(ev[j] >> 16, 255u);
+			b[4 * j + 3] = min(od[j] >> 16, 255u);
+		}
+		if (!fold.packed16) {
+			((uint4 *)fold.out)[(size_t)frame * (SCOPE_VSS_BINS / 16) + g] =
+				make_uint4(b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24, b[4] | b[5] << 8 | b[6] << 16 | b[7] << 24,
+					   b[8] | b[9] << 8 | b[10] << 16 | b[11] << 24, b[12] | b[13] << 8 | b[14] << 16 | b[15] << 24);
+		} else { /* the wire format of the multi-GPU sum: two bins per 32-bit word, lo | hi << 16 */
+			uint4 *wire = (uint4 *)fold.out + ((size_t)frame * (SCOPE_VSS_BINS / 16) + g) * 2;
+			wire[0] = make_uint4(b[0] | b[1] << 16, b[2] | b[3] << 16, b[4] | b[5] << 16, b[6] | b[7] << 16);
+			wire[1] = make_uint4(b[8] | b[9] << 16, b[10] | b[11] << 16, b[12] | b[13] << 16, b[14] | b[15] << 16);
+		}
+	}
+	if (threadIdx.x == 0)
+		__hip_atomic_store(&fold.tickets[frame], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* HIS: the histogram of the same channels comes out of this pass for nothing.  A strip's table IS a histogram per
  * column -- exact 16-bit counts until the flush clamps them -- so the flush, which reads every counter anyway, also
  * adds up each value's 64 columns (the same texels pass the same alpha test in both loops, src/waveform.c:247-248 and

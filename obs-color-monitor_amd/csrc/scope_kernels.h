@@ -59,6 +59,8 @@ struct ScopeTuning {
 	int fold;            /* 1: the slices of a histogram frame are combined inside the launch (atomics + last arrival); 0: partial
 			      * tables + scope_launch_sum_reduce */
 	int vss_sparse;      /* 1: vectorscope partials are written sparse (flagged 16-bin groups only) */
+	int vss_fold;        /* 1: launches of 2 .. 4 slices per frame (the 64-frame batches) combine a frame's partial tables inside the
+			      * launch (last arrival; scope_device.h, vss_write_out) instead of in scope_sat_reduce_sparse_kernel */
 	int wvs_per_cu;      /* cap on persistent waveform workgroups per CU (0 = as many as fit); 1 keeps ~32 KiB of
 			      * loads in flight per CU, which is what the HBM likes best (+5 % for 1-2 channels) */
 	int wvs_persist;     /* 1: one resident set of workgroups walks all units with a continuous load stream */
@@ -95,8 +97,19 @@ hipError_t scope_launch_k0(const uint8_t *src, uint32_t src_linesize, uint8_t *d
  * partials for scope_launch_sat_reduce).  pmask = uint8[n_frames][slices][scope_vss_mask_block(tn)]: SPARSE partials
  * -- only the 16-bin groups holding a count are written and flagged -- for scope_launch_sat_reduce_sparse.
  * fuse_k0: planes are RGB, U/V computed in-kernel. */
+/* fold != NULL (scope_vss_can_fold: sparse partials, 2 .. 4 slices per frame, 1024-thread workgroups): the slices of a frame meet
+ * INSIDE the launch -- the workgroup that arrives last at the frame's ticket adds the other slices' partials to its own and writes
+ * the final table to fold->out[frame] (uint8[65536], or uint32[32768] with packed16); no reduction kernel follows.  tickets =
+ * uint32[SCOPE_MAX_FRAMES], zero before the first launch and left zero by every launch. */
+struct ScopeVssFoldSink {
+	uint8_t *out;
+	uint32_t *tickets;
+	int packed16;
+};
+bool scope_vss_can_fold(uint32_t slices, const uint8_t *pmask, const ScopeTuning &tn);
 hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
-			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st, const ScopeTiming *tm = NULL);
+			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st, const ScopeTiming *tm = NULL,
+			    const ScopeVssFoldSink *fold = NULL);
 /* Threads per workgroup of the vectorscope launch = bytes per sparse-partial mask; 0: this tuning cannot write masks. */
 uint32_t scope_vss_mask_block(const ScopeTuning &tn);
 
@@ -154,7 +167,8 @@ uint32_t scope_trio_strip_width(const ScopeFrameSet &fs, uint32_t num_cu, const 
 uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu, uint32_t strip_width);
 hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t strip_width, uint32_t chmask, int colorspace,
 			     uint8_t *wvs_dst, const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st,
-			     const ScopeTiming *tm = NULL, uint32_t rle_force = 0 /* the vectorscope's run-length form on every slot (tests) */);
+			     const ScopeTiming *tm = NULL, uint32_t rle_force = 0 /* the vectorscope's run-length form on every slot (tests) */,
+			     const ScopeVssFoldSink *fold = NULL /* 2 .. 4 slices: the frame's vectorscope partials meet inside the launch, as scope_launch_vss */);
 
 /* out[f][i] = min(sum_s part[f][s][i], 255), i < len (len % 16 == 0, slices <= 256).  packed16: the result is written
  * as uint32[len / 2], two bins per word (lo | hi << 16) -- the wire format of the multi-GPU table sum. */

@@ -141,6 +141,9 @@ __device__ __forceinline__ u32 scope_slice_begin_cells(u32 total, u32 s, u32 S)
 }
 
 #ifndef WVS_PRIO
+#ifndef WVS_STORE_NT
+#define WVS_STORE_NT 1 /* the batch form's table stores: 1 streaming (nt), 0 plain -- the write-side A/B of round 6 */
+#endif
 #define WVS_PRIO 1 /* the same inside scope_wvs_kernel's units, narrow-strip form only (see there); 0: A/B */
 #endif
 #ifndef SCOPE_STREAM_PRIO
@@ -674,7 +677,7 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 template <int U, bool NT, int MERGE, bool FUSE, int HASH>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs, u32 slices, u32 ncols_a, u32 ncols_b,
 							       u32 xbyte_b, u32 glog2, u32 rle_force, ScopeK0 k0_arg, uint8_t *dst,
-							       uint8_t *pmask)
+							       uint8_t *pmask, VssFold fold)
 {
 	const ScopeK0 k0 = FUSE ? scope_k0_pinned(k0_arg, true, false) : k0_arg;
 	u32 *tab = scope_lds;
@@ -709,34 +712,18 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_vss_kernel(ScopeFrameSet fs
 	SCOPE_STAMP(1);
 
 	/* flush: 16 consecutive bins of one row per lane per step = 8 table words, which the swizzle (a multiple of eight
-	 * words) leaves contiguous: two 16-byte LDS reads, one coalesced 16-byte store */
-	uint4 *out = (uint4 *)(dst + (size_t)unit * SCOPE_VSS_BINS);
-	/* sparse partials are stored by block of 16 groups (256 bins = one table row), the slices of a frame side by side:
-	 * group g of slice s is cell ((frame * 256 + g / 16) * slices + s) * 16 + g % 16, so that what one workgroup of
-	 * the reduction reads -- a row of every slice -- is one contiguous run instead of 256 B out of every 64 KiB */
-	uint4 *outs = (uint4 *)dst + ((size_t)frame * 256u * slices + slice) * 16u;
-	u32 wrote = 0, k = 0;
-	for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
-		const u32 row = 255u - (g >> 4); /* table row v of output row g >> 4 */
-		const u32 w0 = HASH == 2 ? row * VSS_PITCH2 + ((g & 15u) << 3)
-					 : (row << 7) + (((g & 15u) << 3) ^ (HASH == 1 ? 0u : ((row & 15u) << 3)));
-		const uint4 lo = *(const uint4 *)&tab[w0], hi = *(const uint4 *)&tab[w0 + 4];
-		if (!pmask) {
-			out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
-					    vss_clamp_pair(hi.z, hi.w));
-		} else if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0) {
-			/* streaming store: a partial is read once, by other CUs; leaving it dirty in this XCD's L2 only
-			 * moves the write-back to the end of the kernel */
-			const scope_v4 t = {vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
-					    vss_clamp_pair(hi.z, hi.w)};
-			__builtin_nontemporal_store(t, (scope_v4 *)outs + ((size_t)(g >> 4) * slices * 16u + (g & 15u)));
-			wrote |= 1u << k;
-		}
-	}
-	/* the masks likewise: byte t of slice s is ((frame * blockDim / 16 + t / 16) * slices + s) * 16 + t % 16 */
-	if (pmask)
-		pmask[(((size_t)frame * (blockDim.x >> 4) + (threadIdx.x >> 4)) * slices + slice) * 16u + (threadIdx.x & 15u)] =
-			(uint8_t)wrote;
+	 * words) leaves contiguous: two 16-byte LDS reads, one coalesced 16-byte store.  Final table, sparse partial (blocked by table
+	 * row: what one workgroup of the reduction reads -- a row of every slice -- is one contiguous run), or the slices of the
+	 * frame meeting inside the launch: vss_write_out (scope_device.h).  The arrival flag is the LDS word behind the table. */
+	vss_write_out(
+		[&](u32 g, uint4 &lo, uint4 &hi) {
+			const u32 row = 255u - (g >> 4); /* table row v of output row g >> 4 */
+			const u32 w0 = HASH == 2 ? row * VSS_PITCH2 + ((g & 15u) << 3)
+						 : (row << 7) + (((g & 15u) << 3) ^ (HASH == 1 ? 0u : ((row & 15u) << 3)));
+			lo = *(const uint4 *)&tab[w0];
+			hi = *(const uint4 *)&tab[w0 + 4];
+		},
+		frame, slice, slices, dst, pmask, fold, &tab[VssTable<HASH>::words]);
 	SCOPE_STAMP(2);
 }
 
@@ -1244,7 +1231,10 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 				u32 o[4], n[3];
 				gather(value, g, o, n);
 				const scope_v4 t = {o[0], o[1], o[2], o[3]};
-				__builtin_nontemporal_store(t, ocol + (size_t)(255u - value) * (W >> 2));
+				if (WVS_STORE_NT)
+					__builtin_nontemporal_store(t, ocol + (size_t)(255u - value) * (W >> 2));
+				else
+					ocol[(size_t)(255u - value) * (W >> 2)] = t; /* plain (cached) stores: measurement only, round 6 */
 				if (HIS)
 					tally(value, xg < groups, n); /* lanes past the right edge repeat a column group */
 			}
@@ -1782,19 +1772,21 @@ struct VssArgs {
 	Regions rg;
 	ScopeK0 k0;
 	uint8_t *dst, *pmask;
+	VssFold fold;
 	hipStream_t st;
 	const ScopeTiming *tm;
 };
 
 template <int U, bool NT, int MERGE, bool FUSE, int HASH> hipError_t vss_variant(const VssArgs *a)
 {
-	constexpr u32 lds = VssTable<HASH>::words * 4u + (FUSE && HASH == 2 && MERGE == 3 && VSS_RLE_IN(U) ? VSS_RLE_SCRATCH_BYTES : 0u);
+	/* behind the table: the run-length mode's scratch rows, or (at least) the word the in-launch fold's arrival flag lives in */
+	constexpr u32 lds = VssTable<HASH>::words * 4u + (FUSE && HASH == 2 && MERGE == 3 && VSS_RLE_IN(U) ? VSS_RLE_SCRATCH_BYTES : 16u);
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_vss_kernel<U, NT, MERGE, FUSE, HASH>,
 					   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	SCOPE_LAUNCH((scope_vss_kernel<U, NT, MERGE, FUSE, HASH>), dim3(a->fs->n_frames * a->slices), dim3(a->block),
 		     lds, a->st, a->tm, *a->fs, a->slices, a->rg.ncols_a, a->rg.ncols_b, a->rg.xbyte_b, a->glog2, a->rle_force, a->k0,
-		     a->dst, a->pmask);
+		     a->dst, a->pmask, a->fold);
 	return hipGetLastError();
 }
 
@@ -2043,8 +2035,13 @@ uint32_t scope_vss_mask_block(const ScopeTuning &tn)
 	return b >= 512u ? b : 0u; /* a thread's groups must fit the 8 bits of its mask byte */
 }
 
+bool scope_vss_can_fold(uint32_t slices, const uint8_t *pmask, const ScopeTuning &tn)
+{
+	return tn.vss_fold && pmask && slices >= 2 && slices <= VSS_FOLD_MAX && scope_block(tn.vss_block) == SCOPE_BLOCK;
+}
+
 hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k0, int colorspace, uint8_t *dst,
-			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st, const ScopeTiming *tm)
+			    uint8_t *pmask, const ScopeTuning &tn, hipStream_t st, const ScopeTiming *tm, const ScopeVssFoldSink *fold)
 {
 	/* Small launches -- one to a dozen frames, >= 12 workgroups per frame -- give every workgroup well under a megabyte:
 	 * cutting that into 8 lane-group streams leaves runs of a few KiB per stream and the memory system answers
@@ -2063,8 +2060,11 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 	const int unroll = fuse_k0 ? fused_unroll : (tn.vss_unroll > 0 ? tn.vss_unroll : (small ? 2 : 4));
 	if (pmask && !scope_vss_mask_block(tn))
 		return hipErrorInvalidValue;
+	if (fold && !scope_vss_can_fold(slices, pmask, tn))
+		return hipErrorInvalidValue;
+	const VssFold vf = fold ? VssFold{fold->out, fold->tickets, fold->packed16 ? 1u : 0u} : VssFold{NULL, NULL, 0u};
 	const VssArgs a = {&fs, slices, glog2, scope_block(tn.vss_block), tn.vss_rle != 0 ? 1u : 0u, split_regions(fs), scope_k0_matrix(colorspace),
-			   dst, pmask, st, tm};
+			   dst, pmask, vf, st, tm};
 	return vss_pick(unroll, tn.nt_loads, tn.vss_merge, fuse_k0, fuse_k0 ? fused_hash : tn.vss_hash, &a);
 }
 

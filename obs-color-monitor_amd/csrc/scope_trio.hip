@@ -337,7 +337,7 @@ template <int HASH, bool ALLV> __device__ __forceinline__ void trio_rle_pair(u32
 
 template <int CH, bool HIS, int SW>
 __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet fs, u32 strips, u32 slices, ScopeK0 k0_arg,
-								uint8_t *wvs_dst, ScopeWvsHis his, uint8_t *vss_dst, uint8_t *vss_mask, u32 rle_force)
+								uint8_t *wvs_dst, ScopeWvsHis his, uint8_t *vss_dst, uint8_t *vss_mask, u32 rle_force, VssFold fold)
 {
 	const ScopeK0 k0 = scope_k0_pinned(k0_arg, true, false);
 	constexpr u32 slot1 = (CH & 1), slot2 = slot1 + ((CH >> 1) & 1), nch = slot2 + ((CH >> 2) & 1);
@@ -743,15 +743,14 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 #undef TRIO_ISSUE
 #undef TRIO_OK
 
-	/* ---- the slice's vectorscope table: final (one slice per frame) or a sparse partial, as scope_vss_kernel ---------- */
-	{
-		const u32 unit = frame * slices + slice;
-		uint4 *out = (uint4 *)(vss_dst + (size_t)unit * SCOPE_VSS_BINS);
-		uint4 *outs = (uint4 *)vss_dst + ((size_t)frame * 256u * slices + slice) * 16u;
-		u32 wrote = 0, k = 0;
-		for (u32 g = threadIdx.x; g < SCOPE_VSS_BINS / 16; g += blockDim.x, k++) {
+	/* ---- the slice's vectorscope table: final (one slice per frame), a sparse partial, or the frame's slices meeting inside the
+	 * launch -- as scope_vss_kernel: vss_write_out (scope_device.h).  The arrival flag lives in the waveform table's space (read
+	 * out by now; the histogram's hand-off below takes the same space behind a barrier of its own). ---------- */
+	vss_write_out(
+		[&](u32 g, uint4 &lo, uint4 &hi) {
 			const u32 row = 255u - (g >> 4);
-			uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+			lo = make_uint4(0, 0, 0, 0);
+			hi = lo;
 			if (TRIO_HASH == 3) {
 				/* output group (row, k) = bins u in [16 k, 16 k + 15] = words 8 k - 4 .. 8 k + 3 of table row `row` - 16; what lies
 				 * outside the table (rows 0..15 and 241..255, u < 8, u >= 240) no colour reaches: zero */
@@ -776,20 +775,8 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 				lo = *(const uint4 *)&vt[w0];
 				hi = *(const uint4 *)&vt[w0 + 4];
 			}
-			if (!vss_mask) {
-				out[g] = make_uint4(vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
-						    vss_clamp_pair(hi.z, hi.w));
-			} else if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0) {
-				const scope_v4 t = {vss_clamp_pair(lo.x, lo.y), vss_clamp_pair(lo.z, lo.w), vss_clamp_pair(hi.x, hi.y),
-						    vss_clamp_pair(hi.z, hi.w)};
-				__builtin_nontemporal_store(t, (scope_v4 *)outs + ((size_t)(g >> 4) * slices * 16u + (g & 15u)));
-				wrote |= 1u << k;
-			}
-		}
-		if (vss_mask)
-			vss_mask[(((size_t)frame * (blockDim.x >> 4) + (threadIdx.x >> 4)) * slices + slice) * 16u + (threadIdx.x & 15u)] =
-				(uint8_t)wrote;
-	}
+		},
+		frame, slice, slices, vss_dst, vss_mask, fold, &tab[TRIO_WVS_BASE / 4u + 8u]);
 	if (HIS) {
 		/* the slice's totals -> the frame's accumulator, then the arrival ticket; the workgroup that completes the frame moves the
 		 * sums out and leaves accumulator and ticket zero.  The column groups of a value meet in LDS first (the waveform
@@ -837,6 +824,7 @@ struct TrioArgs {
 	ScopeWvsHis his;
 	uint8_t *vss_dst, *vss_mask;
 	u32 rle_force;
+	VssFold fold;
 	hipStream_t st;
 	const ScopeTiming *tm;
 };
@@ -848,7 +836,7 @@ template <int CH, bool HIS, int SW> hipError_t trio_variant(const TrioArgs *a)
 	if (!a)
 		return hipFuncSetAttribute((const void *)scope_trio_kernel<CH, HIS, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	SCOPE_LAUNCH((scope_trio_kernel<CH, HIS, SW>), dim3(a->fs->n_frames * a->slices), dim3(SCOPE_BLOCK), lds, a->st, a->tm, *a->fs,
-		     a->strips, a->slices, a->k0, a->wvs_dst, a->his, a->vss_dst, a->vss_mask, a->rle_force);
+		     a->strips, a->slices, a->k0, a->wvs_dst, a->his, a->vss_dst, a->vss_mask, a->rle_force, a->fold);
 	return hipGetLastError();
 }
 template <bool HIS, int SW> hipError_t trio_pick_ch(u32 chmask, const TrioArgs *a)
@@ -953,16 +941,19 @@ uint32_t scope_trio_slices(const ScopeFrameSet &fs, uint32_t num_cu, uint32_t st
 
 hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t strip_width, uint32_t chmask, int colorspace,
 			     uint8_t *wvs_dst, const ScopeHisSink *his, uint8_t *vss_dst, uint8_t *vss_mask, hipStream_t st,
-			     const ScopeTiming *tm, uint32_t rle_force)
+			     const ScopeTiming *tm, uint32_t rle_force, const ScopeVssFoldSink *fold)
 {
 	if ((chmask & 7u) == 0 || slices == 0 || slices > 256u || (slices > 1 && !vss_mask) || (strip_width != 16u && strip_width != 32u))
 		return hipErrorInvalidValue;
 	if (TRIO_COMPACT && !trio_chroma_fits(scope_k0_matrix(colorspace)))
 		return hipErrorInvalidValue; /* never a silent write outside the compact table */
+	if (fold && (slices < 2 || slices > VSS_FOLD_MAX || !vss_mask))
+		return hipErrorInvalidValue;
+	const VssFold vf = fold ? VssFold{fold->out, fold->tickets, fold->packed16 ? 1u : 0u} : VssFold{NULL, NULL, 0u};
 	ScopeWvsHis h = {NULL, NULL, NULL, 0};
 	if (his)
 		h = {his->acc, his->tickets, his->out, his->chmask & chmask & 7u};
 	const TrioArgs a = {&fs, (fs.width + strip_width - 1u) / strip_width, slices, scope_k0_matrix(colorspace), wvs_dst, h, vss_dst,
-			    slices > 1 ? vss_mask : NULL, rle_force, st, tm};
+			    slices > 1 ? vss_mask : NULL, rle_force, vf, st, tm};
 	return his ? trio_pick_sw<true>(strip_width, chmask, &a) : trio_pick_sw<false>(strip_width, chmask, &a);
 }

@@ -67,6 +67,32 @@ template <bool NT> static inline scope_u2 scope_buf_load2(scope_buf buf, unsigne
 	return scope_u2{p[0], p[1]};
 }
 
+/* the hand-off vocabulary: the emulation's memory is one coherent array */
+struct scope_u4 {
+	unsigned x, y, z, w;
+};
+static inline void scope_buf_store16_sc1(scope_buf buf, unsigned off, scope_u4 v)
+{
+	if ((unsigned long long)off + 16 <= buf.bytes)
+		__builtin_memcpy((unsigned char *)buf.base + off, &v, 16);
+}
+static inline scope_u4 scope_buf_load16_sc1(scope_buf buf, unsigned off)
+{
+	scope_u4 v = {0, 0, 0, 0};
+	if ((unsigned long long)off + 16 <= buf.bytes)
+		__builtin_memcpy(&v, buf.base + off, 16);
+	return v;
+}
+static inline void scope_buf_store1_sc1(scope_buf buf, unsigned off, unsigned byte)
+{
+	if (off < buf.bytes)
+		((unsigned char *)buf.base)[off] = (unsigned char)byte;
+}
+static inline unsigned scope_buf_load1_sc1(scope_buf buf, unsigned off)
+{
+	return off < buf.bytes ? buf.base[off] : 0u;
+}
+
 static inline unsigned scope_perm(unsigned hi, unsigned lo, unsigned sel)
 {
 	const unsigned long long src = ((unsigned long long)hi << 32) | lo;

@@ -11,7 +11,7 @@ DISTS = {1: "uniform", 2: "concentrated", 3: "flat", 4: "bars", 5: "alpha_holes"
 COMPONENTS = (0x07, 0x20, 0x50, 0x70, 0x01, 0x02, 0x04, 0x13)
 
 
-DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 0, "vss.hash": 0, "vss.fused_hash": -1, "vss.groups": -1, "his.unroll": 0, "wvs.wide": 1, "wvs.strip": 0, "wvs.deep": 1, "dock": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.block": 0, "his.block": 0,
+DEFAULTS = {"vss.merge": 3, "vss.unroll": 0, "vss.fused_unroll": 0, "vss.hash": 0, "vss.fused_hash": -1, "vss.groups": -1, "his.unroll": 0, "wvs.wide": 1, "wvs.strip": 0, "wvs.deep": 1, "dock": 1, "wvs.persist": 1, "wvs.per_cu": 1, "fold": 1, "vss.sparse": 1, "vss.fold": 1, "vss.block": 0, "his.block": 0,
             "nt": 1, "slices": 0, "trio.strip": 0, "vss.rle": 0}
 
 
@@ -614,6 +614,57 @@ def check_three_scopes_dev(ctx, oracle, to_dev, to_host, w, h, dists, wc=0x07, h
             assert_same(vss[f], oracle.vectorscope(yuv, w), "dock vectorscope " + tag)
             assert_same(wvs[f], oracle.waveform(rgb, yuv, w, wc), f"dock waveform {wc:#x} " + tag)
             assert_same(his[f], oracle.histogram_counts(rgb, yuv, w, hc), f"dock histogram {hc:#x} " + tag)
+
+
+def check_vectorscope_fold(ctx, oracle, to_dev, to_host, w, h, dists, launches=3, linesize=None):
+    """The in-launch fold of the vectorscope's partial tables (vss_write_out, round 6): launches of 2, 3 and 4 slices per frame --
+    staged planes, fused K0, the packed wire format, the three-scope kernel -- against the oracle AND against the same launch with
+    vss.fold = 0 (partials + the reduction kernel), several launches in a row into fresh tables (the arrival tickets come back to
+    zero; a stale partial of the launch before would show), one slice count after the other on ONE context (the partial buffers are
+    reused with another layout)."""
+    import numpy as np
+
+    pairs = [frames(oracle, w, h, d, linesize, seed=600 + i) if not isinstance(d, dict) else None for i, d in enumerate(dists)]
+    for i, d in enumerate(dists):
+        if isinstance(d, dict):
+            rgb = screen_frame(w, h, 700 + i, linesize=linesize, **d)
+            pairs[i] = (rgb, oracle.rgb_to_yuv(rgb, w, 2))
+    n = len(pairs)
+    ls = pairs[0][0].shape[1]
+    want = [oracle.vectorscope(yuv, w) for _, yuv in pairs]
+    want_wvs = [oracle.waveform(r, y, w, 0x07) for r, y in pairs] if w % 4 == 0 else None
+    keep_rgb, a_rgb = to_dev(np.concatenate([p[0].reshape(-1) for p in pairs]))  # (the handles own the memory)
+    keep_yuv, a_yuv = to_dev(np.concatenate([p[1].reshape(-1) for p in pairs]))
+    b_yuv = ctx._batch([a_yuv + i * h * ls for i in range(n)], ls, w, h, False, 2)
+    b_rgb = ctx._batch([a_rgb + i * h * ls for i in range(n)], ls, w, h, True, 2)
+    for slices in (2, 4, 3):
+        for fold in (1, 0):
+            with options(ctx, **{"slices": slices, "vss.fold": fold}):
+                for rep in range(launches):
+                    tag = f"{w}x{h} slices {slices} fold {fold} launch {rep}"
+                    for name, b in (("staged", b_yuv), ("fused", b_rgb)):
+                        ho, ao = to_dev(np.full(n * 65536, 0xEE, np.uint8))
+                        ctx.vectorscope_batch_dev(b, ao)
+                        got = to_host(ho).reshape(n, 256, 256)
+                        for f in range(n):
+                            assert_same(got[f], want[f], f"vectorscope fold {name} frame {f} {tag}")
+                    hp, ap = to_dev(np.full(n * 32768 * 4, 0xEE, np.uint8))
+                    ctx.vectorscope_batch_dev(b_yuv, ap, packed16=True)
+                    wire = to_host(hp).view(np.uint32).reshape(n, 32768)
+                    for f in range(n):
+                        flat = want[f].reshape(-1).astype(np.uint32)
+                        assert_same(wire[f], flat[0::2] | (flat[1::2] << 16), f"vectorscope fold packed frame {f} {tag}")
+                    if w % 4 == 0:
+                        hv, av = to_dev(np.full(n * 65536, 0xEE, np.uint8))
+                        hw, aw = to_dev(np.full(n * 256 * w * 4, 0xEE, np.uint8))
+                        hh, ah = to_dev(np.full(n * 4096, 0xEE, np.uint8))
+                        ctx.three_scopes_batch_dev(b_rgb, 0x07, 0x07, av, aw, ah)
+                        got = to_host(hv).reshape(n, 256, 256)
+                        wv = to_host(hw).reshape(n, 256, w, 4)
+                        for f in range(n):
+                            assert_same(got[f], want[f], f"three scopes: vectorscope fold frame {f} {tag}")
+                            assert_same(wv[f], want_wvs[f], f"three scopes: waveform beside the fold frame {f} {tag}")
+    del keep_rgb, keep_yuv
 
 
 def check_vectorscope_side_reduce(ctx, oracle, to_dev, to_host, w, h, dists, calls=12, fuse=False):

@@ -225,3 +225,32 @@ def test_gpus8_one_hung_rank_still_prints_a_line(shm_rccl):
     attempts = d["launcher"]["attempts"]
     assert len(attempts) == 2 and attempts[0]["failure"] and attempts[1]["failure"] is None and attempts[1]["extra_args"] == ["--torch-reduce"]
     assert d["n_gpus"] == 8 and d["config"]["reduce"].startswith("torch.distributed") and d["parity"].startswith("bit-exact")
+
+
+def test_dry_run_prints_the_plan_without_a_device(shm_rccl):
+    """`bench.py --gpus 8 --dry-run`: one JSON line, every rank's rows / launches / wire bytes / reduce path, no device touched (it
+    runs where there is none) -- and the plan agrees with what a real (emulated) N = 2 run then reports."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], env=clean_env(), capture_output=True, text=True,
+                         timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    p = json.loads(lines[0])
+    assert p["dry_run"] is True and p["n_gpus"] == 8 and len(p["ranks"]) == 8 and p["scaling"] == "weak"
+    assert [r["config4"]["rows"] for r in p["ranks"]] == [[540 * r, 540 * (r + 1)] for r in range(8)]  # BASELINE config 4's row tiles
+    assert all(r["headline"]["frames"] == 64 and r["headline"]["slices_per_frame"] == 4 for r in p["ranks"])
+    assert "INSIDE the launch" in p["ranks"][0]["headline"]["partial_tables"]
+    assert p["table_sum"]["ranks_in_communicator_expected"] == 8 and "ncclAllReduce" in p["table_sum"]["what"]
+    assert p["table_sum"]["config4_wire_bytes_per_step"] == 16 * 32768 * 4
+    assert p["launch"]["ladder"] == ["C-ABI: scope_table_allreduce (RCCL, dlopen)", "--torch-reduce", "--no-collective"]
+    # the same command line shape at N = 2 on the emulation: the plan's rows and communicator size are what the run reports
+    args2 = ["--gpus", "2", *SMALL, *C4]
+    plan = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args2, "--dry-run"], env=clean_env(), capture_output=True,
+                                     text=True, timeout=120, cwd=ROOT).stdout)
+    rc, d, err = run_bench(args2, clean_env())
+    assert rc == 0, err[-3000:]
+    assert d["config4"]["rows_of_this_rank"] == plan["ranks"][0]["config4"]["rows"] == [0, 20]
+    assert d["config"]["rccl"]["ranks_in_communicator"] == plan["table_sum"]["ranks_in_communicator_expected"] == 2
+    # replicas never claim a table sum, a waveform never needs one
+    assert json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "waveform", "--dry-run"], env=clean_env(),
+                                     capture_output=True, text=True, timeout=120, cwd=ROOT).stdout)["table_sum"]["what"].startswith("none")

@@ -413,6 +413,25 @@ def test_k0_all_colours_fixed_point_path(emul_ctx, oracle, cs):
     pc.assert_same(emul_ctx.convert_rgb_yuv(rgb, 4096, cs), oracle.rgb_to_yuv(rgb, 4096, cs), f"K0 exhaustive cs{cs}")
 
 
+@pytest.mark.parametrize("block", [256, 512, 1024])
+def test_vectorscope_workgroup_sizes(emul_ctx, oracle, block):
+    """vss_write_out for every workgroup size: 16 / 8 / 4 table groups per thread -- dense partials below 512 threads, a mask byte of
+    eight groups at 512, the in-launch fold only at 1024 (round 6: the loop over a thread's groups once stopped at eight)."""
+    for slices in (1, 3):
+        with pc.options(emul_ctx, **{"vss.block": block, "slices": slices}):
+            pc.check_vectorscope(emul_ctx, oracle, 160, 90, 1)
+            pc.check_vectorscope(emul_ctx, oracle, 160, 90, 2, fuse=True)
+
+
+def test_vectorscope_partials_meet_inside_the_launch(emul_ctx, oracle):
+    """vss_write_out's fold (round 6): 2 / 3 / 4 slices per frame, every producer of vectorscope partials, against the oracle and
+    against the reduction kernel's path."""
+    dev = lambda *a, **k: pc.check_vectorscope_fold(emul_ctx, oracle, _np_dev, lambda hnd: hnd, *a, **k)  # noqa: E731
+    dev(128, 72, [1, 2, 5], launches=2)
+    dev(100, 37, [3, {"detail": 0.05}], launches=2, linesize=100 * 4 + 16)  # flat (one bin saturates in every slice), screen-like
+    dev(64, 2100, [3], launches=1)                                            # tall and flat: clamp passes before the fold
+
+
 def test_frame_pool_alloc_and_free(emul_ctx):
     """scope_frame_pool_alloc: several candidate allocations, each read and timed, the fastest kept and the rest freed;
     the kept pool is ordinary device memory a scope reads from."""

@@ -1020,6 +1020,56 @@ def test_bench_one_gpu_line_has_config4_and_rccl_rank_count(hip_ctx):
     assert d["scaling"] == "strong" and d["value"] == c4["value"]
 
 
+def test_vectorscope_partials_meet_inside_the_launch(hip_ctx, oracle):
+    """vss_write_out's fold (round 6: the frame's last-arriving workgroup adds the other slices' write-through partials to its
+    own): 2 / 3 / 4 slices per frame through every producer (staged, fused, packed wire format, the three-scope kernel), several
+    launches in a row, against the oracle and against the reduction kernel's path; 4K frames so that the workgroups of a frame
+    finish at different moments on different XCDs."""
+    to_dev, to_host = _torch_dev()
+
+    def dev(*a, **k):
+        pc.check_vectorscope_fold(hip_ctx, oracle, to_dev, to_host, *a, **k)
+
+    dev(3840, 2160, [1, 3, {"detail": 0.03}, 5], launches=3)
+    dev(1924, 1083, [2, 1], launches=2, linesize=1924 * 4 + 64)
+    dev(640, 360, [1, 2, 3, 4, 5, 1, 2, 3], launches=4)
+
+
+def test_vectorscope_fold_stress(hip_ctx, oracle):
+    """The hand-off under UNEVEN load with every table word checked, many times: sixteen different 1080p frames of very different
+    cost (noise, flat, screen-like) per launch, four slices per frame, 300 launches back to back into fresh tables; a stale or a
+    missing partial shows as a wrong count."""
+    import numpy as np
+    import torch
+
+    w, h, n = 1920, 1080, 16
+    kinds = [1, 3, {"detail": 0.03}, 2, 5, {"detail": 0.3}, 3, 1] * 2
+    pairs = []
+    for i, d in enumerate(kinds):
+        if isinstance(d, dict):
+            rgb = pc.screen_frame(w, h, 900 + i, **d)
+            pairs.append((rgb, oracle.rgb_to_yuv(rgb, w, 2)))
+        else:
+            pairs.append(pc.frames(oracle, w, h, d, seed=800 + i))
+    want = torch.from_numpy(np.stack([oracle.vectorscope(y, w).reshape(-1) for _, y in pairs])).cuda()
+    t_yuv = torch.from_numpy(np.stack([y for _, y in pairs])).cuda()
+    t_rgb = torch.from_numpy(np.stack([r for r, _ in pairs])).cuda()
+    b_yuv = hip_ctx.make_device_batch(t_yuv, 4 * w, w, h, planes_are_rgb=False)
+    b_rgb = hip_ctx.make_device_batch(t_rgb, 4 * w, w, h, planes_are_rgb=True, colorspace=2)
+    with pc.options(hip_ctx, **{"slices": 4}):
+        outs = [torch.full((n, 65536), 0xEE, dtype=torch.uint8, device="cuda") for _ in range(8)]
+        bad = 0
+        for it in range(300):
+            o = outs[it % 8]
+            o.fill_(0xEE)
+            hip_ctx.vectorscope_batch_dev(b_rgb if it % 3 == 2 else b_yuv, o, sync=False)
+            if it % 8 == 7:
+                hip_ctx.sync()
+                bad += sum(int((x != want).sum()) for x in outs)
+        hip_ctx.sync()
+        assert bad == 0, f"{bad} wrong table cells over 300 folded launches"
+
+
 def test_frame_pool_alloc_places_a_pool(hip_ctx, oracle):
     """scope_frame_pool_alloc on the GPU: four candidates of 256 MB each are read and timed, the fastest is kept (its rate
     comes first and is the maximum), the pool is ordinary device memory that torch can view and a scope can read, and

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--comp", type=lambda x: int(x, 0), default=None, help="component mask of the waveform / histogram workloads (default 0x07, 0x70 for *_yuv)")
     ap.add_argument("--opt-a", action="append", default=[], help="key=value for the first library's context")
     ap.add_argument("--opt-b", action="append", default=[], help="key=value for the second (the same .so twice compares options)")
+    ap.add_argument("--whole", action="store_true", help="rate of the WHOLE call (every kernel it enqueues and the gaps between them: wall clock over 60 calls "
+                    "between synchronizes, no profiling), not of the accumulation kernel alone")
     ap.add_argument("--opts", default="", help="options per library, ';'-separated lists of k=v[,k=v] (overrides --opt-a / --opt-b)")
     args = ap.parse_args()
     per_lib = [[kv for kv in part.split(",") if kv] for part in args.opts.split(";")] if args.opts else [args.opt_a, args.opt_b]
@@ -90,7 +92,17 @@ def main():
                     while time.perf_counter() < t_end:
                         fn()
                         c.sync()
-                k, wall, _ = timed(c, fn, reps=30)
+                if args.whole:
+                    for _ in range(5):
+                        fn()
+                    c.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(60):
+                        fn()
+                    c.sync()
+                    k = (time.perf_counter() - t0) / 60 * 1e3
+                else:
+                    k, wall, _ = timed(c, fn, reps=30)
                 res[i].append(n * (4 * W * H + table) / (k * 1e-3) / 1e9)
         for i, p in enumerate(args.libs):
             r = sorted(res[i])
