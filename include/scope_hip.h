@@ -138,6 +138,13 @@ int scope_ctx_device_info(scope_ctx *ctx, struct scope_device_info *info);
  *   "nt" 0|1     streaming (non-temporal) loads
  *   "slices"     workgroups per frame (0 = automatic) */
 int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value);
+/* Counters for tests and A/B runs: which form the launches of this context took -- so that a path a test means to cover cannot fall
+ * back to another one silently.  "vss.rows_launches" / "his.rows_launches": vectorscope / histogram launches that walked padded
+ * planes in whole rows (the ROWS form; the kernels' own predicate asked on the host); "vss.fold_launches" / "trio.fold_launches":
+ * launches whose partial vectorscope tables met inside the launch; "trio.chroma_guard_selftest": bit 0 / 1 = BT.601 / BT.709 fit
+ * the three-scope kernel's compact table, bit 2 / 3 = their full-range forms are refused by the launch-time guard (15 expected).
+ * No reference counterpart. */
+int scope_ctx_get_stat(scope_ctx *ctx, const char *key, uint64_t *value);
 const char *scope_strerror(int status);
 const char *scope_last_error(scope_ctx *ctx);
 int scope_abi_version(void);

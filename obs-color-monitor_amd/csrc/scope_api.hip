@@ -57,6 +57,7 @@ struct scope_ctx {
 	 * pipeline threads and its render thread (the reference runs one "color-monitor" thread per stand-alone
 	 * source, src/common.c:375-403).  Recursive: scope_surface_begin() keeps it until scope_surface_end(). */
 	std::recursive_mutex mu;
+	uint64_t stat_vss_rows, stat_his_rows, stat_vss_fold, stat_trio_fold; /* scope_ctx_get_stat: launches that took a form (tests) */
 	std::vector<ScopePoolRec> pools; /* pools scope_frame_pool_alloc mapped; a pool still there when the context goes is unmapped with it */
 	/* scope_surface_begin .. scope_surface_end: host planes uploaded once and reused by every scope call that is
 	 * handed the same plane (the ROI / dock fan-out) */
@@ -384,6 +385,7 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 		if (slices < min_slices)
 			slices = min_slices;
 		const uint32_t mask_block = ctx->tn.vss_sparse ? scope_vss_mask_block(ctx->tn) : 0u;
+		ctx->stat_vss_rows += scope_vss_rows_mode_host(fs, slices, ctx->tn) ? 1u : 0u;
 		if (slices == 1 && !packed) {
 			TIMED_LAUNCH(ctx, scope_launch_vss(fs, 1, fuse, colorspace, dst, NULL, ctx->tn, ctx->stream, tm_));
 		} else if ((flags & SCOPE_SIDE_REDUCE) && mask_block) {
@@ -419,6 +421,7 @@ int run_vectorscope(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, ui
 			const bool folded = mask_block && scope_vss_can_fold(slices, ctx->pmask, ctx->tn);
 			TIMED_LAUNCH(ctx, scope_launch_vss(fs, slices, fuse, colorspace, ctx->partial, mask_block ? ctx->pmask : NULL,
 							   ctx->tn, ctx->stream, tm_, folded ? &sink : NULL));
+			ctx->stat_vss_fold += folded ? 1u : 0u;
 			/* one partial per frame and a packed result: the "reduction" of one table is just the repacking */
 			if (folded)
 				;
@@ -571,6 +574,7 @@ int run_dock(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint32_t 
 							    slices > 1 ? ctx->partial : vss_dst, ctx->pmask, ctx->stream, tm_, (uint32_t)ctx->tn.vss_rle,
 							    folded ? &vsink : NULL));
 		}
+		ctx->stat_trio_fold += folded ? 1u : 0u;
 		if (partials && !folded)
 			HIP_TRY(ctx, scope_launch_sat_reduce_sparse(ctx->partial, ctx->pmask, vss_dst, nf, slices, mask_block, 0, ctx->stream));
 		launched = true;
@@ -610,6 +614,7 @@ int run_histogram(scope_ctx *ctx, const uint8_t *const *planes, uint32_t n, uint
 			return fail(ctx, SCOPE_EINVAL, "pitch * height too large", hipSuccess);
 		if (slices < min_slices)
 			slices = min_slices;
+		ctx->stat_his_rows += scope_his_rows_mode_host(fs, slices) ? 1u : 0u;
 		if (slices == 1) {
 			TIMED_LAUNCH(ctx, scope_launch_his(fs, 1, chmask, fuse, colorspace, dst, NULL, NULL, ctx->tn, ctx->stream, tm_));
 		} else if (ctx->tn.fold) {
@@ -965,6 +970,26 @@ int scope_ctx_set_option(scope_ctx *ctx, const char *key, int value)
 		ctx->tn.vss_rle = value != 0;
 	else if (!strcmp(key, "slices"))
 		ctx->slices_override = value;
+	else
+		return fail(ctx, SCOPE_EINVAL, key, hipSuccess);
+	return SCOPE_OK;
+}
+
+int scope_ctx_get_stat(scope_ctx *ctx, const char *key, uint64_t *value)
+{
+	if (!ctx || !key || !value)
+		return SCOPE_EINVAL;
+	std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+	if (!strcmp(key, "vss.rows_launches"))
+		*value = ctx->stat_vss_rows;
+	else if (!strcmp(key, "his.rows_launches"))
+		*value = ctx->stat_his_rows;
+	else if (!strcmp(key, "vss.fold_launches"))
+		*value = ctx->stat_vss_fold;
+	else if (!strcmp(key, "trio.fold_launches"))
+		*value = ctx->stat_trio_fold;
+	else if (!strcmp(key, "trio.chroma_guard_selftest"))
+		*value = scope_trio_chroma_selftest();
 	else
 		return fail(ctx, SCOPE_EINVAL, key, hipSuccess);
 	return SCOPE_OK;

@@ -82,6 +82,11 @@ struct ScopeTiming {
 };
 
 ScopeK0 scope_k0_matrix(int colorspace);
+ScopeK0 scope_k0_matrix_full_range(int colorspace); /* for the self-test of scope_trio_kernel's chroma guard only */
+/* host-side mirrors of the kernels' ROWS-form predicate (scope_ctx_get_stat) and the guard's self-test */
+bool scope_vss_rows_mode_host(const ScopeFrameSet &fs, uint32_t slices, const ScopeTuning &tn);
+bool scope_his_rows_mode_host(const ScopeFrameSet &fs, uint32_t slices);
+uint32_t scope_trio_chroma_selftest(void); /* bit 0 / 1: BT.601 / BT.709 fit the compact table; bit 2 / 3: their full-range forms are refused */
 
 /* Dynamic-LDS opt-in for every instantiation; call once per device before launching (scope_trio_init: the part of it that
  * lives in scope_trio.hip; scope_kernels_init calls it). */

@@ -67,6 +67,19 @@ ScopeK0 scope_k0_matrix(int colorspace)
 	return k;
 }
 
+/* The same rows with FULL-RANGE chroma (x 255 / 224): a matrix the library does not offer.  It exists for one caller, the self-test of
+ * scope_trio_kernel's launch-time chroma guard, which must refuse it (its U and V reach 0 and 255, outside the compact table). */
+ScopeK0 scope_k0_matrix_full_range(int colorspace)
+{
+	ScopeK0 k = scope_k0_matrix(colorspace);
+	const float sc = 255.0f / 224.0f;
+	k.ur *= sc, k.ug *= sc, k.ub *= sc, k.vr *= sc, k.vg *= sc, k.vb *= sc;
+	const float cu[3] = {k.ur, k.ug, k.ub}, cv[3] = {k.vr, k.vg, k.vb};
+	k0_fixed_row(cu, (double)0.5f - (double)0.00390625f, k.fu);
+	k0_fixed_row(cv, (double)0.5f, k.fv);
+	return k;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Pixel streaming
  *
@@ -142,7 +155,14 @@ __device__ __forceinline__ u32 scope_slice_begin_cells(u32 total, u32 s, u32 S)
 
 #ifndef WVS_PRIO
 #ifndef WVS_STORE_NT
-#define WVS_STORE_NT 1 /* the batch form's table stores: 1 streaming (nt), 0 plain -- the write-side A/B of round 6 */
+#define WVS_STORE_NT 4 /* the batch form's table stores.  4: by channel count -- write-through (sc1) for the one-channel masks, streaming (nt)
+			* for the others.  Round 6's write-side A/B on three boxes (profiles/round6/ab_waveform_stores_*.txt):
+			* against nt (1, rounds 1-5), sc1 (2) gives the one-channel modes +3.0 ... +4.1 % and RGB / luma -1.6 ... +0.2 %;
+			* plain stores (0) lose 0 ... 10 %, sc1 + nt (3) 1 ... 2 % */
+#endif
+#ifndef WVS_NARROW_STORE
+#define WVS_NARROW_STORE 2 /* the narrow-strip (one-frame) form's table stores: 2 write-through (+1 ... +3.6 % at one and three frames per call),
+			    * 1 streaming (rounds 2-5; A/B) */
 #endif
 #define WVS_PRIO 1 /* the same inside scope_wvs_kernel's units, narrow-strip form only (see there); 0: A/B */
 #endif
@@ -329,7 +349,7 @@ __device__ __forceinline__ void scope_stream(const uint8_t *plane, u32 linesize,
 /* Does a padded plane's slice run the ROWS form of scope_stream?  A row must be whole lane groups (every lane of a wave in one
  * column phase) and a lane group's share at least sixteen rows (streams are whole rows: a share of 8.4 rows -- one 4K frame
  * over 256 workgroups -- would be 8 rows here and 9 there). */
-__device__ __forceinline__ bool scope_rows_mode(u32 linesize, u32 ncols, u32 cell_bytes, u32 rows, u32 slices, u32 glog2)
+__host__ __device__ __forceinline__ bool scope_rows_mode(u32 linesize, u32 ncols, u32 cell_bytes, u32 rows, u32 slices, u32 glog2)
 {
 	return SCOPE_ROWS && linesize != ncols * cell_bytes && ncols % (64u >> glog2) == 0u && rows >= ((16u * slices) << glog2);
 }
@@ -1217,7 +1237,11 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 						  (acc[c].x & 0xffffu) + (acc[c].x >> 16) + (acc[c].y & 0xffffu) + (acc[c].y >> 16));
 			}
 			const scope_v4 t = {o[0], o[1], o[2], o[3]};
-			__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
+			if (WVS_NARROW_STORE == 2)
+				scope_llvm_raw_buffer_store_v4i32(scope_i4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]}, scope_buf_make(table, SCOPE_WVS_ROWS * W * 4u),
+								  (int)(((xs + (g << 2)) + (255u - value) * W) * 4u), 0, 16);
+			else
+				__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g << 2)) * 4) + (size_t)(255u - value) * (W >> 2));
 		} else if (WIDE) {
 			/* width % 4 == 0 and a 16-byte aligned table: a fixed number of unconditional vector stores per
 			 * lane (lanes past the right edge repeat the strip's last column group), so the waits of the
@@ -1231,10 +1255,17 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_wvs_kernel(ScopeFrameSet fs
 				u32 o[4], n[3];
 				gather(value, g, o, n);
 				const scope_v4 t = {o[0], o[1], o[2], o[3]};
-				if (WVS_STORE_NT)
+				constexpr int STORE = WVS_STORE_NT == 4 ? (nch == 1 ? 2 : 1) : WVS_STORE_NT;
+				if (STORE == 1) {
 					__builtin_nontemporal_store(t, ocol + (size_t)(255u - value) * (W >> 2));
-				else
+				} else if (STORE == 0) {
 					ocol[(size_t)(255u - value) * (W >> 2)] = t; /* plain (cached) stores: measurement only, round 6 */
+				} else { /* 2: write-through (sc1: the table's bytes leave the L2 at once and take no line from the pixel stream --
+					  * the one-channel modes, which do the least arithmetic between their loads, gain 4 %); 3: sc1 + nt */
+					const scope_buf ob = scope_buf_make(table, SCOPE_WVS_ROWS * W * 4u);
+					scope_llvm_raw_buffer_store_v4i32(scope_i4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]}, ob,
+									  (int)(((xs + (g << 2)) + (255u - value) * W) * 4u), 0, STORE == 2 ? 16 : 18);
+				}
 				if (HIS)
 					tally(value, xg < groups, n); /* lanes past the right edge repeat a column group */
 			}
@@ -2035,6 +2066,27 @@ uint32_t scope_vss_mask_block(const ScopeTuning &tn)
 	return b >= 512u ? b : 0u; /* a thread's groups must fit the 8 bits of its mask byte */
 }
 
+/* lane groups per wave (log2): 8 streams for batches, one for launches of a few frames (see scope_launch_vss) */
+static u32 vss_glog2(uint32_t slices, const ScopeTuning &tn)
+{
+	const u32 g = tn.vss_groups_log2 < 0 ? (slices >= 12 ? 0u : 3u) : (u32)tn.vss_groups_log2;
+	return g > 3 ? 3 : g; /* lane groups of >= 8 lanes: every request still covers a whole 128-byte line */
+}
+
+/* Does this launch walk its planes in the ROWS form of scope_stream?  The kernels' own predicate (scope_rows_mode), asked on the
+ * host with the launcher's own region split and lane groups: what scope_ctx_get_stat("vss.rows_launches" / "his.rows_launches")
+ * counts, so that a test can tell that a padded plane took the form and did not fall back to the general one silently. */
+bool scope_vss_rows_mode_host(const ScopeFrameSet &fs, uint32_t slices, const ScopeTuning &tn)
+{
+	const Regions r = split_regions(fs);
+	return r.ncols_a != 0 && scope_rows_mode(fs.linesize, r.ncols_a, 16u, fs.height, slices, vss_glog2(slices, tn));
+}
+bool scope_his_rows_mode_host(const ScopeFrameSet &fs, uint32_t slices)
+{
+	const Regions r = split_regions(fs);
+	return r.ncols_a != 0 && scope_rows_mode(fs.linesize, r.ncols_a, 16u, fs.height, slices, 0u);
+}
+
 bool scope_vss_can_fold(uint32_t slices, const uint8_t *pmask, const ScopeTuning &tn)
 {
 	return tn.vss_fold && pmask && slices >= 2 && slices <= VSS_FOLD_MAX && scope_block(tn.vss_block) == SCOPE_BLOCK;
@@ -2048,9 +2100,7 @@ hipError_t scope_launch_vss(const ScopeFrameSet &fs, uint32_t slices, int fuse_k
 	 * 10-15 % slower (12 frames: 0.49 -> 0.59 of peak, 3 frames 0.36 -> 0.41; profiles/round2/latency_r2e.txt).
 	 * There the slice is walked as ONE stream, two loads per lane in flight; the big batches keep 8 streams x 4. */
 	const bool small = slices >= 12;
-	u32 glog2 = tn.vss_groups_log2 < 0 ? (small ? 0u : 3u) : (u32)tn.vss_groups_log2;
-	if (glog2 > 3)
-		glog2 = 3; /* lane groups of >= 8 lanes: every request still covers a whole 128-byte line */
+	const u32 glog2 = vss_glog2(slices, tn);
 	/* the fused-K0 form: the pair-addressed table (HASH 2) everywhere, four loads per lane where the frames are many; small
 	 * launches keep two (bench.py --frames 1 / 3 --workload vectorscope_rgb, us per call on distinct HBM-resident frames,
 	 * visit s3: table as the plain kernel's + two loads 18.5 / 30.0, pair table + two loads 18.2 / 29.3, pair table +

@@ -102,6 +102,9 @@
 #define TRIO_RLE_WHOLE (!TRIO_ABSORB) /* the run-length form's whole-wave shortcut (trio_rle_pair): what stands in for the absorb mode where
 					* that is compiled out (A/B: flat frames 13 % behind the absorb mode, visit d6) */
 #endif
+#ifndef TRIO_STORE_SC1
+#define TRIO_STORE_SC1 0 /* the strip's read-out stores: 0 streaming (nt), 1 write-through (sc1, as the waveform kernel's batch form; A/B) */
+#endif
 #ifndef TRIO_RLE_FASTONLY
 #define TRIO_RLE_FASTONLY 0 /* 1: only the branch-free slot form carries the run-length form (the checked slots -- two of 36 per 4K strip -- keep
 			      * the absorb mode): less code (A/B) */
@@ -716,8 +719,13 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 #pragma unroll
 				for (u32 j = 0; j < NV; j++) {
 					const scope_v4 t = {o[j][0], o[j][1], o[j][2], o[j][3]};
-					__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g4 << 2)) * 4) +
-									       (size_t)(255u - (value0 + (1024u >> GL) * j)) * (W >> 2));
+					if (TRIO_STORE_SC1)
+						scope_llvm_raw_buffer_store_v4i32(scope_i4{(int)o[j][0], (int)o[j][1], (int)o[j][2], (int)o[j][3]},
+										  scope_buf_make(table, SCOPE_WVS_ROWS * W * 4u),
+										  (int)(((xs + (g4 << 2)) + (255u - (value0 + (1024u >> GL) * j)) * W) * 4u), 0, 16);
+					else
+						__builtin_nontemporal_store(t, (scope_v4 *)(table + (size_t)(xs + (g4 << 2)) * 4) +
+										       (size_t)(255u - (value0 + (1024u >> GL) * j)) * (W >> 2));
 				}
 			}
 		}
@@ -899,11 +907,22 @@ static bool trio_chroma_fits(const ScopeK0 &k)
 	return true;
 }
 
+/* the verdict per matrix the library knows, worked out once (scope_k0_matrix: 1 -> 601, anything else -> 709) */
+static bool trio_chroma_fits_cs(int colorspace)
+{
+	static const bool ok[2] = {trio_chroma_fits(scope_k0_matrix(1)), trio_chroma_fits(scope_k0_matrix(2))};
+	return !TRIO_COMPACT || ok[colorspace == 1 ? 0 : 1];
+}
+
+uint32_t scope_trio_chroma_selftest(void)
+{
+	return (trio_chroma_fits(scope_k0_matrix(1)) ? 1u : 0u) | (trio_chroma_fits(scope_k0_matrix(2)) ? 2u : 0u) |
+	       (!trio_chroma_fits(scope_k0_matrix_full_range(1)) ? 4u : 0u) | (!trio_chroma_fits(scope_k0_matrix_full_range(2)) ? 8u : 0u);
+}
+
 bool scope_trio_fits(const ScopeFrameSet &fs, const uint8_t *wvs_dst, const ScopeTuning &tn)
 {
-	/* both matrices the library knows (scope_k0_matrix: 1 -> 601, anything else -> 709), once */
-	static const bool chroma_ok = !TRIO_COMPACT || (trio_chroma_fits(scope_k0_matrix(1)) && trio_chroma_fits(scope_k0_matrix(2)));
-	if (!chroma_ok)
+	if (!trio_chroma_fits_cs(1) || !trio_chroma_fits_cs(2))
 		return false; /* the two-pass path then (scope_api.hip): its tables hold every bin */
 	/* the vector shape, a column's rows within the waveform's 16-bit counters, 32-bit offsets */
 	return scope_wvs_vector_shape(fs, wvs_dst, tn) && fs.height >= 1 && fs.height <= 65535u &&
@@ -945,8 +964,8 @@ hipError_t scope_launch_trio(const ScopeFrameSet &fs, uint32_t slices, uint32_t 
 {
 	if ((chmask & 7u) == 0 || slices == 0 || slices > 256u || (slices > 1 && !vss_mask) || (strip_width != 16u && strip_width != 32u))
 		return hipErrorInvalidValue;
-	if (TRIO_COMPACT && !trio_chroma_fits(scope_k0_matrix(colorspace)))
-		return hipErrorInvalidValue; /* never a silent write outside the compact table */
+	if (!trio_chroma_fits_cs(colorspace))
+		return hipErrorInvalidValue; /* never a silent write outside the compact table (the verdict is cached per matrix) */
 	if (fold && (slices < 2 || slices > VSS_FOLD_MAX || !vss_mask))
 		return hipErrorInvalidValue;
 	const VssFold vf = fold ? VssFold{fold->out, fold->tickets, fold->packed16 ? 1u : 0u} : VssFold{NULL, NULL, 0u};

@@ -26,7 +26,7 @@ COMP_RGB, COMP_Y, COMP_UV, COMP_YUV = 0x07, 0x20, 0x50, 0x70
 ABI_SYMBOLS = (
     "scope_abi_version", "scope_strerror", "scope_last_error",
     "scope_ctx_create", "scope_ctx_destroy", "scope_ctx_set_stream", "scope_ctx_get_stream", "scope_ctx_sync", "scope_ctx_fence",
-    "scope_ctx_device_info", "scope_ctx_set_option",
+    "scope_ctx_device_info", "scope_ctx_set_option", "scope_ctx_get_stat",
     "scope_convert_rgb_yuv",
     "scope_vectorscope", "scope_waveform", "scope_histogram_counts", "scope_histogram", "scope_histogram_level",
     "scope_vectorscope_batch", "scope_waveform_batch", "scope_histogram_counts_batch",
@@ -118,6 +118,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "scope_ctx_fence": (i32, [vp]),
         "scope_ctx_device_info": (i32, [vp, C.POINTER(DeviceInfo)]),
         "scope_ctx_set_option": (i32, [vp, C.c_char_p, i32]),
+        "scope_ctx_get_stat": (i32, [vp, C.c_char_p, C.POINTER(u64)]),
         "scope_convert_rgb_yuv": (i32, [vp, vp, u32, vp, u32, u32, u32, i32, u32]),
         "scope_vectorscope": (i32, [vp, C.POINTER(SurfaceData), u32, vp]),
         "scope_waveform": (i32, [vp, C.POINTER(SurfaceData), u32, u32, vp]),
@@ -217,6 +218,12 @@ class ScopeContext:
 
     def set_option(self, key: str, value: int):
         self._check(self.L.scope_ctx_set_option(self.h, key.encode(), int(value)))
+
+    def get_stat(self, key: str) -> int:
+        """scope_ctx_get_stat: which form this context's launches took ("vss.rows_launches", "vss.fold_launches", ...)."""
+        v = C.c_uint64()
+        self._check(self.L.scope_ctx_get_stat(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
 
     def set_stream(self, hip_stream: int | None):
         """Run on the caller's hipStream_t.  A NULL/0 handle selects the context's OWN stream, which does

@@ -67,6 +67,15 @@ template <bool NT> static inline scope_u2 scope_buf_load2(scope_buf buf, unsigne
 	return scope_u2{p[0], p[1]};
 }
 
+/* a 16-byte store through a buffer resource, whatever its cache flavour (aux) */
+struct scope_i4 {
+	int x, y, z, w;
+};
+static inline void scope_llvm_raw_buffer_store_v4i32(scope_i4 d, scope_buf buf, int off, int, int)
+{
+	if ((unsigned long long)(unsigned)off + 16 <= buf.bytes)
+		__builtin_memcpy((unsigned char *)buf.base + (unsigned)off, &d, 16);
+}
 /* the hand-off vocabulary: the emulation's memory is one coherent array */
 struct scope_u4 {
 	unsigned x, y, z, w;

@@ -640,6 +640,7 @@ def check_vectorscope_fold(ctx, oracle, to_dev, to_host, w, h, dists, launches=3
     for slices in (2, 4, 3):
         for fold in (1, 0):
             with options(ctx, **{"slices": slices, "vss.fold": fold}):
+                before = ctx.get_stat("vss.fold_launches"), ctx.get_stat("trio.fold_launches")
                 for rep in range(launches):
                     tag = f"{w}x{h} slices {slices} fold {fold} launch {rep}"
                     for name, b in (("staged", b_yuv), ("fused", b_rgb)):
@@ -664,6 +665,9 @@ def check_vectorscope_fold(ctx, oracle, to_dev, to_host, w, h, dists, launches=3
                         for f in range(n):
                             assert_same(got[f], want[f], f"three scopes: vectorscope fold frame {f} {tag}")
                             assert_same(wv[f], want_wvs[f], f"three scopes: waveform beside the fold frame {f} {tag}")
+                # the form the test means to cover is the form that ran (no silent fall-back to the reduction kernel, or the other way)
+                assert ctx.get_stat("vss.fold_launches") - before[0] == (3 * launches if fold else 0), (slices, fold)
+                assert ctx.get_stat("trio.fold_launches") - before[1] == (launches if fold and w % 4 == 0 else 0), (slices, fold)
     del keep_rgb, keep_yuv
 
 

@@ -72,7 +72,8 @@ def test_vectorscope_fused_k0_long_streams(emul_ctx, oracle, merge, hash_):
 
 
 @pytest.mark.parametrize("groups,w,h,slices", [(0, 256, 80, 1), (0, 256, 80, 4), (3, 64, 300, 2), (2, 128, 200, 3), (1, 384, 70, 2),
-                                               (0, 256, 530, 1), (3, 64, 2100, 1)])  # the last two: eight batches of the unchecked main loop
+                                               (0, 256, 530, 1), (3, 64, 2100, 1),  # these two: eight batches of the unchecked main loop
+                                               (3, 32, 259, 2)])  # ONE lane group per row (64 >> 3 cells), shares of 129 and 130 rows
 def test_padded_planes_walk_whole_rows(emul_ctx, oracle, groups, w, h, slices):
     """scope_stream's ROWS form: a padded DEVICE plane (linesize > 4 W, src/vectorscope.c:225,236; host planes are packed on
     their way to the GPU) whose rows are whole lane groups is walked in whole rows with a wave-uniform column cursor -- the plain
@@ -80,11 +81,37 @@ def test_padded_planes_walk_whole_rows(emul_ctx, oracle, groups, w, h, slices):
     and the histogram's kernels.  The widths here are multiples of 64 >> groups cells and every lane group has sixteen rows or
     more, so this form runs (seen with a probe build); the geometry tests (odd widths, few rows) keep the general form covered."""
     ls = 4 * w + 64
+    rows0 = emul_ctx.get_stat("vss.rows_launches"), emul_ctx.get_stat("his.rows_launches")
     for unroll in (0, 4):
         with pc.options(emul_ctx, **{"slices": slices, "vss.groups": groups, "vss.unroll": unroll, "vss.fused_unroll": unroll}):
             pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, w, h, ls, n=2)
+    # the ROWS form is the form that ran (the kernels' own predicate, asked on the host: scope_ctx_get_stat) -- a change of the
+    # predicate, of the sixteen-rows threshold or -DSCOPE_ROWS=0 would otherwise leave these tests green on the general form
+    assert emul_ctx.get_stat("vss.rows_launches") - rows0[0] >= 4, "the padded vectorscope launches did not take the ROWS form"
+    if (w // 4) % 64 == 0 and h >= 16 * slices:  # the histogram's kernels walk a slice as ONE stream: a row must be whole waves
+        assert emul_ctx.get_stat("his.rows_launches") - rows0[1] >= 2, "the padded histogram launches did not take the ROWS form"
+    rows1 = emul_ctx.get_stat("vss.rows_launches")
     with pc.options(emul_ctx, **{"slices": slices, "vss.groups": groups, "vss.merge": 0}):
         pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, w, h, ls, n=1, offset=16)
+    assert emul_ctx.get_stat("vss.rows_launches") > rows1  # (planes that start 16 bytes into their buffer are as aligned as before)
+
+
+def test_packed_planes_never_take_the_rows_form(emul_ctx, oracle):
+    before = emul_ctx.get_stat("vss.rows_launches"), emul_ctx.get_stat("his.rows_launches")
+    pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, 256, 80, 4 * 256, n=2)   # no padding
+    pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, 100, 80, 4 * 100 + 64, n=1)  # rows that are not whole lane groups
+    with pc.options(emul_ctx, slices=8):
+        pc.check_device_path(emul_ctx, oracle, _np_dev, lambda hnd: hnd, 256, 80, 4 * 256 + 64, n=1)  # ten rows per slice: below sixteen
+    assert (emul_ctx.get_stat("vss.rows_launches"), emul_ctx.get_stat("his.rows_launches")) == before
+
+
+def test_three_scope_chroma_guard(emul_ctx):
+    """scope_trio_kernel's launch-time guard on the compact vectorscope table (trio_chroma_fits): both matrices the library knows
+    fit, their FULL-RANGE forms -- whose chroma reaches 0 and 255 -- are refused (the two-pass path would run: `dock` 0 is that
+    path, covered by test_three_scopes_one_read[0])."""
+    assert emul_ctx.get_stat("trio.chroma_guard_selftest") == 15
+    with pytest.raises(Exception):
+        emul_ctx.get_stat("no.such.counter")
 
 
 @pytest.mark.parametrize("comp", pc.COMPONENTS)
