@@ -524,6 +524,52 @@ template <int HASH> __device__ __forceinline__ void vss_flush_lane(u32 *tab, Vss
 	st.count = 0;
 }
 
+/* The absorb mode's state in ONE register, S = count | U << 16 | V << 24 (round 6; a lane's count stays below 65 281, an epoch's
+ * texels): with (colour, count, U | U << 16, V | V << 16) in four registers the compiler copied all four at every join of the
+ * binning code's paths -- four to twelve v_mov per slot of the three-scope kernel on the path noise takes.  What the compare needs
+ * is two byte permutes away.  Flush: every lane of the wave (uniform control flow); one colour throughout the wave -- the flat
+ * frame -- and one lane adds the wave's total. */
+template <int HASH> __device__ __forceinline__ void vss_flush_packed(u32 *tab, u32 &S)
+{
+	/* every lane of the wave (uniform control flow); one colour throughout the wave: one lane adds the wave's total */
+	const u32 n = S & 0xffffu;
+	const u64 pending = __ballot(n != 0);
+	if (pending == 0)
+		return;
+	const u32 leader = (u32)(__ffsll((long long)pending) - 1);
+	const u32 colour = __builtin_amdgcn_readlane(S >> 16, leader);
+	if (__all(n == 0 || (S >> 16) == colour)) {
+		const u32 total = scope_wave_sum(n);
+		if ((threadIdx.x & 63u) == leader)
+			vss_add<HASH>(tab, colour << 8, total); /* key = U << 8 | V << 16 */
+	} else if (n) {
+		vss_add<HASH>(tab, (S >> 16) << 8, n);
+	}
+	S &= 0xffff0000u;
+}
+
+/* two pairs (one 16-byte cell) against the lane's colour: the packed form of vss_absorb_pairs */
+__device__ __forceinline__ void vss_absorb_pairs1(u32 *tab, u32 &S, u32 pu0, u32 pv0, u32 pu1, u32 pv1)
+{
+	const u32 lane_u = scope_perm(0u, S, 0x0c020c02u), lane_v = scope_perm(0u, S, 0x0c030c03u); /* S = 0: no pair has U = V = 0 */
+	const u32 x0 = scope_bitop3<0xf6>(pu0 ^ lane_u, pv0, lane_v); /* (pu ^ lane_u) | (pv ^ lane_v) */
+	const u32 x1 = scope_bitop3<0xf6>(pu1 ^ lane_u, pv1, lane_v);
+	if ((x0 | x1) == 0u) {
+		S += 4u;
+		return;
+	}
+	/* one colour throughout?  Then the four differences are equal (necessary; the exact test only where that holds) */
+	if (x0 == x1 && x0 == scope_perm(0u, x0, 0x01000302u) && pu0 == pu1 && pv0 == pv1 && pu0 == scope_perm(0u, pu0, 0x01000302u) &&
+	    pv0 == scope_perm(0u, pv0, 0x01000302u)) {
+		if (S & 0xffffu)
+			vss_add<2>(tab, (S >> 16) << 8, S & 0xffffu);
+		S = scope_perm(pv0, pu0, 0x04000c0cu) | 4u;
+		return;
+	}
+	vss_add_pair(tab, pu0, pv0);
+	vss_add_pair(tab, pu1, pv1);
+}
+
 __device__ __forceinline__ u32 vss_clamp_word(u32 w)
 {
 	const u32 lo = min(w & 0xffffu, 255u);

@@ -361,6 +361,9 @@ __host__ __device__ __forceinline__ bool scope_rows_mode(u32 linesize, u32 ncols
  * one frame per call, the ring of three) is dominated by its start-up, and carrying the mode's code cost it 2.5-4 % on noise and
  * natural content for +4 % (one frame) / +14 % (three) on screen content (visit c4/c5, profiles/round4/ab_fused_vectorscope.txt). */
 #define VSS_RLE_IN(U) (VSS_RLE && (U) == 4)
+#ifndef VSS_PACKED_STATE
+#define VSS_PACKED_STATE 1 /* the fused kernel's absorb state in one register (vss_absorb_pairs1); 0: four (rounds 3-5; A/B) */
+#endif
 #ifndef VSS_RLE_LEAN
 #define VSS_RLE_LEAN 1 /* 0: round 4's instruction sequence of the run-length modes (A/B) */
 #endif
@@ -405,6 +408,21 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 		/* the lane's colour as U | U << 16 and V | V << 16; 0xffffffff (no pair looks like that) while it has none */
 		u32 lane_u = st.colour == 0xffffffffu ? 0xffffffffu : scope_perm(0u, st.colour, 0x0c010c01u);
 		u32 lane_v = st.colour == 0xffffffffu ? 0xffffffffu : scope_perm(0u, st.colour, 0x0c020c02u);
+		/* VSS_PACKED_STATE (round 6): the same state in ONE register inside this region, S = count | U << 16 | V << 24
+		 * (vss_absorb_pairs1, scope_device.h: four registers were copied at every join of the binning paths) */
+		u32 S = VSS_PACKED_STATE && st.colour != 0xffffffffu ? (st.count | ((st.colour << 8) & 0xffff0000u)) : 0u;
+		auto epoch_s = [&](u32 px) { /* `epoch` with the packed state */
+			if (since_clamp + px > VSS_EPOCH_PIXELS) {
+				vss_flush_packed<HASH>(tab, S);
+				__syncthreads();
+				vss_clamp_pass(tab, VssTable<HASH>::words);
+				__syncthreads();
+				since_clamp = 0;
+			}
+			since_clamp += px;
+		};
+		(void)lane_u;
+		(void)lane_v;
 		/* ---- RUN-LENGTH MODE: the wave's window as runs of flat cells --------------------------------------------------
 		 * Screen capture -- OBS's daily bread -- is flat areas with a little single-texel detail.  The per-lane absorb mode
 		 * below suits content on which a LANE's stream is one colour for long; but a lane's consecutive cells lie 2 KiB apart
@@ -536,12 +554,19 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 			if (__builtin_expect(absorb, false)) {
 #pragma unroll
 				for (int k = 0; k < U; k++)
-					if (ok[k])
-						vss_absorb_pairs(tab, st, lane_u, lane_v, pu[k][0], pv[k][0], pu[k][1], pv[k][1]);
+					if (ok[k]) {
+						if (VSS_PACKED_STATE)
+							vss_absorb_pairs1(tab, S, pu[k][0], pv[k][0], pu[k][1], pv[k][1]);
+						else
+							vss_absorb_pairs(tab, st, lane_u, lane_v, pu[k][0], pv[k][0], pu[k][1], pv[k][1]);
+					}
 				if (VSS_RLE_IN(U) && MERGE == 3 && __builtin_amdgcn_readfirstlane(rle_on) == 2u) {
 					/* entering the run-length mode with the next batch: it keeps nothing in the lanes, so what the absorb mode
 					 * holds goes to the table now (rare; every lane of the wave takes part) */
-					vss_flush_lane<HASH>(tab, st);
+					if (VSS_PACKED_STATE)
+						vss_flush_packed<HASH>(tab, S);
+					else
+						vss_flush_lane<HASH>(tab, st);
 					rle_on = 1u;
 					rle_clock = 1u;
 				}
@@ -554,7 +579,17 @@ __device__ __forceinline__ void vss_region(u32 *tab, const uint8_t *plane, u32 l
 					}
 			}
 		};
-		if (linesize == ncols * 16u)
+		if (VSS_PACKED_STATE) {
+			if (linesize == ncols * 16u)
+				scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch_s, bin_pairs);
+			else if (rows_mode)
+				scope_stream<4, U, NT, false, true, false, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch_s, bin_pairs);
+			else
+				scope_stream<4, U, NT, false>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch_s, bin_pairs);
+			/* back into the two-register form the kernel's other region and its last flush know */
+			st.count = S & 0xffffu;
+			st.colour = S ? ((S >> 16) << 8) : 0xffffffffu;
+		} else if (linesize == ncols * 16u)
 			scope_stream<4, U, NT, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_pairs);
 		else if (rows_mode)
 			scope_stream<4, U, NT, false, true, false, true>(plane, linesize, xbyte0, ncols, c0, c1, glog2, prologue, epoch, bin_pairs);

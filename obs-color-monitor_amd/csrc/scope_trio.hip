@@ -238,24 +238,6 @@ template <int CH, u32 VS> __device__ __forceinline__ void trio_count2(u32 *tab, 
  * (a lane's count stays below 65 281, an epoch's texels); what the compare needs is two byte permutes away.  The mode runs only
  * where the vote found the WHOLE wave flat (flat frames, the inside of large areas: a lane's colour then rarely changes and a
  * slot costs six instructions and no LDS operation); everything between that and noise is the run-length form's. */
-template <int HASH> __device__ __forceinline__ void trio_absorb_flush(u32 *tab, u32 &S)
-{
-	/* every lane of the wave (uniform control flow); one colour throughout the wave: one lane adds the wave's total */
-	const u32 n = S & 0xffffu;
-	const u64 pending = __ballot(n != 0);
-	if (pending == 0)
-		return;
-	const u32 leader = (u32)(__ffsll((long long)pending) - 1);
-	const u32 colour = __builtin_amdgcn_readlane(S >> 16, leader);
-	if (__all(n == 0 || (S >> 16) == colour)) {
-		const u32 total = scope_wave_sum(n);
-		if ((threadIdx.x & 63u) == leader)
-			vss_add<HASH>(tab, colour << 8, total); /* key = U << 8 | V << 16 */
-	} else if (n) {
-		vss_add<HASH>(tab, (S >> 16) << 8, n);
-	}
-	S &= 0xffff0000u;
-}
 template <int HASH> __device__ __forceinline__ void trio_absorb_pair(u32 *tab, u32 &S, u32 pu, u32 pv)
 {
 	constexpr u32 pitch = VssTable<HASH>::pitch, bias = VssTable<HASH>::bias;
@@ -530,7 +512,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 			if (since + round_px > VSS_EPOCH_PIXELS && !(TRIO_EXP & 8)) { /* uniform across the workgroup */
 				TRIO_T(tc0);
 				if (TRIO_PAIR && TRIO_ABSORB == 1)
-					trio_absorb_flush<TRIO_HASH>(tab, S); /* pending texels belong to the epoch that ends here */
+					vss_flush_packed<TRIO_HASH>(tab, S); /* pending texels belong to the epoch that ends here */
 				else
 					vss_flush_lane<TRIO_HASH>(tab, st);
 				__syncthreads();
@@ -680,7 +662,7 @@ __global__ __launch_bounds__(SCOPE_BLOCK) void scope_trio_kernel(ScopeFrameSet f
 		}
 		const bool last_strip = s_b + 1u == nst;
 		if (last_strip)
-			(TRIO_PAIR && TRIO_ABSORB == 1) ? trio_absorb_flush<TRIO_HASH>(tab, S) : vss_flush_lane<TRIO_HASH>(tab, st); /* the lanes' pending texels, before the table is read out */
+			(TRIO_PAIR && TRIO_ABSORB == 1) ? vss_flush_packed<TRIO_HASH>(tab, S) : vss_flush_lane<TRIO_HASH>(tab, st); /* the lanes' pending texels, before the table is read out */
 		TRIO_T(tb0);
 		__syncthreads();
 		TRIO_T(tb1);
