@@ -1545,7 +1545,8 @@ float median3(float a, float b, float c)
 
 /* ONE physical allocation tried at up to `candidates` address ranges.  SCOPE_OK with *pool set; SCOPE_EAGAIN (nothing allocated) when
  * the driver refuses a virtual-memory call: the caller falls back to plain allocations. */
-int pool_alloc_vmm(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **pool, float *rate /* [candidates] */, uint32_t *best_out)
+int pool_alloc_vmm(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **pool, float *rate /* [candidates] */, uint32_t *best_out,
+		   uint32_t *tried_out)
 {
 	if (!SCOPE_POOL_VMM)
 		return SCOPE_EAGAIN;
@@ -1597,32 +1598,46 @@ int pool_alloc_vmm(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **p
 		rc = fail(ctx, SCOPE_EIO, "hipEventCreate", hipGetLastError());
 	float r[3][SCOPE_POOL_MAX_CANDIDATES] = {{0}};
 	bool vmm_ok = true;
-	for (int round = 0; round < 3 && rc == SCOPE_OK && vmm_ok && pp.probe_bytes; round++)
-		for (uint32_t i = 0; i < candidates && rc == SCOPE_OK && vmm_ok; i++) {
-			vmm_ok = map_at(i);
-			if (!vmm_ok)
-				break;
-			if (round == 0 && i == 0) /* what the physical memory holds is anybody's: a known content, once (it travels with the handle) */
-				rc = hipMemsetAsync((uint8_t *)base, 0x5a, size, ctx->stream) == hipSuccess ? SCOPE_OK : fail(ctx, SCOPE_EIO, "hipMemsetAsync", hipGetLastError());
-			if (rc == SCOPE_OK)
-				rc = pool_probe(ctx, &pp, (uint8_t *)base + (size_t)i * slot, ev, round == 0 ? 2 : 1, 4, &r[round][i]);
-			(void)hipStreamSynchronize(ctx->stream);
-			vmm_ok = hipMemUnmap((uint8_t *)base + (size_t)i * slot, size) == hipSuccess && vmm_ok;
-		}
+	auto slot_at = [&](uint32_t i) { return (uint8_t *)base + (size_t)i * slot; };
+	/* The allocation is mapped at EVERY candidate range at once (one handle, several addresses) and stays mapped while the ranges
+	 * are read in turn; the losers are unmapped at the end, the winner's mapping is never touched again.  (Round 6's first form
+	 * mapped one range at a time and mapped the winner anew at the end: a kernel that WROTE the pool right after that last
+	 * hipMemMap -- the caller's first copy into it -- took a GPU memory access fault in one call of five, tools/pool_stress.py;
+	 * reads by the library's own probe launches never did.  A mapping is therefore never torn down and made again here.) */
+	uint32_t mapped = 0;
+	for (; rc == SCOPE_OK && mapped < candidates; mapped++)
+		if (!map_at(mapped))
+			break;
+	if (rc == SCOPE_OK && mapped == 0)
+		vmm_ok = false;
+	const uint32_t nc = mapped; /* a driver that refuses to alias a handle leaves one range: a plain allocation's worth */
+	if (rc == SCOPE_OK && vmm_ok && pp.probe_bytes && nc > 1) {
+		/* what the physical memory holds is anybody's: a known content, once (every range shows the same bytes) */
+		if (hipMemsetAsync(slot_at(0), 0x5a, size, ctx->stream) != hipSuccess)
+			rc = fail(ctx, SCOPE_EIO, "hipMemsetAsync", hipGetLastError());
+		for (int round = 0; round < 3 && rc == SCOPE_OK; round++)
+			for (uint32_t i = 0; i < nc && rc == SCOPE_OK; i++)
+				rc = pool_probe(ctx, &pp, slot_at(i), ev, round == 0 ? 2 : 1, 4, &r[round][i]);
+	}
 	uint32_t best = 0;
-	for (uint32_t i = 0; i < candidates; i++) {
+	for (uint32_t i = 0; i < nc; i++) {
 		rate[i] = median3(r[0][i], r[1][i], r[2][i]);
 		if (rate[i] > rate[best])
 			best = i;
 	}
-	if (rc == SCOPE_OK && vmm_ok)
-		vmm_ok = map_at(best);
+	(void)hipDeviceSynchronize(); /* nothing of any stream may still read a range that goes away */
+	for (uint32_t i = 0; i < mapped; i++)
+		if ((rc != SCOPE_OK || !vmm_ok || i != best) && hipMemUnmap(slot_at(i), size) != hipSuccess)
+			vmm_ok = false;
+	(void)hipDeviceSynchronize();
 	if (ev[0])
 		(void)hipEventDestroy(ev[0]);
 	if (ev[1])
 		(void)hipEventDestroy(ev[1]);
 	if (rc != SCOPE_OK || !vmm_ok) {
 		(void)hipGetLastError();
+		if (rc == SCOPE_OK && mapped) /* (an unmap failed: the winner is still mapped) */
+			(void)hipMemUnmap(slot_at(best), size);
 		(void)hipMemAddressFree(base, slot * candidates);
 		(void)hipMemRelease(h);
 		return rc != SCOPE_OK ? rc : SCOPE_EAGAIN;
@@ -1631,6 +1646,7 @@ int pool_alloc_vmm(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **p
 	ctx->pools.push_back(rec);
 	*pool = rec.va;
 	*best_out = best;
+	*tried_out = nc;
 	return SCOPE_OK;
 }
 
@@ -1655,9 +1671,9 @@ int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, 
 	uint32_t n = 0, best = 0;
 	int rc = SCOPE_OK;
 	if (candidates > 1) {
-		rc = pool_alloc_vmm(ctx, bytes, candidates, pool, rate, &best);
+		rc = pool_alloc_vmm(ctx, bytes, candidates, pool, rate, &best, &n);
 		if (rc == SCOPE_OK)
-			n = candidates;
+			;
 		else if (rc != SCOPE_EAGAIN)
 			return rc;
 	}

@@ -1,6 +1,7 @@
 /*
- * scope_common.c -- ring + "color-monitor" consumer thread of the reference
- * (src/common.c:335-403) for the stand-alone host, and the module's shared GPU context.
+ * scope_common.c -- the staging ring and the "color-monitor" consumer thread behind the reference's cm_* interface
+ * (src/common.c:223-403; the ring itself is this build's own single-producer single-consumer sequence ring, scope_common.h)
+ * for the stand-alone host, and the module's shared GPU contexts.
  *
  * One reference quirk is NOT reproduced: in the reference the producer stacks a raw RGB copy in
  * front of the YUV rows whenever CM_FLAG_RAW_TEXTURE is set (src/common.c:191-205) but the consumer skips a first plane only
@@ -95,26 +96,37 @@ static void cm_pipeline_thread_loop(struct cm_source *src, struct cm_surface_que
 	src->frames_processed++;
 }
 
-/* src/common.c:375-403 */
+/* Ring the doorbell: whoever sleeps on it looks at the counters again. */
+static void cm_ring_bell(struct cm_source *src)
+{
+	pthread_mutex_lock(&src->pipeline_mutex);
+	pthread_cond_broadcast(&src->pipeline_cond);
+	pthread_mutex_unlock(&src->pipeline_mutex);
+}
+
+/* The consumer ("color-monitor" thread; the reference's loop is src/common.c:375-403): take the oldest published frame it has not
+ * started on, run the callback on its slot, say so.  It sleeps on the doorbell only while nothing is published. */
 static void *cm_pipeline_thread(void *data)
 {
 	struct cm_source *src = data;
-	pthread_mutex_lock(&src->pipeline_mutex);
-	while (!src->request_exit) {
-		const int next = (src->i_read_queue + 1) % CM_SURFACE_QUEUE_SIZE;
-		if (src->i_write_queue == next || src->i_staging_queue == next) {
-			pthread_cond_wait(&src->pipeline_cond, &src->pipeline_mutex);
-			continue;
+	for (;;) {
+		const uint64_t k = atomic_load_explicit(&src->taken, memory_order_relaxed); /* only this thread moves it */
+		if (atomic_load_explicit(&src->staged, memory_order_acquire) == k) {
+			pthread_mutex_lock(&src->pipeline_mutex);
+			while (!atomic_load_explicit(&src->request_exit, memory_order_acquire) &&
+			       atomic_load_explicit(&src->staged, memory_order_acquire) == k)
+				pthread_cond_wait(&src->pipeline_cond, &src->pipeline_mutex);
+			pthread_mutex_unlock(&src->pipeline_mutex);
 		}
-		src->i_read_queue = next;
-		src->busy = true;
-		pthread_mutex_unlock(&src->pipeline_mutex);
-		cm_pipeline_thread_loop(src, &src->queue[next]);
-		pthread_mutex_lock(&src->pipeline_mutex);
-		src->busy = false;
-		pthread_cond_broadcast(&src->pipeline_cond); /* lets cm_drain() observe progress */
+		if (atomic_load_explicit(&src->request_exit, memory_order_acquire))
+			break;
+		if (atomic_load_explicit(&src->staged, memory_order_acquire) == k)
+			continue;
+		atomic_store_explicit(&src->taken, k + 1, memory_order_release); /* the producer may now reuse slot (k - 1) % N, not k % N */
+		cm_pipeline_thread_loop(src, &src->queue[k % CM_SURFACE_QUEUE_SIZE]);
+		atomic_store_explicit(&src->done, k + 1, memory_order_release);
+		cm_ring_bell(src); /* lets cm_drain() see the progress */
 	}
-	pthread_mutex_unlock(&src->pipeline_mutex);
 	return NULL;
 }
 
@@ -122,7 +134,7 @@ static void cm_start_thread(struct cm_source *src)
 {
 	if (src->pipeline_thread_running)
 		return;
-	src->request_exit = false;
+	atomic_store_explicit(&src->request_exit, false, memory_order_release);
 	src->pipeline_thread_running = pthread_create(&src->pipeline_thread, NULL, cm_pipeline_thread, src) == 0;
 }
 
@@ -130,10 +142,8 @@ static void cm_stop_thread(struct cm_source *src)
 {
 	if (!src->pipeline_thread_running)
 		return;
-	pthread_mutex_lock(&src->pipeline_mutex);
-	src->request_exit = true;
-	pthread_cond_broadcast(&src->pipeline_cond);
-	pthread_mutex_unlock(&src->pipeline_mutex);
+	atomic_store_explicit(&src->request_exit, true, memory_order_release);
+	cm_ring_bell(src);
 	pthread_join(src->pipeline_thread, NULL);
 	src->pipeline_thread_running = false;
 }
@@ -183,9 +193,10 @@ void cm_create(struct cm_source *src, obs_data_t *settings, obs_source_t *source
 	memset(src, 0, sizeof *src);
 	src->flags = flags;
 	src->self = source;
-	src->i_write_queue = 0; /* src/common.c:33-35 */
-	src->i_staging_queue = 0;
-	src->i_read_queue = CM_SURFACE_QUEUE_SIZE - 1;
+	atomic_init(&src->staged, 0); /* an empty ring: nothing published, nothing taken */
+	atomic_init(&src->taken, 0);
+	atomic_init(&src->done, 0);
+	atomic_init(&src->request_exit, false);
 	pthread_mutex_init(&src->pipeline_mutex, NULL);
 	pthread_cond_init(&src->pipeline_cond, NULL);
 	cm_update(src, settings);
@@ -217,17 +228,15 @@ void cm_tick(void *data, float unused)
 		cm_start_thread(src);
 }
 
-/* src/common.c:260-268: the consumer is a full ring behind -> this frame is not staged. */
+/* The consumer is a full ring behind -> this frame is not staged but dropped (the reference's rule, src/common.c:260-268).  With
+ * `staged - taken == CM_SURFACE_QUEUE_SIZE - 1` frames published and not yet started on, the next frame's slot is the one the
+ * consumer may still be reading (frame taken - 1). */
 static bool drop_if_behind(struct cm_source *src)
 {
-	pthread_mutex_lock(&src->pipeline_mutex);
-	const bool behind = src->i_write_queue == src->i_read_queue;
-	if (behind) {
-		src->i_staging_queue = -1;
+	const uint64_t n = atomic_load_explicit(&src->staged, memory_order_relaxed); /* only the producer moves it */
+	const bool behind = n - atomic_load_explicit(&src->taken, memory_order_acquire) >= CM_SURFACE_QUEUE_SIZE - 1;
+	if (behind)
 		src->frames_dropped++;
-		pthread_cond_broadcast(&src->pipeline_cond);
-	}
-	pthread_mutex_unlock(&src->pipeline_mutex);
 	return behind;
 }
 
@@ -241,7 +250,8 @@ bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t
 
 	if (drop_if_behind(src))
 		return false;
-	const int w = src->i_write_queue; /* only the producer moves it; the consumer never takes this slot */
+	const uint64_t n = atomic_load_explicit(&src->staged, memory_order_relaxed); /* this frame's number; slot n % N is the producer's */
+	const int w = (int)(n % CM_SURFACE_QUEUE_SIZE);
 
 	/* src/common.c:272-282: the ROI rectangle, when valid, selects the sub-rectangle that is staged */
 	uint32_t x = 0, y = 0, cx = width, cy = height;
@@ -280,13 +290,10 @@ bool cm_stage_surface(struct cm_source *src, const uint8_t *video_data, uint32_t
 	item->cb = src->callback;
 	item->cb_data = src->callback_data;
 
-	/* :322-329 -- the slot just staged stays off limits until the NEXT frame is staged (in the
-	 * reference its GPU->CPU copy is still in flight); cm_drain() releases it explicitly */
-	pthread_mutex_lock(&src->pipeline_mutex);
-	src->i_staging_queue = w;
-	src->i_write_queue = (w + 1) % CM_SURFACE_QUEUE_SIZE;
-	pthread_cond_broadcast(&src->pipeline_cond);
-	pthread_mutex_unlock(&src->pipeline_mutex);
+	/* publish: the slot's bytes and fields are written; the release store makes them the consumer's (which takes the frame at
+	 * once: nothing here is still in flight, unlike the reference's stage copy, src/common.c:322-329) */
+	atomic_store_explicit(&src->staged, n + 1, memory_order_release);
+	cm_ring_bell(src);
 	return true;
 }
 
@@ -359,11 +366,10 @@ bool cm_render_target(struct cm_source *src, const uint8_t *target_rgb, uint32_t
 
 void cm_drain(struct cm_source *src)
 {
+	/* every published frame has been through its callback (a source without a running thread has nobody to wait for) */
 	pthread_mutex_lock(&src->pipeline_mutex);
-	src->i_staging_queue = -1; /* as the reference does when it drops a frame, :262-264 */
-	pthread_cond_broadcast(&src->pipeline_cond);
 	while (src->pipeline_thread_running &&
-	       (src->busy || (src->i_read_queue + 1) % CM_SURFACE_QUEUE_SIZE != src->i_write_queue))
+	       atomic_load_explicit(&src->done, memory_order_acquire) != atomic_load_explicit(&src->staged, memory_order_acquire))
 		pthread_cond_wait(&src->pipeline_cond, &src->pipeline_mutex);
 	pthread_mutex_unlock(&src->pipeline_mutex);
 }

@@ -10,6 +10,7 @@
 #define SCOPE_COMMON_H
 
 #include <pthread.h>
+#include <stdatomic.h>
 
 #include "../../include/scope_hip.h"
 #include "obs_shim.h"
@@ -81,18 +82,25 @@ struct roi_source;
 /* src/common.h:48-87, minus everything that only exists to talk to libobs graphics */
 struct cm_source {
 	struct cm_surface_queue_item queue[CM_SURFACE_QUEUE_SIZE];
-	/* the ring's indices and the three flags below: every access that another thread can see happens under pipeline_mutex
-	 * (the reference marks them `volatile` and reads some of them bare, src/common.h:54-55,64-68; here the mutex is the
-	 * ordering, the consumer's wait is the condition variable's, and nothing is left to `volatile`) */
-	int i_write_queue, i_staging_queue;
-	int i_read_queue;
+	/* The ring is this build's own: a single-producer single-consumer SEQUENCE ring.  Frame k lives in slot k % CM_SURFACE_QUEUE_SIZE;
+	 * `staged` counts the frames the producer (the graphics thread) has published, `taken` the frames the consumer (the
+	 * source's "color-monitor" thread) has started on, `done` the frames whose callback has returned -- three monotonic C11
+	 * atomics: the producer publishes with a release store of `staged` behind the slot's bytes, the consumer acquires it; the
+	 * consumer's release stores of `taken` / `done` are what the producer's "am I a ring behind?" test and cm_drain acquire.
+	 * The mutex and the condition variable are only a doorbell for sleeping (nobody's data is ordered by them).
+	 * What is kept of the reference's ring (src/common.h:46,54-55, src/common.c:260-268): three slots, and a frame is DROPPED,
+	 * not queued, when the consumer is a full ring behind (staged - taken == 2: slot (taken - 1) % 3 may still be read).  What is
+	 * not: its three `volatile` indices read bare, and the slot held back until the NEXT frame is staged (i_staging_queue: in
+	 * the reference that slot's GPU -> host copy is still in flight; here a staged slot's bytes are there when it is published,
+	 * so the consumer takes the newest frame at once -- one frame less latency, and the last frame of a stream is not left
+	 * waiting for a successor). */
+	_Atomic uint64_t staged, taken, done;
 
 	pthread_t pipeline_thread;
-	pthread_mutex_t pipeline_mutex;
+	pthread_mutex_t pipeline_mutex; /* the doorbell: sleeping and waking only */
 	pthread_cond_t pipeline_cond;
 	bool pipeline_thread_running; /* start / stop / drain: the thread that ticks the source (the graphics thread) */
-	bool request_exit;
-	bool busy; /* the consumer is inside a callback (cm_drain waits for it) */
+	_Atomic bool request_exit;
 
 	cm_surface_cb_t callback;
 	void *callback_data;
