@@ -349,9 +349,8 @@ def run_rank(args):
         p_rf = roofline(wl, pw.algo_bytes, 1, med(p_kus) * 1e-3, p_ms, None)
         f_rf = roofline(wl, work.algo_bytes, 1, med(first_kus) * 1e-3, f_ms, None)
         placement = {"candidates": args.placement_candidates, "pool": src_name,
-                     "by": "scope_frame_pool_alloc (C-ABI): ONE physical allocation mapped at `candidates` address ranges in turn "
-                           "(hipMemCreate / hipMemMap), each read by the vectorscope accumulation kernel in three interleaved rounds "
-                           "(own begin/end stamps), mapped for good at the best; untimed set-up",
+                     "by": "scope_frame_pool_alloc (C-ABI): `candidates` plain allocations held at once, each read by the vectorscope "
+                           "accumulation kernel in three interleaved rounds (own begin/end stamps), the best median kept; untimed set-up",
                      "pool_read_gbps": rates, "value": round(n * w * h / (p_ms * 1e-3) / 1e9, 3), "ms_per_step": round(p_ms, 4),
                      "frac": p_rf["frac"], "frac_kernel": p_rf["frac_kernel"], "avg_launch_ms": p_rf["avg_launch_ms"], "parity": bool(p_ok),
                      "measured": "three alternating rounds of the K steps on the process's first pool and on the placed pool; medians",

@@ -381,11 +381,11 @@ int scope_rccl_comm_info(void *rccl_comm, int *n_ranks, int *rank, int *version)
 
 /* ---- frame pools ----------------------------------------------------------------------------
  * Where a long-lived pool of frames lies in HBM decides a few per cent of every streaming kernel's rate on this chip
- * (profiles/HISTORY.md section 5: allocations come in fast and slow physical ranges, +-2.5 %, and the first ones a process makes
- * are regularly the slow ones).  A host that keeps frames resident -- a ring of staged surfaces, a batch it reduces again
- * and again -- can let the library look before it settles: scope_frame_pool_alloc makes up to `candidates` device
- * allocations of `bytes` (all held at the same time: candidates x bytes of HBM for a few milliseconds), reads each with the
- * vectorscope accumulation kernel itself (the bytes taken as frames; timed by the kernel's own begin / end stamps), keeps the
+ * (pools read at 0.79 ... 0.86 of peak on some boxes, alike on others).  A host that keeps frames
+ * resident -- a ring of staged surfaces, a batch it reduces again and again -- can let the library look before it settles:
+ * scope_frame_pool_alloc makes up to `candidates` device allocations of `bytes` (all held at the same time: candidates x
+ * bytes of HBM for a few milliseconds), reads each with the vectorscope accumulation kernel itself in three interleaved
+ * rounds (the bytes taken as frames; timed by the kernel's own begin / end stamps; the median round decides), keeps the
  * fastest and frees the rest.
  * candidates <= 1 is a plain allocation.  read_gbps (optional, room for `candidates` floats) receives the measured rates,
  * the kept allocation's first; *tried (optional) how many were made (fewer than asked for when memory ran out).  The

@@ -14,21 +14,11 @@
 #include <math.h>
 #include <stdio.h>
 #include <mutex>
-#include <vector>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
 
 #define SCOPE_PROFILE_SLOTS 512u
-
-/* a frame pool scope_frame_pool_alloc mapped itself: one physical allocation (`handle`) at `va` inside an address reservation */
-struct ScopePoolRec {
-	void *va;
-	size_t size;
-	void *reserve_base;
-	size_t reserve_size;
-	unsigned long long handle; /* hipMemGenericAllocationHandle_t */
-};
 
 struct scope_ctx {
 	int device;
@@ -58,7 +48,6 @@ struct scope_ctx {
 	 * source, src/common.c:375-403).  Recursive: scope_surface_begin() keeps it until scope_surface_end(). */
 	std::recursive_mutex mu;
 	uint64_t stat_vss_rows, stat_his_rows, stat_vss_fold, stat_trio_fold; /* scope_ctx_get_stat: launches that took a form (tests) */
-	std::vector<ScopePoolRec> pools; /* pools scope_frame_pool_alloc mapped; a pool still there when the context goes is unmapped with it */
 	/* scope_surface_begin .. scope_surface_end: host planes uploaded once and reused by every scope call that is
 	 * handed the same plane (the ROI / dock fan-out) */
 	struct {
@@ -821,12 +810,6 @@ void scope_ctx_destroy(scope_ctx *ctx)
 		return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
-	for (const ScopePoolRec &rec : ctx->pools) { /* pools the host did not give back */
-		(void)hipMemUnmap(rec.va, rec.size);
-		(void)hipMemRelease((hipMemGenericAllocationHandle_t)(uintptr_t)rec.handle);
-		(void)hipMemAddressFree(rec.reserve_base, rec.reserve_size);
-	}
-	ctx->pools.clear();
 	if (ctx->partial)
 		(void)hipFree(ctx->partial);
 	if (ctx->stage_in)
@@ -1473,17 +1456,22 @@ int scope_table_unpack_clamp_u16x2_u8(scope_ctx *ctx, const uint32_t *in, uint8_
 	return SCOPE_OK;
 }
 
-/* ---- frame pools: WHICH ADDRESS RANGE a long-lived pool is mapped at decides a few per cent of every streaming kernel's rate ------
+/* ---- frame pools: WHICH ADDRESS RANGE a long-lived pool lies at decides a few per cent of every streaming kernel's rate ------------
  * Round 6's probe (tools/placement_vmm_probe.hip, profiles/round6/placement_vmm_probe_c6.txt): on a box whose pools spread over 8 %
  * the rate FOLLOWS THE VIRTUAL ADDRESS RANGE, not the physical memory -- two hipMemCreate handles that swap their addresses swap
- * their rates (0.856 <-> 0.809 of peak), the same handle reads 0.807 / 0.856 / 0.808 at three ranges, an offset of 2 or 64 MiB
- * inside a range changes nothing, the latency of dependent loads is the same on fast and slow ranges at every stride (it is not
- * the size of the page-table fragments), and one 24 GiB mapping reads the same in every 2 GiB window.  So the search needs ONE
- * physical allocation: it is mapped at up to `candidates` ranges of one address reservation in turn, each read a few times by
- * the vectorscope accumulation kernel (three interleaved rounds, the kernel's own begin / end stamps, the fastest launch of a
- * round counts, the median round decides), and stays at the best.  Nothing is copied, and candidates x bytes of HBM are never held.
- * Where the driver has no virtual-memory calls (the CPU emulation; older stacks) the round-3 form runs instead: `candidates`
- * plain allocations held at once, each probed, the fastest kept. */
+ * their rates (0.856 <-> 0.809 of peak), an offset of 2 or 64 MiB inside a range changes nothing, the latency of dependent loads
+ * is the same on fast and slow ranges at every stride, one 24 GiB mapping reads the same in every 2 GiB window.  What a search
+ * needs, then, is candidates at DIFFERENT ADDRESS RANGES -- which plain allocations held at the same time are: `candidates`
+ * hipMalloc'ed pools, each read by the vectorscope accumulation kernel in THREE INTERLEAVED ROUNDS (the kernel's own begin / end
+ * stamps, the fastest launch of a round counts, the median round decides: a ranking by one pass each, rounds 3-5's, is within
+ * the noise of a box whose ranges read alike), the best kept, the rest freed.  candidates x bytes of HBM are held for a few
+ * milliseconds.
+ * Two forms on HIP's virtual-memory calls -- ONE physical allocation tried at several ranges, nothing held twice -- were built in
+ * round 6 and withdrawn: mapped at one range at a time and mapped anew at the best, the caller's first WRITE into the pool
+ * right after that hipMemMap took a GPU memory access fault in one call of five (tools/pool_stress.py; the default bench line
+ * aborted once in an evidence visit); aliased at all ranges at once, with the losers unmapped at the end, it never faulted but the
+ * surviving mapping read 3.5 % slower than a plain allocation (0.81 against 0.84 in three of three runs,
+ * profiles/round6/pool_search_s6_aliased.txt).  The virtual-memory calls stay in the probe tool. */
 namespace {
 
 struct PoolProbe {
@@ -1539,117 +1527,6 @@ float median3(float a, float b, float c)
 	return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b));
 }
 
-#ifndef SCOPE_POOL_VMM
-#define SCOPE_POOL_VMM 1 /* 0: the round-3 form only (A/B) */
-#endif
-
-/* ONE physical allocation tried at up to `candidates` address ranges.  SCOPE_OK with *pool set; SCOPE_EAGAIN (nothing allocated) when
- * the driver refuses a virtual-memory call: the caller falls back to plain allocations. */
-int pool_alloc_vmm(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **pool, float *rate /* [candidates] */, uint32_t *best_out,
-		   uint32_t *tried_out)
-{
-	if (!SCOPE_POOL_VMM)
-		return SCOPE_EAGAIN;
-	hipMemAllocationProp prop;
-	memset(&prop, 0, sizeof prop);
-	prop.type = hipMemAllocationTypePinned;
-	prop.location.type = hipMemLocationTypeDevice;
-	prop.location.id = ctx->device;
-	size_t gran = 0;
-	if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess) {
-		(void)hipGetLastError();
-		return SCOPE_EAGAIN;
-	}
-	const size_t two_mib = (size_t)2 << 20, gib = (size_t)1 << 30;
-	if (gran < two_mib)
-		gran = two_mib;
-	const size_t size = ((size_t)bytes + gran - 1) / gran * gran;
-	const size_t slot = (size + gib - 1) / gib * gib + gib; /* ranges a whole GiB and more apart */
-	hipMemGenericAllocationHandle_t h;
-	if (hipMemCreate(&h, size, &prop, 0) != hipSuccess) {
-		(void)hipGetLastError();
-		return SCOPE_EAGAIN;
-	}
-	void *base = NULL;
-	if (hipMemAddressReserve(&base, slot * candidates, two_mib, NULL, 0) != hipSuccess) {
-		(void)hipGetLastError();
-		(void)hipMemRelease(h);
-		return SCOPE_EAGAIN;
-	}
-	hipMemAccessDesc acc;
-	memset(&acc, 0, sizeof acc);
-	acc.location.type = hipMemLocationTypeDevice;
-	acc.location.id = ctx->device;
-	acc.flags = hipMemAccessFlagsProtReadWrite;
-	auto map_at = [&](uint32_t i) {
-		uint8_t *va = (uint8_t *)base + (size_t)i * slot;
-		if (hipMemMap(va, size, 0, h, 0) != hipSuccess)
-			return false;
-		if (hipMemSetAccess(va, size, &acc, 1) != hipSuccess) {
-			(void)hipMemUnmap(va, size);
-			return false;
-		}
-		return true;
-	};
-	PoolProbe pp;
-	hipEvent_t ev[2] = {NULL, NULL};
-	int rc = pool_probe_setup(ctx, bytes, &pp);
-	if (rc == SCOPE_OK && (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))
-		rc = fail(ctx, SCOPE_EIO, "hipEventCreate", hipGetLastError());
-	float r[3][SCOPE_POOL_MAX_CANDIDATES] = {{0}};
-	bool vmm_ok = true;
-	auto slot_at = [&](uint32_t i) { return (uint8_t *)base + (size_t)i * slot; };
-	/* The allocation is mapped at EVERY candidate range at once (one handle, several addresses) and stays mapped while the ranges
-	 * are read in turn; the losers are unmapped at the end, the winner's mapping is never touched again.  (Round 6's first form
-	 * mapped one range at a time and mapped the winner anew at the end: a kernel that WROTE the pool right after that last
-	 * hipMemMap -- the caller's first copy into it -- took a GPU memory access fault in one call of five, tools/pool_stress.py;
-	 * reads by the library's own probe launches never did.  A mapping is therefore never torn down and made again here.) */
-	uint32_t mapped = 0;
-	for (; rc == SCOPE_OK && mapped < candidates; mapped++)
-		if (!map_at(mapped))
-			break;
-	if (rc == SCOPE_OK && mapped == 0)
-		vmm_ok = false;
-	const uint32_t nc = mapped; /* a driver that refuses to alias a handle leaves one range: a plain allocation's worth */
-	if (rc == SCOPE_OK && vmm_ok && pp.probe_bytes && nc > 1) {
-		/* what the physical memory holds is anybody's: a known content, once (every range shows the same bytes) */
-		if (hipMemsetAsync(slot_at(0), 0x5a, size, ctx->stream) != hipSuccess)
-			rc = fail(ctx, SCOPE_EIO, "hipMemsetAsync", hipGetLastError());
-		for (int round = 0; round < 3 && rc == SCOPE_OK; round++)
-			for (uint32_t i = 0; i < nc && rc == SCOPE_OK; i++)
-				rc = pool_probe(ctx, &pp, slot_at(i), ev, round == 0 ? 2 : 1, 4, &r[round][i]);
-	}
-	uint32_t best = 0;
-	for (uint32_t i = 0; i < nc; i++) {
-		rate[i] = median3(r[0][i], r[1][i], r[2][i]);
-		if (rate[i] > rate[best])
-			best = i;
-	}
-	(void)hipDeviceSynchronize(); /* nothing of any stream may still read a range that goes away */
-	for (uint32_t i = 0; i < mapped; i++)
-		if ((rc != SCOPE_OK || !vmm_ok || i != best) && hipMemUnmap(slot_at(i), size) != hipSuccess)
-			vmm_ok = false;
-	(void)hipDeviceSynchronize();
-	if (ev[0])
-		(void)hipEventDestroy(ev[0]);
-	if (ev[1])
-		(void)hipEventDestroy(ev[1]);
-	if (rc != SCOPE_OK || !vmm_ok) {
-		(void)hipGetLastError();
-		if (rc == SCOPE_OK && mapped) /* (an unmap failed: the winner is still mapped) */
-			(void)hipMemUnmap(slot_at(best), size);
-		(void)hipMemAddressFree(base, slot * candidates);
-		(void)hipMemRelease(h);
-		return rc != SCOPE_OK ? rc : SCOPE_EAGAIN;
-	}
-	ScopePoolRec rec = {(uint8_t *)base + (size_t)best * slot, size, base, slot * candidates, (unsigned long long)(uintptr_t)h};
-	ctx->pools.push_back(rec);
-	*pool = rec.va;
-	*best_out = best;
-	*tried_out = nc;
-	return SCOPE_OK;
-}
-
 } // namespace
 
 int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, void **pool, float *read_gbps,
@@ -1667,53 +1544,43 @@ int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, 
 		candidates = 1;
 	if (candidates > SCOPE_POOL_MAX_CANDIDATES)
 		candidates = SCOPE_POOL_MAX_CANDIDATES;
-	float rate[SCOPE_POOL_MAX_CANDIDATES] = {0};
+	void *cand[SCOPE_POOL_MAX_CANDIDATES] = {NULL};
+	float rate[SCOPE_POOL_MAX_CANDIDATES] = {0}, r[3][SCOPE_POOL_MAX_CANDIDATES] = {{0}};
+	hipEvent_t ev[2] = {NULL, NULL};
+	PoolProbe pp;
+	memset(&pp, 0, sizeof pp);
+	int rc = candidates > 1 ? pool_probe_setup(ctx, bytes, &pp) : SCOPE_OK;
+	if (rc == SCOPE_OK && candidates > 1 && (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))
+		rc = fail(ctx, SCOPE_EIO, "hipEventCreate", hipGetLastError());
+	/* all candidates are held at once: freeing one and allocating again hands out the same address range again */
 	uint32_t n = 0, best = 0;
-	int rc = SCOPE_OK;
-	if (candidates > 1) {
-		rc = pool_alloc_vmm(ctx, bytes, candidates, pool, rate, &best, &n);
-		if (rc == SCOPE_OK)
-			;
-		else if (rc != SCOPE_EAGAIN)
-			return rc;
-	}
-	if (!*pool) {
-		/* plain allocations, all held at once (freeing one and allocating again hands out the same virtual range again), each
-		 * probed; the fastest stays */
-		void *cand[SCOPE_POOL_MAX_CANDIDATES] = {NULL};
-		hipEvent_t ev[2] = {NULL, NULL};
-		PoolProbe pp;
-		rc = candidates > 1 ? pool_probe_setup(ctx, bytes, &pp) : SCOPE_OK;
-		if (rc == SCOPE_OK && candidates > 1 && (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))
-			rc = fail(ctx, SCOPE_EIO, "hipEventCreate", hipGetLastError());
-		for (; rc == SCOPE_OK && n < candidates; n++) {
-			const hipError_t e = hipMalloc(&cand[n], (size_t)bytes);
-			if (e != hipSuccess) {
-				cand[n] = NULL;
-				(void)hipGetLastError(); /* the launchers end with hipGetLastError(): a stale out-of-memory must not fail the next one */
-				if (n == 0)
-					rc = fail(ctx, SCOPE_ENOMEM, "hipMalloc (frame pool)", e);
-				break; /* fewer candidates than asked for: the best of those there are */
-			}
-			if (candidates == 1 || pp.probe_bytes == 0)
-				continue; /* nothing to compare */
-			rc = pool_probe(ctx, &pp, cand[n], ev, 3, 5, &rate[n]);
-			if (rate[n] > rate[best])
-				best = n;
+	for (; rc == SCOPE_OK && n < candidates; n++) {
+		const hipError_t e = hipMalloc(&cand[n], (size_t)bytes);
+		if (e != hipSuccess) {
+			cand[n] = NULL;
+			(void)hipGetLastError(); /* the launchers end with hipGetLastError(): a stale out-of-memory must not fail the next one */
+			if (n == 0)
+				rc = fail(ctx, SCOPE_ENOMEM, "hipMalloc (frame pool)", e);
+			break; /* fewer candidates than asked for: the best of those there are */
 		}
-		if (rc == SCOPE_OK) {
-			*pool = cand[best];
-			cand[best] = NULL;
-		}
-		for (uint32_t i = 0; i < SCOPE_POOL_MAX_CANDIDATES; i++)
-			if (cand[i])
-				(void)hipFree(cand[i]);
-		if (ev[0])
-			(void)hipEventDestroy(ev[0]);
-		if (ev[1])
-			(void)hipEventDestroy(ev[1]);
+		/* a known content in every candidate (what fresh memory holds is anybody's, and the kernel's rate depends on it) */
+		if (candidates > 1 && pp.probe_bytes && hipMemsetAsync(cand[n], 0x5a, (size_t)bytes, ctx->stream) != hipSuccess)
+			rc = fail(ctx, SCOPE_EIO, "hipMemsetAsync (frame pool)", hipGetLastError());
 	}
+	if (rc == SCOPE_OK && n > 1 && pp.probe_bytes) {
+		for (int round = 0; round < 3 && rc == SCOPE_OK; round++)
+			for (uint32_t i = 0; i < n && rc == SCOPE_OK; i++)
+				rc = pool_probe(ctx, &pp, cand[i], ev, round == 0 ? 2 : 1, 4, &r[round][i]);
+		for (uint32_t i = 0; i < n; i++) {
+			rate[i] = median3(r[0][i], r[1][i], r[2][i]);
+			if (rate[i] > rate[best])
+				best = i;
+		}
+	}
+	(void)hipStreamSynchronize(ctx->stream);
 	if (rc == SCOPE_OK) {
+		*pool = cand[best];
+		cand[best] = NULL;
 		if (tried)
 			*tried = n;
 		if (read_gbps) {
@@ -1724,6 +1591,13 @@ int scope_frame_pool_alloc(scope_ctx *ctx, uint64_t bytes, uint32_t candidates, 
 					read_gbps[k++] = rate[i];
 		}
 	}
+	for (uint32_t i = 0; i < SCOPE_POOL_MAX_CANDIDATES; i++)
+		if (cand[i])
+			(void)hipFree(cand[i]);
+	if (ev[0])
+		(void)hipEventDestroy(ev[0]);
+	if (ev[1])
+		(void)hipEventDestroy(ev[1]);
 	return rc;
 }
 
@@ -1732,21 +1606,7 @@ int scope_frame_pool_free(scope_ctx *ctx, void *pool)
 	SCOPE_ENTER(ctx);
 	if (st)
 		return st;
-	if (!pool)
-		return SCOPE_OK;
-	for (size_t i = 0; i < ctx->pools.size(); i++)
-		if (ctx->pools[i].va == pool) {
-			const ScopePoolRec rec = ctx->pools[i];
-			ctx->pools.erase(ctx->pools.begin() + (long)i);
-			(void)hipStreamSynchronize(ctx->stream);
-			const bool ok = hipMemUnmap(rec.va, rec.size) == hipSuccess;
-			const bool ok2 = hipMemRelease((hipMemGenericAllocationHandle_t)(uintptr_t)rec.handle) == hipSuccess;
-			const bool ok3 = hipMemAddressFree(rec.reserve_base, rec.reserve_size) == hipSuccess;
-			if (!(ok && ok2 && ok3))
-				return fail(ctx, SCOPE_EIO, "frame pool: unmap / release / address free", hipGetLastError());
-			return SCOPE_OK;
-		}
-	if (hipFree(pool) != hipSuccess)
+	if (pool && hipFree(pool) != hipSuccess)
 		return fail(ctx, SCOPE_EIO, "hipFree (frame pool)", hipGetLastError());
 	return SCOPE_OK;
 }

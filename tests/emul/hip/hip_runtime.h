@@ -87,52 +87,6 @@ hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st);
-/* HIP's virtual-memory calls: the emulation has none (scope_frame_pool_alloc then takes its plain-allocation form) */
-typedef void *hipMemGenericAllocationHandle_t;
-enum { hipMemAllocationTypePinned = 1, hipMemLocationTypeDevice = 1, hipMemAccessFlagsProtReadWrite = 3, hipMemAllocationGranularityRecommended = 1 };
-struct hipMemLocation {
-	int type, id;
-};
-struct hipMemAllocationProp {
-	int type;
-	hipMemLocation location;
-};
-struct hipMemAccessDesc {
-	hipMemLocation location;
-	int flags;
-};
-static inline hipError_t hipMemGetAllocationGranularity(size_t *, const hipMemAllocationProp *, int)
-{
-	return 801; /* hipErrorNotSupported */
-}
-static inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *, size_t, const hipMemAllocationProp *, unsigned long long)
-{
-	return 801;
-}
-static inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t)
-{
-	return 801;
-}
-static inline hipError_t hipMemAddressReserve(void **, size_t, size_t, void *, unsigned long long)
-{
-	return 801;
-}
-static inline hipError_t hipMemAddressFree(void *, size_t)
-{
-	return 801;
-}
-static inline hipError_t hipMemMap(void *, size_t, size_t, hipMemGenericAllocationHandle_t, unsigned long long)
-{
-	return 801;
-}
-static inline hipError_t hipMemUnmap(void *, size_t)
-{
-	return 801;
-}
-static inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t)
-{
-	return 801;
-}
 hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind k,
 			    hipStream_t st);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st);
