@@ -43,6 +43,9 @@ def test_documents_quote_exactly_what_the_kept_files_give():
     ns, calls = make_tables.rocprof_avg_ns(tag, fp, "headline_only")
     assert calls > 1000 and abs(algo / (ns * 1e-9) / 1e9 / 8000.0 - line["roofline"]["frac_kernel"]) < 0.04, \
         "rocprofv3's average of the headline kernel agrees with the line's own stamps (another process, another pool: a few per cent)"
+    # the SQ counters are the accumulation kernel's, not those of the K0 launches that prepared the frames in the same process
+    valu = make_tables.sq(fp, "three_scope_x64_uniform", "SQ_INSTS_VALU")
+    assert valu is not None and 15.0 < valu * 64 / (64 * 3840 * 2160) < 40.0, "SQ_INSTS_VALU per texel of the three-scope kernel"
     assert f"`{fp}`" in block and f"**{line['value']:.0f}**" in block and f"**{line['roofline']['frac']:.3f}**" in block
 
 
