@@ -361,6 +361,10 @@ def run_rank(args):
         rf["frac_kernel_first_pool_same_rounds"] = f_rf["frac_kernel"]
         rf["frac_placed"] = p_rf["frac"]
         rf["frac_kernel_placed"] = p_rf["frac_kernel"]
+        # what the search is worth: placed pool over first pool INSIDE the same alternating rounds (both legs run a minute after the
+        # headline, when the chip reads 3-4 % slower: neither compares with `frac`)
+        rf["placed_over_first_same_rounds"] = round(p_rf["frac"] / f_rf["frac"], 4) if f_rf["frac"] else None
+        rf["placed_over_first_same_rounds_kernel"] = round(p_rf["frac_kernel"] / f_rf["frac_kernel"], 4) if f_rf["frac_kernel"] else None
         parity = parity and bool(p_ok)
         del pw, placed
         dev.sync()

@@ -468,7 +468,8 @@ def compact_line(result, detail=None):
     if rf:
         r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "achieved_kernel", "frac_kernel", "avg_launch_ms",
                        "launches_timed", "algorithmic_bytes_per_launch", "traffic", "frac_placed", "frac_kernel_placed",
-                        "frac_first_pool_same_rounds", "frac_kernel_first_pool_same_rounds"))
+                        "frac_first_pool_same_rounds", "frac_kernel_first_pool_same_rounds", "placed_over_first_same_rounds",
+                        "placed_over_first_same_rounds_kernel"))
         r["kernel"] = _short(r.get("kernel"), 40)
         r["traffic_source"] = _short(rf.get("traffic_source"), 60)
         out["roofline"] = r
