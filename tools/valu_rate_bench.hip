@@ -108,6 +108,72 @@ OPKERNEL(cvtub, )
 	asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(c[j]) : "v"(a), "v"(b));
 OPKERNEL(addsdwa, )
 
+#define STEP_or(j) asm volatile("v_or_b32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(or, )
+#define STEP_xor(j) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(xor, )
+#define STEP_sub(j) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(sub, )
+#define STEP_lshl(j) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(lshl, )
+#define STEP_ashr(j) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(ashr, )
+#define STEP_addf(j) asm volatile("v_add_f32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(addf, )
+#define STEP_minf(j) asm volatile("v_min_f32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(minf, )
+#define STEP_maxf(j) asm volatile("v_max_f32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(maxf, )
+#define STEP_fmac(j) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(fmac, )
+#define STEP_cvtu32(j) asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(cvtu32, )
+#define STEP_cvtf32(j) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(cvtf32, )
+#define STEP_cvtub0(j) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(cvtub0, )
+#define STEP_lshlor(j) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(lshlor, )
+#define STEP_or3(j) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(or3, )
+#define STEP_xad(j) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(xad, )
+#define STEP_max(j) asm volatile("v_max_u32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(max, )
+#define STEP_cndmask2(j) asm volatile("v_cndmask_b32 %0, %0, %1, s[10:11]" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(cndmask2, )
+#define STEP_addco(j) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b) : "vcc");
+OPKERNEL(addco, )
+#define STEP_mbcnt(j) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(mbcnt, )
+#define STEP_sad(j) asm volatile("v_sad_u32 %0, %0, %1, %2" : "+v"(c[j]) : "v"(a), "v"(b));
+OPKERNEL(sad, )
+/* two-dword results: each lane's chain is a register pair */
+#define PKKERNEL(name, ASM)                                                                                                       \
+	__global__ void __launch_bounds__(1024) k_##name(u32 iters, u32 *out, unsigned long long *clk)                           \
+	{                                                                                                                         \
+		typedef float f2 __attribute__((ext_vector_type(2)));                                                             \
+		f2 c[8], a = {1.0000001f, 0.9999999f}, b = {1e-9f, -1e-9f};                                                        \
+		for (int j = 0; j < 8; j++)                                                                                       \
+			c[j] = (f2){(float)(threadIdx.x + j), (float)(blockIdx.x + j)};                                           \
+		asm volatile("" : "+v"(a), "+v"(b));                                                                              \
+		for (u32 it = 0; it < iters; it++) {                                                                              \
+			R128(STEP_##name)                                                                                         \
+		}                                                                                                                 \
+		float s = 0;                                                                                                      \
+		for (int j = 0; j < 8; j++)                                                                                       \
+			s += c[j].x + c[j].y;                                                                                     \
+		out[blockIdx.x * blockDim.x + threadIdx.x] = __float_as_uint(s);                                                   \
+		if (threadIdx.x == 0)                                                                                             \
+			clk[blockIdx.x] = 0;                                                                                      \
+	}
+#define STEP_pkfma(j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(c[j]) : "v"(a), "v"(b));
+PKKERNEL(pkfma, )
+#define STEP_pkmulf(j) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+PKKERNEL(pkmulf, )
+#define STEP_pkaddf(j) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(c[j]) : "v"(a), "v"(b));
+PKKERNEL(pkaddf, )
+
 typedef void (*kern_t)(u32, u32 *, unsigned long long *);
 
 static void run(const char *name, kern_t k, int num_cu, u32 *out, unsigned long long *clk)
@@ -184,5 +250,28 @@ int main()
 	RUN(cmp);
 	RUN(cndmask);
 	RUN(cvtub);
+	RUN(or);
+	RUN(xor);
+	RUN(sub);
+	RUN(lshl);
+	RUN(ashr);
+	RUN(addf);
+	RUN(minf);
+	RUN(maxf);
+	RUN(fmac);
+	RUN(pkfma);
+	RUN(pkmulf);
+	RUN(pkaddf);
+	RUN(cvtu32);
+	RUN(cvtf32);
+	RUN(cvtub0);
+	RUN(lshlor);
+	RUN(or3);
+	RUN(xad);
+	RUN(max);
+	RUN(cndmask2);
+	RUN(addco);
+	RUN(mbcnt);
+	RUN(sad);
 	return 0;
 }
